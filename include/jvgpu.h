@@ -1,0 +1,185 @@
+/*
+ * jvgpu.h — C ABI of the MI355X-native jVector graph-search engine.
+ *
+ * This is the drop-in boundary for ONE path of opensearch-project/opensearch-jvector:
+ *   JVectorKnnFloatVectorQuery.approximateSearch -> JVectorReader.search -> jvector GraphSearcher.search
+ * Every entry point below states the reference call site it replaces (paths relative to the
+ * reference repo root; J/ = src/main/java/org/opensearch/knn/index/codec/jvector/).
+ *
+ * Plain C: pointers + sizes only, no C++/torch types.  All functions return 0 (JV_OK) or a
+ * negative jv_status; the message for the calling thread's last failure is jv_last_error().
+ * No function aborts the process.
+ *
+ * Threading: jv_search / jv_search_batch* are re-entrant on one handle (the reference calls
+ * JVectorReader.search concurrently from Lucene's per-leaf search threads:
+ * src/test/java/org/opensearch/knn/index/codec/jvector/KNNJVectorTests.java:982-1027).
+ * jv_index_create / jv_index_destroy are single-threaded per handle, like the reference's
+ * FieldEntry constructor / close (J/JVectorReader.java:284-337, :367-378).
+ */
+#ifndef JVGPU_H
+#define JVGPU_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JVGPU_ABI_VERSION 1
+
+/* ---- status codes (the Java shim maps them to the reference's exception types,
+ *      SURVEY §8(b) "Errors": EINVAL -> IllegalArgumentException, EUNSUPPORTED ->
+ *      UnsupportedOperationException, EDEVICE/ENOMEM -> IOException) ---- */
+typedef enum jv_status {
+    JV_OK = 0,
+    JV_EINVAL = -1,
+    JV_ENOMEM = -2,
+    JV_EDEVICE = -3,
+    JV_EUNSUPPORTED = -4,
+    JV_EINTERNAL = -5
+} jv_status;
+
+/* ---- similarity: jvector VectorSimilarityFunction ordinals as mapped by
+ *      VectorSimilarityMapper (J/JVectorReader.java:384-432): Lucene EUCLIDEAN->0,
+ *      DOT_PRODUCT->1, COSINE->2, MAXIMUM_INNER_PRODUCT->1 (with score_scale = 2 when the
+ *      field has no PQ, J/JVectorReader.java:220-239,359-364). ---- */
+typedef enum jv_similarity {
+    JV_SIM_EUCLIDEAN = 0,   /* score = 1 / (1 + sum (a-b)^2)            */
+    JV_SIM_DOT_PRODUCT = 1, /* score = (1 + sum a*b) / 2                */
+    JV_SIM_COSINE = 2       /* score = (1 + dot / sqrt(|a|^2 |b|^2)) / 2 */
+} jv_similarity;
+
+/* ---- descriptor flags ---- */
+#define JV_DESC_DEVICE_POINTERS 0x1u /* vectors/adj/pq_codes/ord2doc already live in HBM on `device` */
+#define JV_DESC_BORROW          0x2u /* with DEVICE_POINTERS: do not copy, caller keeps them alive   */
+#define JV_DESC_FUSED_ADC       0x4u /* also build the fused layout: per node, its neighbours' PQ codes
+                                        stored next to its adjacency row (a layout choice; scores are
+                                        bit-identical to the plain layout)                            */
+
+/* One upper layer of a hierarchical graph (hierarchy_enabled; default false:
+ * K/common/KNNConstants.java:109).  Layer 0 is the dense adj[n][R] array below. */
+typedef struct jv_layer_desc {
+    int32_t count;        /* nodes present in this layer                                   */
+    int32_t degree;       /* row stride of `adj`                                           */
+    const int32_t* nodes; /* [count] ordinals, strictly ascending                          */
+    const int32_t* adj;   /* [count][degree] neighbour ordinals, -1 padded                 */
+} jv_layer_desc;
+
+/* Everything FieldEntry holds after OnDiskGraphIndex.load + PQVectors.load
+ * (J/JVectorReader.java:284-337; J/JVectorIndexQuantization.java:68-89,166-186),
+ * flattened.  The library copies what it needs to HBM before jv_index_create returns
+ * (unless JV_DESC_BORROW); the caller may free its arrays immediately. */
+typedef struct jv_index_desc {
+    uint32_t struct_size; /* sizeof(jv_index_desc), for ABI evolution                      */
+    uint32_t flags;       /* JV_DESC_*                                                     */
+    int32_t device;       /* HIP device ordinal                                            */
+    int32_t n;            /* graph nodes (ordinals 0..n-1)                                 */
+    int32_t d;            /* vector dimension                                              */
+    int32_t R;            /* layer-0 max degree = row stride of adj                        */
+    int32_t similarity;   /* jv_similarity                                                 */
+    float score_scale;    /* 1, or 2 for Lucene MAXIMUM_INNER_PRODUCT without PQ           */
+    int32_t entry_node;   /* view.entryNode().node; -1 => empty index                      */
+    int32_t num_upper_layers;          /* 0 when hierarchy is off                          */
+    const jv_layer_desc* upper_layers; /* [num_upper_layers], index 0 = layer 1            */
+    const float* vectors;   /* [n][d] inline full-precision vectors                        */
+    const int32_t* adj;     /* [n][R] neighbour ordinals in stored order, -1 padded        */
+    /* product quantisation (pq_M == 0 => exact-only index) */
+    int32_t pq_M;                 /* subspaces                                             */
+    int32_t pq_K;                 /* clusters per subspace, <= 256                         */
+    const int32_t* pq_sub_sizes;  /* [pq_M] or NULL => jvector's even split (d/M, first d%M get +1) */
+    const float* pq_codebooks;    /* concat over m of [pq_K][sub_size[m]]                  */
+    const float* pq_centroid;     /* [d] global centroid or NULL                           */
+    const uint8_t* pq_codes;      /* [n][pq_M]                                             */
+    /* ordinal -> Lucene doc id (GraphNodeIdToDocMap, J/GraphNodeIdToDocMap.java:147-161) */
+    const int32_t* ord2doc;       /* [n] or NULL => identity                               */
+    int32_t max_doc;              /* doc-id space size (for accept bitsets)                */
+    int32_t reserved;
+} jv_index_desc;
+
+typedef struct jv_index jv_index; /* opaque handle */
+
+/* Per-query counters, in the order the reference reads them from SearchResult
+ * (J/JVectorReader.java:183-187) and adds to KNNCounter (:189-192). */
+enum { JV_STAT_VISITED = 0, JV_STAT_RERANKED = 1, JV_STAT_EXPANDED = 2, JV_STAT_EXPANDED_BASE = 3, JV_NUM_STATS = 4 };
+
+/* Extended per-query status written to out_flags by the batch calls. */
+#define JV_QFLAG_RETRIED_BIG 0x1 /* on-chip scratch overflowed; query was re-run on the HBM-scratch variant */
+
+/* Replaces: FieldEntry constructor (J/JVectorReader.java:284-337) — once per segment x field. */
+int jv_index_create(const jv_index_desc* desc, jv_index** out);
+
+/* Replaces: FieldEntry.close (J/JVectorReader.java:367-378).  NULL is a no-op. */
+void jv_index_destroy(jv_index* index);
+
+/* Replaces: the body of JVectorReader.search, J/JVectorReader.java:147-177, i.e.
+ *   buildScoreFunctionProvider(q, view)  (:152, :352-365)
+ *   acceptOrds lambda                    (:157-163)  -> accept_doc_words (doc-space bitset, bit = doc id;
+ *                                                       NULL => accept all, like `acceptDocs == null`)
+ *   GraphSearcher.search(ssp, topK, rerankK, threshold, rerankFloor, acceptOrds)  (:165-173)
+ * Outputs: up to topK (ordinal, score) pairs in descending score order, ties by ascending
+ * ordinal; out_docs (optional) = ord2doc[ordinal] as the reference's collect loop does (:175-177);
+ * out_stats[JV_NUM_STATS] = visited, reranked, expanded, expandedBaseLayer (:183-187).
+ * rerankK < topK -> JV_EINVAL (jvector throws IllegalArgumentException). */
+int jv_search(jv_index* index, const float* query, int32_t topK, int32_t rerankK, float threshold,
+              float rerankFloor, const uint64_t* accept_doc_words, int64_t accept_num_docs,
+              int32_t* out_nodes, int32_t* out_docs, float* out_scores, int32_t* out_count,
+              int32_t* out_stats);
+
+/* nq independent searches with shared parameters (the GPU's natural unit of work; the reference
+ * has no batch call — Lucene issues one search per leaf per thread).  Row-major outputs:
+ * out_nodes/out_docs/out_scores [nq][topK], out_count [nq], out_stats [nq][JV_NUM_STATS].
+ * Unused tail entries of a row are ordinal/doc -1 and score 0.  Host pointers. */
+int jv_search_batch(jv_index* index, const float* queries, int32_t nq, int32_t topK, int32_t rerankK,
+                    float threshold, float rerankFloor, const uint64_t* accept_doc_words,
+                    int64_t accept_num_docs, int32_t* out_nodes, int32_t* out_docs, float* out_scores,
+                    int32_t* out_count, int32_t* out_stats);
+
+/* Same, but every pointer is a DEVICE pointer on the index's device and the work is enqueued on
+ * `hip_stream` (a hipStream_t passed as void*; NULL = the library's own stream, synchronous).
+ * With a caller stream the call returns after enqueueing; results are valid after the caller
+ * synchronises that stream.  Queries that overflow the on-chip scratch are reported through
+ * out_flags (bit 31 set = needs retry) and must be resolved with jv_search_batch_device_finish. */
+int jv_search_batch_device(jv_index* index, const float* d_queries, int32_t nq, int32_t topK,
+                           int32_t rerankK, float threshold, float rerankFloor,
+                           const uint64_t* d_accept_doc_words, int64_t accept_num_docs,
+                           int32_t* d_out_nodes, int32_t* d_out_docs, float* d_out_scores,
+                           int32_t* d_out_count, int32_t* d_out_stats, int32_t* d_out_flags,
+                           void* hip_stream);
+
+/* Replaces (next-scope row f1): JVectorVectorScorer.score (J/JVectorVectorScorer.java:36-53) — the
+ * exact scorer Lucene falls back to for selective filters: score `count` ordinals against one query.
+ * Scores carry score_scale exactly like the search path. Host pointers. */
+int jv_score_ordinals(jv_index* index, const float* query, const int32_t* ordinals, int32_t count,
+                      float* out_scores);
+
+/* Merge per-shard top-k lists (the step Lucene's TopDocs.merge performs over leaves, and the
+ * exchange step of the doc-range sharded multi-GPU layout): `lists` rows of `k` (doc, score)
+ * pairs each (doc < 0 = empty slot) -> best k by (score desc, doc asc).  DEVICE pointers,
+ * nq independent merges. */
+int jv_merge_topk_device(int32_t device, const int32_t* d_docs, const float* d_scores, int32_t nq,
+                         int32_t lists, int32_t k, int32_t* d_out_docs, float* d_out_scores,
+                         void* hip_stream);
+
+/* Introspection used by the benchmark's roofline accounting. */
+typedef struct jv_index_info {
+    int32_t n, d, R, similarity, pq_M, pq_K, num_upper_layers, device;
+    int64_t hbm_bytes;          /* bytes resident in HBM for this index          */
+    int32_t row_stride_floats;  /* padded vector row stride                       */
+    int32_t fused_adc;          /* 1 if the fused layout is present               */
+} jv_index_info;
+int jv_index_get_info(const jv_index* index, jv_index_info* out);
+
+/* Tunables (process-wide, read at call time): name = "lds_visited_slots", "lds_candidates",
+ * "max_resident_queries", "force_big_path". Returns JV_EINVAL for unknown names. */
+int jv_set_option(const char* name, int64_t value);
+
+/* Thread-local message of the calling thread's most recent failing call ("" if none). */
+const char* jv_last_error(void);
+
+int jv_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JVGPU_H */

@@ -1,0 +1,705 @@
+// jv_abi.cpp — implementation of the C ABI in include/jvgpu.h on top of the HIP kernels.
+//
+// jv_index_create copies the flattened FieldEntry (J/JVectorReader.java:284-337) into HBM once;
+// jv_search* stage the query (4d bytes) and run the whole GraphSearcher.search
+// (J/JVectorReader.java:165-173) on the GPU.  There is NO CPU fallback anywhere in this file: if the
+// device or the kernels are unavailable every call fails with JV_EDEVICE.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/jvgpu.h"
+#include "jv_device.h"
+
+extern "C" {
+hipError_t jvk_set_max_lds(int pq, int big, int bytes);
+hipError_t jvk_launch_search_lds(const JvIndexDev* ix, const JvSearchArgs* a, int pq, int lds_bytes, hipStream_t s);
+hipError_t jvk_launch_search_big(const JvIndexDev* ix, const JvSearchArgs* a, int pq, int blocks, int lds_bytes,
+                                 int force_all, hipStream_t s);
+hipError_t jvk_launch_score_ordinals(const JvIndexDev* ix, const float* d_query, const int32_t* d_ordinals,
+                                     int count, float* d_out, hipStream_t s);
+hipError_t jvk_launch_merge_topk(const int32_t* d_docs, const float* d_scores, int nq, int lists, int k,
+                                 int32_t* d_out_docs, float* d_out_scores, hipStream_t s);
+}
+
+namespace {
+
+constexpr int kMaxLds = 160 * 1024;
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(e_ == hipErrorOutOfMemory ? JV_ENOMEM : JV_EDEVICE, "%s failed: %s", #expr, \
+                        hipGetErrorString(e_));                                                   \
+    } while (0)
+
+// process-wide tunables (jv_set_option)
+std::atomic<int64_t> opt_lds_visited_slots{0};  // 0 = auto
+std::atomic<int64_t> opt_lds_candidates{0};     // 0 = auto
+std::atomic<int64_t> opt_force_big{0};
+std::atomic<int64_t> opt_big_blocks{32};
+std::atomic<int64_t> opt_big_cand_cap{65536};
+
+int next_pow2(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+struct Ctx {
+    hipStream_t stream = nullptr;
+    hipEvent_t last_use = nullptr;
+    hipStream_t last_stream = nullptr;
+    // device staging for the host-pointer API
+    float* d_queries = nullptr;
+    size_t queries_cap = 0;  // floats
+    int32_t* d_nodes = nullptr;
+    int32_t* d_docs = nullptr;
+    float* d_scores = nullptr;
+    size_t out_cap = 0;  // nq*topK entries
+    int32_t* d_count = nullptr;
+    int32_t* d_stats = nullptr;
+    int32_t* d_flags = nullptr;
+    size_t nq_cap = 0;
+    uint64_t* d_accept = nullptr;
+    size_t accept_cap = 0;  // words
+    // big-path HBM scratch
+    uint32_t* big_visited = nullptr;
+    int64_t* big_cand = nullptr;
+    int32_t* work_counter = nullptr;
+    int big_blocks = 0;
+    int big_cand_cap = 0;
+    size_t big_words = 0;
+};
+
+}  // namespace
+
+struct jv_index {
+    int device = 0;
+    JvIndexDev dev{};
+    jv_index_info info{};
+    std::vector<void*> owned;  // device allocations to free
+    std::mutex mu;
+    std::vector<Ctx*> free_ctx;
+    std::vector<Ctx*> all_ctx;
+    Ctx* async_ctx = nullptr;
+    std::mutex async_mu;
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(jv_index* ix, T** out, size_t count) {
+    void* p = nullptr;
+    size_t bytes = count * sizeof(T);
+    if (bytes == 0) bytes = sizeof(T);
+    HIPCHK(hipMalloc(&p, bytes));
+    ix->owned.push_back(p);
+    ix->info.hbm_bytes += (int64_t)bytes;
+    *out = (T*)p;
+    return JV_OK;
+}
+
+int grow(void** p, size_t* cap, size_t need, size_t elem) {
+    if (need <= *cap && *p) return JV_OK;
+    if (*p) HIPCHK(hipFree(*p));
+    *p = nullptr;
+    size_t ncap = need < 16 ? 16 : need + need / 2;
+    HIPCHK(hipMalloc(p, ncap * elem));
+    *cap = ncap;
+    return JV_OK;
+}
+
+int ctx_create(jv_index* ix, Ctx** out) {
+    Ctx* c = new Ctx();
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->last_use, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->work_counter, sizeof(int32_t));
+    if (e != hipSuccess) {
+        delete c;
+        return fail(JV_EDEVICE, "context creation failed: %s", hipGetErrorString(e));
+    }
+    ix->all_ctx.push_back(c);
+    *out = c;
+    return JV_OK;
+}
+
+void ctx_destroy(Ctx* c) {
+    if (!c) return;
+    hipFree(c->d_queries);
+    hipFree(c->d_nodes);
+    hipFree(c->d_docs);
+    hipFree(c->d_scores);
+    hipFree(c->d_count);
+    hipFree(c->d_stats);
+    hipFree(c->d_flags);
+    hipFree(c->d_accept);
+    hipFree(c->big_visited);
+    hipFree(c->big_cand);
+    hipFree(c->work_counter);
+    if (c->last_use) hipEventDestroy(c->last_use);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int ctx_acquire(jv_index* ix, Ctx** out) {
+    {
+        std::lock_guard<std::mutex> lk(ix->mu);
+        if (!ix->free_ctx.empty()) {
+            *out = ix->free_ctx.back();
+            ix->free_ctx.pop_back();
+            return JV_OK;
+        }
+    }
+    std::lock_guard<std::mutex> lk(ix->mu);
+    return ctx_create(ix, out);
+}
+void ctx_release(jv_index* ix, Ctx* c) {
+    std::lock_guard<std::mutex> lk(ix->mu);
+    ix->free_ctx.push_back(c);
+}
+
+struct Geometry {
+    int hash_slots, cand_cap, res_cap;
+    int lds_fast, lds_big;
+    bool fast_ok;
+};
+
+// LDS carve of the fast path (must mirror search_one in jv_kernels.hip)
+Geometry plan_geometry(const jv_index* ix, int rk) {
+    Geometry g{};
+    const JvIndexDev& d = ix->dev;
+    const bool pq = d.pq_M > 0;
+    int fixed = d.nch * 64 * 4 + JV_TODO * 8 + (pq ? d.pq_M * 256 * 4 : 0);
+    g.lds_big = fixed;
+    g.res_cap = (rk + 1) & ~1;
+    if (g.res_cap < 2) g.res_cap = 2;
+    int64_t hs = opt_lds_visited_slots.load();
+    int64_t cc = opt_lds_candidates.load();
+    // visited ~ 25 x rerankK at R=32; keep the table <= 75 % full
+    g.hash_slots = hs > 0 ? next_pow2((int)hs) : next_pow2(rk * 40 < 1024 ? 1024 : rk * 40);
+    if (g.hash_slots > 32768) g.hash_slots = 32768;
+    g.cand_cap = cc > 0 ? (int)cc : (rk * 4 < 512 ? 512 : rk * 4);
+    if (g.cand_cap > 4096 && cc <= 0) g.cand_cap = 4096;
+    if (g.cand_cap < rk) g.cand_cap = rk;
+    g.cand_cap = (g.cand_cap + 1) & ~1;
+    auto total = [&]() { return (int64_t)fixed + (int64_t)g.res_cap * 8 + (int64_t)g.cand_cap * 8 + (int64_t)g.hash_slots * 4; };
+    while (total() > kMaxLds && g.hash_slots > 256 && hs <= 0) g.hash_slots >>= 1;
+    g.fast_ok = total() <= kMaxLds && fixed <= kMaxLds;
+    g.lds_fast = (int)total();
+    return g;
+}
+
+int ensure_big(jv_index* ix, Ctx* c, int rk) {
+    int blocks = (int)opt_big_blocks.load();
+    if (blocks < 1) blocks = 1;
+    int cap = (int)opt_big_cand_cap.load();
+    int res_cap = ((rk + 1) & ~1);
+    if (cap < 4 * rk) cap = 4 * rk;
+    cap += res_cap;
+    size_t words = ((size_t)ix->dev.n + 31) / 32;
+    if (words == 0) words = 1;
+    if (c->big_blocks != blocks || c->big_words != words) {
+        if (c->big_visited) HIPCHK(hipFree(c->big_visited));
+        c->big_visited = nullptr;
+        HIPCHK(hipMalloc((void**)&c->big_visited, (size_t)blocks * words * sizeof(uint32_t)));
+        c->big_words = words;
+    }
+    if (c->big_blocks != blocks || c->big_cand_cap < cap) {
+        if (c->big_cand) HIPCHK(hipFree(c->big_cand));
+        c->big_cand = nullptr;
+        HIPCHK(hipMalloc((void**)&c->big_cand, (size_t)blocks * (size_t)cap * sizeof(int64_t)));
+        c->big_cand_cap = cap;
+    }
+    c->big_blocks = blocks;
+    return JV_OK;
+}
+
+// enqueue one batch on `stream`; all pointers are device pointers
+int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queries, int nq, int topK, int rk,
+                  float thr, float floor_, const uint64_t* d_accept, int64_t accept_docs, int32_t* d_nodes,
+                  int32_t* d_docs, float* d_scores, int32_t* d_count, int32_t* d_stats, int32_t* d_flags) {
+    const bool pq = ix->dev.pq_M > 0;
+    Geometry g = plan_geometry(ix, rk);
+    if (g.lds_big > kMaxLds)
+        return fail(JV_EUNSUPPORTED, "query + PQ look-up table need %d B of LDS (> %d): pq_M=%d too large", g.lds_big,
+                    kMaxLds, ix->dev.pq_M);
+    int rc = ensure_big(ix, c, rk);
+    if (rc != JV_OK) return rc;
+    JvSearchArgs a{};
+    a.queries = d_queries;
+    a.qlist = nullptr;
+    a.nq = nq;
+    a.topK = topK;
+    a.rk = rk;
+    a.threshold = thr;
+    a.rerank_floor = floor_;
+    a.accept = d_accept;
+    a.accept_docs = accept_docs;
+    a.out_nodes = d_nodes;
+    a.out_docs = d_docs;
+    a.out_scores = d_scores;
+    a.out_count = d_count;
+    a.out_stats = d_stats;
+    a.out_flags = d_flags;
+    a.hash_slots = g.hash_slots;
+    a.cand_cap = g.cand_cap;
+    a.res_cap = g.res_cap;
+    a.big_visited = c->big_visited;
+    a.big_cand = c->big_cand;
+    a.big_cand_cap = c->big_cand_cap;
+    a.work_counter = c->work_counter;
+    const bool force_big = opt_force_big.load() != 0 || !g.fast_ok;
+    HIPCHK(hipMemsetAsync(c->work_counter, 0, sizeof(int32_t), stream));
+    if (!force_big) HIPCHK(jvk_launch_search_lds(&ix->dev, &a, pq ? 1 : 0, g.lds_fast, stream));
+    HIPCHK(jvk_launch_search_big(&ix->dev, &a, pq ? 1 : 0, c->big_blocks, g.lds_big, force_big ? 1 : 0, stream));
+    return JV_OK;
+}
+
+int check_common(jv_index* index, const void* q, int nq, int topK, int rk, float thr) {
+    if (!index) return fail(JV_EINVAL, "index is NULL");
+    if (!q && nq > 0) return fail(JV_EINVAL, "query pointer is NULL");
+    if (nq < 0 || topK < 0) return fail(JV_EINVAL, "negative nq/topK");
+    // jvector: "rerankK %d must be >= topK %d" -> IllegalArgumentException
+    if (rk < topK) return fail(JV_EINVAL, "rerankK %d must be >= topK %d", rk, topK);
+    if (thr > 0.0f)
+        return fail(JV_EUNSUPPORTED, "threshold queries (threshold > 0) are not implemented on the GPU path yet");
+    return JV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int jv_abi_version(void) { return JVGPU_ABI_VERSION; }
+
+const char* jv_last_error(void) { return g_last_error.c_str(); }
+
+int jv_set_option(const char* name, int64_t value) {
+    if (!name) return fail(JV_EINVAL, "option name is NULL");
+    std::string n(name);
+    if (n == "lds_visited_slots") opt_lds_visited_slots = value;
+    else if (n == "lds_candidates") opt_lds_candidates = value;
+    else if (n == "force_big_path") opt_force_big = value;
+    else if (n == "big_blocks") opt_big_blocks = value;
+    else if (n == "big_cand_cap") opt_big_cand_cap = value;
+    else return fail(JV_EINVAL, "unknown option '%s'", name);
+    return JV_OK;
+}
+
+void jv_index_destroy(jv_index* ix) {
+    if (!ix) return;
+    hipSetDevice(ix->device);
+    hipDeviceSynchronize();
+    for (Ctx* c : ix->all_ctx) ctx_destroy(c);
+    for (void* p : ix->owned) hipFree(p);
+    delete ix;
+}
+
+int jv_index_create(const jv_index_desc* desc, jv_index** out) {
+    if (!desc || !out) return fail(JV_EINVAL, "desc/out is NULL");
+    *out = nullptr;
+    if (desc->struct_size != sizeof(jv_index_desc))
+        return fail(JV_EINVAL, "jv_index_desc.struct_size %u != %zu (ABI mismatch)", desc->struct_size, sizeof(jv_index_desc));
+    const int n = desc->n, d = desc->d, R = desc->R;
+    if (n < 0 || d <= 0 || R <= 0) return fail(JV_EINVAL, "bad shape n=%d d=%d R=%d", n, d, R);
+    // VectorSimilarityMapper.ordToDistFunc throws IllegalArgumentException on unknown ordinals (J/JVectorReader.java:407-413)
+    if (desc->similarity < 0 || desc->similarity > 2) return fail(JV_EINVAL, "invalid similarity ordinal %d", desc->similarity);
+    if (n > 0 && (!desc->vectors || !desc->adj)) return fail(JV_EINVAL, "vectors/adj is NULL");
+    if (desc->entry_node >= n) return fail(JV_EINVAL, "entry_node %d out of range", desc->entry_node);
+    if (desc->num_upper_layers < 0 || desc->num_upper_layers > JV_MAX_UPPER_LAYERS)
+        return fail(JV_EUNSUPPORTED, "num_upper_layers %d not in [0,%d]", desc->num_upper_layers, JV_MAX_UPPER_LAYERS);
+    if (desc->num_upper_layers > 0 && !desc->upper_layers) return fail(JV_EINVAL, "upper_layers is NULL");
+    if (desc->score_scale != 1.0f && desc->score_scale != 2.0f) return fail(JV_EINVAL, "score_scale must be 1 or 2");
+    const int M = desc->pq_M;
+    if (M < 0 || M > d) return fail(JV_EINVAL, "pq_M %d out of range", M);
+    if (M > 0) {
+        if (desc->pq_K <= 0 || desc->pq_K > 256) return fail(JV_EINVAL, "pq_K %d not in [1,256]", desc->pq_K);
+        if (!desc->pq_codebooks || (n > 0 && !desc->pq_codes)) return fail(JV_EINVAL, "pq arrays are NULL");
+        if ((M + 15) / 16 > 64) return fail(JV_EUNSUPPORTED, "pq_M %d > 1024", M);
+    }
+    const bool devptr = (desc->flags & JV_DESC_DEVICE_POINTERS) != 0;
+    const bool borrow = devptr && (desc->flags & JV_DESC_BORROW) != 0;
+    if (desc->flags & JV_DESC_FUSED_ADC) return fail(JV_EUNSUPPORTED, "fused ADC layout not implemented yet");
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(JV_EDEVICE, "no HIP device available (%s): the GPU engine has no CPU fallback", hipGetErrorString(e));
+    if (desc->device < 0 || desc->device >= ndev) return fail(JV_EINVAL, "device %d out of range [0,%d)", desc->device, ndev);
+    HIPCHK(hipSetDevice(desc->device));
+
+    jv_index* ix = new jv_index();
+    ix->device = desc->device;
+    JvIndexDev& D = ix->dev;
+    D.n = n;
+    D.d = d;
+    D.R = R;
+    D.stride = (d + 3) & ~3;
+    D.nch = (D.stride + 63) / 64;
+    D.sim = desc->similarity;
+    D.score_scale = desc->score_scale;
+    D.entry = n > 0 ? desc->entry_node : -1;
+    D.num_upper = desc->num_upper_layers;
+    const hipMemcpyKind kind = devptr ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    int rc = JV_OK;
+#define TRY(x)                       \
+    do {                             \
+        rc = (x);                    \
+        if (rc != JV_OK) goto error; \
+    } while (0)
+#define TRYHIP(x)                                                                          \
+    do {                                                                                   \
+        hipError_t e2 = (x);                                                               \
+        if (e2 != hipSuccess) {                                                            \
+            rc = fail(e2 == hipErrorOutOfMemory ? JV_ENOMEM : JV_EDEVICE, "%s failed: %s", #x, \
+                      hipGetErrorString(e2));                                              \
+            goto error;                                                                    \
+        }                                                                                  \
+    } while (0)
+    {
+        if (n > 0) {
+            if (borrow && D.stride == d) {
+                D.vectors = desc->vectors;
+            } else {
+                float* v = nullptr;
+                TRY(dev_alloc(ix, &v, (size_t)n * D.stride));
+                if (D.stride == d) {
+                    TRYHIP(hipMemcpy(v, desc->vectors, (size_t)n * d * sizeof(float), kind));
+                } else {
+                    TRYHIP(hipMemset(v, 0, (size_t)n * D.stride * sizeof(float)));
+                    TRYHIP(hipMemcpy2D(v, (size_t)D.stride * 4, desc->vectors, (size_t)d * 4, (size_t)d * 4, (size_t)n, kind));
+                }
+                D.vectors = v;
+            }
+            if (borrow) {
+                D.adj = desc->adj;
+            } else {
+                int32_t* a = nullptr;
+                TRY(dev_alloc(ix, &a, (size_t)n * R));
+                TRYHIP(hipMemcpy(a, desc->adj, (size_t)n * R * sizeof(int32_t), kind));
+                D.adj = a;
+            }
+            if (desc->ord2doc) {
+                if (borrow) {
+                    D.ord2doc = desc->ord2doc;
+                } else {
+                    int32_t* o = nullptr;
+                    TRY(dev_alloc(ix, &o, (size_t)n));
+                    TRYHIP(hipMemcpy(o, desc->ord2doc, (size_t)n * sizeof(int32_t), kind));
+                    D.ord2doc = o;
+                }
+            }
+        }
+        // upper layers are always host arrays (tiny)
+        for (int l = 0; l < D.num_upper; l++) {
+            const jv_layer_desc& L = desc->upper_layers[l];
+            if (L.count < 0 || L.degree <= 0 || (L.count > 0 && (!L.nodes || !L.adj))) {
+                rc = fail(JV_EINVAL, "bad upper layer %d", l + 1);
+                goto error;
+            }
+            int32_t *nd = nullptr, *ad = nullptr;
+            TRY(dev_alloc(ix, &nd, (size_t)L.count));
+            TRY(dev_alloc(ix, &ad, (size_t)L.count * L.degree));
+            if (L.count > 0) {
+                TRYHIP(hipMemcpy(nd, L.nodes, (size_t)L.count * sizeof(int32_t), hipMemcpyHostToDevice));
+                TRYHIP(hipMemcpy(ad, L.adj, (size_t)L.count * L.degree * sizeof(int32_t), hipMemcpyHostToDevice));
+            }
+            D.upper[l].count = L.count;
+            D.upper[l].degree = L.degree;
+            D.upper[l].nodes = nd;
+            D.upper[l].adj = ad;
+        }
+        if (M > 0) {
+            D.pq_M = M;
+            D.pq_K = desc->pq_K;
+            D.pq_lanes = next_pow2((M + 15) / 16);
+            D.pq_code_stride = (M + 15) & ~15;
+            // subspace layout: jvector getSubvectorSizesAndOffsets (size d/M, first d%M get +1) unless given
+            std::vector<int32_t> off(M + 1, 0);
+            for (int m = 0; m < M; m++) {
+                int s = desc->pq_sub_sizes ? desc->pq_sub_sizes[m] : d / M + (m < d % M ? 1 : 0);
+                if (s <= 0) {
+                    rc = fail(JV_EINVAL, "pq_sub_sizes[%d] = %d", m, s);
+                    goto error;
+                }
+                off[m + 1] = off[m] + s;
+            }
+            if (off[M] != d) {
+                rc = fail(JV_EINVAL, "pq subspace sizes sum to %d, expected d=%d", off[M], d);
+                goto error;
+            }
+            int32_t* doff = nullptr;
+            TRY(dev_alloc(ix, &doff, (size_t)M + 1));
+            TRYHIP(hipMemcpy(doff, off.data(), (size_t)(M + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+            D.pq_sub_off = doff;
+            // codebooks (host) -> transposed [dim][256]
+            std::vector<float> cbT((size_t)d * 256, 0.0f);
+            std::vector<float> norm;
+            if (D.sim == JV_SIM_COSINE) norm.assign((size_t)M * 256, 0.0f);
+            const float* cb = desc->pq_codebooks;
+            for (int m = 0; m < M; m++) {
+                int s = off[m + 1] - off[m];
+                for (int c = 0; c < desc->pq_K; c++) {
+                    const float* cv = cb + (size_t)c * s;
+                    float acc = 0.0f;
+                    for (int i = 0; i < s; i++) {
+                        cbT[(size_t)(off[m] + i) * 256 + c] = cv[i];
+                        acc = std::fmaf(cv[i], cv[i], acc);  // same chain as the oracle's norm table
+                    }
+                    if (!norm.empty()) norm[(size_t)m * 256 + c] = acc;
+                }
+                cb += (size_t)desc->pq_K * s;
+            }
+            float* dcb = nullptr;
+            TRY(dev_alloc(ix, &dcb, cbT.size()));
+            TRYHIP(hipMemcpy(dcb, cbT.data(), cbT.size() * sizeof(float), hipMemcpyHostToDevice));
+            D.pq_cbT = dcb;
+            if (!norm.empty()) {
+                float* dn = nullptr;
+                TRY(dev_alloc(ix, &dn, norm.size()));
+                TRYHIP(hipMemcpy(dn, norm.data(), norm.size() * sizeof(float), hipMemcpyHostToDevice));
+                D.pq_norm_lut = dn;
+            }
+            if (desc->pq_centroid) {
+                float* dc = nullptr;
+                TRY(dev_alloc(ix, &dc, (size_t)d));
+                TRYHIP(hipMemcpy(dc, desc->pq_centroid, (size_t)d * sizeof(float), hipMemcpyHostToDevice));
+                D.pq_centroid = dc;
+            }
+            if (n > 0) {
+                if (borrow && D.pq_code_stride == M) {
+                    D.pq_codes = desc->pq_codes;
+                } else {
+                    uint8_t* codes = nullptr;
+                    TRY(dev_alloc(ix, &codes, (size_t)n * D.pq_code_stride));
+                    if (D.pq_code_stride == M) {
+                        TRYHIP(hipMemcpy(codes, desc->pq_codes, (size_t)n * M, kind));
+                    } else {
+                        TRYHIP(hipMemset(codes, 0, (size_t)n * D.pq_code_stride));
+                        TRYHIP(hipMemcpy2D(codes, (size_t)D.pq_code_stride, desc->pq_codes, (size_t)M, (size_t)M, (size_t)n, kind));
+                    }
+                    D.pq_codes = codes;
+                }
+            }
+        }
+        for (int pq = 0; pq < 2; pq++)
+            for (int big = 0; big < 2; big++) TRYHIP(jvk_set_max_lds(pq, big, kMaxLds));
+        TRY(ctx_create(ix, &ix->async_ctx));
+    }
+    ix->info.n = n;
+    ix->info.d = d;
+    ix->info.R = R;
+    ix->info.similarity = D.sim;
+    ix->info.pq_M = D.pq_M;
+    ix->info.pq_K = D.pq_K;
+    ix->info.num_upper_layers = D.num_upper;
+    ix->info.device = ix->device;
+    ix->info.row_stride_floats = D.stride;
+    ix->info.fused_adc = 0;
+    *out = ix;
+    return JV_OK;
+error:
+    jv_index_destroy(ix);
+    return rc;
+#undef TRY
+#undef TRYHIP
+}
+
+int jv_index_get_info(const jv_index* index, jv_index_info* out) {
+    if (!index || !out) return fail(JV_EINVAL, "index/out is NULL");
+    *out = index->info;
+    return JV_OK;
+}
+
+int jv_search_batch_device(jv_index* index, const float* d_queries, int32_t nq, int32_t topK, int32_t rerankK,
+                           float threshold, float rerankFloor, const uint64_t* d_accept_doc_words,
+                           int64_t accept_num_docs, int32_t* d_out_nodes, int32_t* d_out_docs,
+                           float* d_out_scores, int32_t* d_out_count, int32_t* d_out_stats,
+                           int32_t* d_out_flags, void* hip_stream) {
+    int rc = check_common(index, d_queries, nq, topK, rerankK, threshold);
+    if (rc != JV_OK) return rc;
+    if (nq == 0) return JV_OK;
+    if (!d_out_nodes || !d_out_scores || !d_out_count || !d_out_stats) return fail(JV_EINVAL, "output pointer is NULL");
+    HIPCHK(hipSetDevice(index->device));
+    std::lock_guard<std::mutex> lk(index->async_mu);
+    Ctx* c = index->async_ctx;
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    if (c->last_stream && c->last_stream != s) HIPCHK(hipStreamWaitEvent(s, c->last_use, 0));
+    if (!d_out_flags) {
+        rc = grow((void**)&c->d_flags, &c->nq_cap, (size_t)nq, sizeof(int32_t));
+        if (rc != JV_OK) return rc;
+        d_out_flags = c->d_flags;
+    }
+    if (topK == 0 || index->dev.n == 0 || index->dev.entry < 0) {
+        HIPCHK(hipMemsetAsync(d_out_count, 0, (size_t)nq * 4, s));
+        HIPCHK(hipMemsetAsync(d_out_stats, 0, (size_t)nq * 16, s));
+        HIPCHK(hipMemsetAsync(d_out_flags, 0, (size_t)nq * 4, s));
+        if (topK > 0) {
+            HIPCHK(hipMemsetAsync(d_out_nodes, 0xFF, (size_t)nq * topK * 4, s));
+            if (d_out_docs) HIPCHK(hipMemsetAsync(d_out_docs, 0xFF, (size_t)nq * topK * 4, s));
+            HIPCHK(hipMemsetAsync(d_out_scores, 0, (size_t)nq * topK * 4, s));
+        }
+    } else {
+        rc = enqueue_batch(index, c, s, d_queries, nq, topK, rerankK, threshold, rerankFloor, d_accept_doc_words,
+                           accept_num_docs, d_out_nodes, d_out_docs, d_out_scores, d_out_count, d_out_stats, d_out_flags);
+        if (rc != JV_OK) return rc;
+    }
+    HIPCHK(hipEventRecord(c->last_use, s));
+    c->last_stream = s;
+    if (!hip_stream) HIPCHK(hipStreamSynchronize(s));
+    return JV_OK;
+}
+
+int jv_search_batch(jv_index* index, const float* queries, int32_t nq, int32_t topK, int32_t rerankK,
+                    float threshold, float rerankFloor, const uint64_t* accept_doc_words, int64_t accept_num_docs,
+                    int32_t* out_nodes, int32_t* out_docs, float* out_scores, int32_t* out_count, int32_t* out_stats) {
+    int rc = check_common(index, queries, nq, topK, rerankK, threshold);
+    if (rc != JV_OK) return rc;
+    if (nq == 0) return JV_OK;
+    const size_t outn = (size_t)nq * (size_t)topK;
+    if (topK == 0 || index->dev.n == 0 || index->dev.entry < 0) {
+        for (size_t i = 0; i < outn; i++) {
+            if (out_nodes) out_nodes[i] = -1;
+            if (out_docs) out_docs[i] = -1;
+            if (out_scores) out_scores[i] = 0.0f;
+        }
+        if (out_count) memset(out_count, 0, sizeof(int32_t) * (size_t)nq);
+        if (out_stats) memset(out_stats, 0, sizeof(int32_t) * 4 * (size_t)nq);
+        return JV_OK;
+    }
+    HIPCHK(hipSetDevice(index->device));
+    Ctx* c = nullptr;
+    rc = ctx_acquire(index, &c);
+    if (rc != JV_OK) return rc;
+    struct Releaser {
+        jv_index* ix;
+        Ctx* c;
+        ~Releaser() { ctx_release(ix, c); }
+    } rel{index, c};
+    const int d = index->dev.d;
+    if ((rc = grow((void**)&c->d_queries, &c->queries_cap, (size_t)nq * d, sizeof(float))) != JV_OK) return rc;
+    if (outn > c->out_cap || !c->d_nodes) {
+        size_t cap = 0;
+        hipFree(c->d_nodes); c->d_nodes = nullptr;
+        hipFree(c->d_docs); c->d_docs = nullptr;
+        hipFree(c->d_scores); c->d_scores = nullptr;
+        size_t c1 = 0, c2 = 0;
+        if ((rc = grow((void**)&c->d_nodes, &cap, outn, 4)) != JV_OK) return rc;
+        if ((rc = grow((void**)&c->d_docs, &c1, cap, 4)) != JV_OK) return rc;
+        if ((rc = grow((void**)&c->d_scores, &c2, cap, 4)) != JV_OK) return rc;
+        c->out_cap = cap;
+    }
+    if ((size_t)nq > c->nq_cap || !c->d_count) {
+        hipFree(c->d_count); c->d_count = nullptr;
+        hipFree(c->d_stats); c->d_stats = nullptr;
+        hipFree(c->d_flags); c->d_flags = nullptr;
+        size_t cap = 0, c1 = 0, c2 = 0;
+        if ((rc = grow((void**)&c->d_count, &cap, (size_t)nq, 4)) != JV_OK) return rc;
+        if ((rc = grow((void**)&c->d_stats, &c1, cap * 4, 4)) != JV_OK) return rc;
+        if ((rc = grow((void**)&c->d_flags, &c2, cap, 4)) != JV_OK) return rc;
+        c->nq_cap = cap;
+    }
+    const uint64_t* d_accept = nullptr;
+    if (accept_doc_words) {
+        if (accept_num_docs < 0) return fail(JV_EINVAL, "accept_num_docs < 0");
+        size_t words = ((size_t)accept_num_docs + 63) / 64;
+        if ((rc = grow((void**)&c->d_accept, &c->accept_cap, words, 8)) != JV_OK) return rc;
+        HIPCHK(hipMemcpyAsync(c->d_accept, accept_doc_words, words * 8, hipMemcpyHostToDevice, c->stream));
+        d_accept = c->d_accept;
+    }
+    HIPCHK(hipMemcpyAsync(c->d_queries, queries, (size_t)nq * d * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    rc = enqueue_batch(index, c, c->stream, c->d_queries, nq, topK, rerankK, threshold, rerankFloor, d_accept,
+                       accept_num_docs, c->d_nodes, c->d_docs, c->d_scores, c->d_count, c->d_stats, c->d_flags);
+    if (rc != JV_OK) return rc;
+    std::vector<int32_t> flags((size_t)nq);
+    if (out_nodes) HIPCHK(hipMemcpyAsync(out_nodes, c->d_nodes, outn * 4, hipMemcpyDeviceToHost, c->stream));
+    if (out_docs) HIPCHK(hipMemcpyAsync(out_docs, c->d_docs, outn * 4, hipMemcpyDeviceToHost, c->stream));
+    if (out_scores) HIPCHK(hipMemcpyAsync(out_scores, c->d_scores, outn * 4, hipMemcpyDeviceToHost, c->stream));
+    if (out_count) HIPCHK(hipMemcpyAsync(out_count, c->d_count, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
+    if (out_stats) HIPCHK(hipMemcpyAsync(out_stats, c->d_stats, (size_t)nq * 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(flags.data(), c->d_flags, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < nq; i++) {
+        if ((uint32_t)flags[i] & (JV_FLAG_FAILED | JV_FLAG_OVERFLOW))
+            return fail(JV_ENOMEM, "query %d overflowed the HBM scratch (big_cand_cap=%d); raise option big_cand_cap", i,
+                        c->big_cand_cap);
+    }
+    return JV_OK;
+}
+
+int jv_search(jv_index* index, const float* query, int32_t topK, int32_t rerankK, float threshold,
+              float rerankFloor, const uint64_t* accept_doc_words, int64_t accept_num_docs, int32_t* out_nodes,
+              int32_t* out_docs, float* out_scores, int32_t* out_count, int32_t* out_stats) {
+    return jv_search_batch(index, query, 1, topK, rerankK, threshold, rerankFloor, accept_doc_words, accept_num_docs,
+                           out_nodes, out_docs, out_scores, out_count, out_stats);
+}
+
+int jv_score_ordinals(jv_index* index, const float* query, const int32_t* ordinals, int32_t count, float* out_scores) {
+    if (!index || !query || (count > 0 && (!ordinals || !out_scores))) return fail(JV_EINVAL, "NULL argument");
+    if (count <= 0) return JV_OK;
+    HIPCHK(hipSetDevice(index->device));
+    if (index->dev.n == 0) {
+        memset(out_scores, 0, sizeof(float) * (size_t)count);
+        return JV_OK;
+    }
+    Ctx* c = nullptr;
+    int rc = ctx_acquire(index, &c);
+    if (rc != JV_OK) return rc;
+    struct Releaser {
+        jv_index* ix;
+        Ctx* c;
+        ~Releaser() { ctx_release(ix, c); }
+    } rel{index, c};
+    const int d = index->dev.d;
+    float* dq = nullptr;
+    int32_t* dord = nullptr;
+    float* dout = nullptr;
+    HIPCHK(hipMalloc((void**)&dq, (size_t)d * 4));
+    hipError_t e = hipMalloc((void**)&dord, (size_t)count * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&dout, (size_t)count * 4);
+    if (e == hipSuccess) e = hipMemcpyAsync(dq, query, (size_t)d * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dord, ordinals, (size_t)count * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = jvk_launch_score_ordinals(&index->dev, dq, dord, count, dout, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out_scores, dout, (size_t)count * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(dq);
+    hipFree(dord);
+    hipFree(dout);
+    if (e != hipSuccess) return fail(JV_EDEVICE, "jv_score_ordinals: %s", hipGetErrorString(e));
+    return JV_OK;
+}
+
+int jv_merge_topk_device(int32_t device, const int32_t* d_docs, const float* d_scores, int32_t nq, int32_t lists,
+                         int32_t k, int32_t* d_out_docs, float* d_out_scores, void* hip_stream) {
+    if (nq < 0 || lists <= 0 || k <= 0) return fail(JV_EINVAL, "bad merge shape");
+    if (nq == 0) return JV_OK;
+    if (!d_docs || !d_scores || !d_out_docs || !d_out_scores) return fail(JV_EINVAL, "NULL argument");
+    if ((int64_t)lists * k * 8 > 64 * 1024) return fail(JV_EUNSUPPORTED, "lists*k too large for one LDS tile");
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(jvk_launch_merge_topk(d_docs, d_scores, nq, lists, k, d_out_docs, d_out_scores, (hipStream_t)hip_stream));
+    if (!hip_stream) HIPCHK(hipStreamSynchronize(nullptr));
+    return JV_OK;
+}
+
+}  // extern "C"

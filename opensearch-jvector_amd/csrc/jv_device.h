@@ -1,0 +1,69 @@
+// jv_device.h — structures shared between the C-ABI host code (jv_abi.cpp) and the HIP kernels
+// (jv_kernels.hip).  gfx950 only.
+#pragma once
+#include <stdint.h>
+
+#define JV_WAVE 64
+#define JV_MAX_UPPER_LAYERS 16
+#define JV_TODO 64 /* neighbours scored per adjacency chunk */
+
+struct JvLayerDev {
+    int32_t count;
+    int32_t degree;
+    const int32_t* nodes;
+    const int32_t* adj;
+};
+
+// The HBM-resident index: flat arrays, nothing else (DESIGN.md "Data layout in HBM").
+struct JvIndexDev {
+    int32_t n, d, R;
+    int32_t stride;       // floats per vector row, = roundup(d, 4): rows are 16-B aligned, zero padded
+    int32_t nch;          // number of 64-float chunks per row = ceil(stride / 64)
+    int32_t sim;          // jv_similarity
+    float score_scale;    // Lucene MIP fix-up (exact-provider search path and exact scorer only)
+    int32_t entry;
+    int32_t num_upper;
+    JvLayerDev upper[JV_MAX_UPPER_LAYERS];
+    const float* vectors;    // [n][stride]
+    const int32_t* adj;      // [n][R]
+    const int32_t* ord2doc;  // [n] or nullptr (identity)
+    // PQ
+    int32_t pq_M, pq_K;
+    int32_t pq_lanes;        // lanes per node in ADC scoring = next_pow2(ceil(M/16))
+    const float* pq_cbT;     // [d][256]: codebook transposed, entry (dim, c) = codebook[m(dim)][c][dim - off(m)]
+    const int32_t* pq_sub_off;  // [M+1] first dimension of each subspace
+    int32_t pq_code_stride;     // bytes per code row = roundup(M, 16)
+    const float* pq_centroid;   // [d] or nullptr
+    const uint8_t* pq_codes;    // [n][M]
+    const float* pq_norm_lut;   // [M][256] |centroid|^2 (cosine) or nullptr
+    const uint8_t* pq_fused;    // fused layout: [n][R][M] neighbours' codes next to the adjacency order, or nullptr
+};
+
+struct JvSearchArgs {
+    const float* queries;  // [nq][d]
+    const int32_t* qlist;  // optional indirection (big-path retry list) or nullptr
+    int32_t nq;
+    int32_t topK, rk;
+    float threshold, rerank_floor;
+    const uint64_t* accept;  // doc-space bitset or nullptr
+    int64_t accept_docs;
+    int32_t* out_nodes;
+    int32_t* out_docs;
+    float* out_scores;
+    int32_t* out_count;
+    int32_t* out_stats;
+    int32_t* out_flags;
+    // on-chip scratch geometry (bytes offsets into dynamic LDS)
+    int32_t hash_slots;  // power of two (LDS path)
+    int32_t cand_cap;
+    int32_t res_cap;     // >= rk
+    // HBM scratch (big path): per resident block
+    uint32_t* big_visited;   // [blocks][ceil(n/32)]
+    int64_t* big_cand;       // [blocks][big_cand_cap]
+    int32_t big_cand_cap;
+    int32_t* work_counter;   // big path: dynamic query dequeue
+};
+
+#define JV_FLAG_OVERFLOW 0x80000000u /* on-chip scratch overflow: query must be re-run on the big path */
+#define JV_FLAG_FAILED   0x40000000u /* big path overflowed as well */
+#define JV_FLAG_BIG      0x1u

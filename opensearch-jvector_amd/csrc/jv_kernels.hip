@@ -1,0 +1,782 @@
+// jv_kernels.hip — hand-written HIP kernels (gfx950 / CDNA4) for the jVector GraphSearcher hot path.
+//
+// One 64-lane wavefront (= one workgroup) runs one query's whole beam search:
+//   * the query vector, the PQ look-up table, both NodeQueues and the visited set live in LDS;
+//   * an expansion reads one adjacency row (coalesced 4R bytes), filters it through the LDS visited
+//     set, and scores the survivors with a quarter-wave (16 lanes x 16 B = one 256-B burst) per
+//     vector row, four rows per wave-instruction, many rows in flight;
+//   * all queue operations are wave-parallel scans over small unsorted LDS arrays (a pop is an
+//     arg-max), which yields exactly the order jvector's binary heaps define because NodeQueue keys
+//     are unique and totally ordered.
+// Thousands of such waves are resident at once; HBM bandwidth comes from the aggregate of their
+// independent row gathers.  No MFMA: this path is gather/scan work (<= 0.5 flop per byte).
+//
+// Semantics follow jvector 4.0.0-rc.9 GraphSearcher as called from
+// J/JVectorReader.java:165-173; the CPU oracle (oracle/jv_oracle.c) is the
+// checker and uses the identical canonical fp32 order, so scores are bit-equal.
+//
+// Compile with -ffp-contract=off: every fused multiply-add is an explicit fmaf().
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "jv_device.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+#define KEY_MIN ((int64_t)0x8000000000000000ll)
+#define KEY_MAX ((int64_t)0x7fffffffffffffffll)
+#define HASH_EMPTY 0xFFFFFFFFu
+
+// ---------------------------------------------------------------------------------------------
+// NodeQueue keys (jvector NodeQueue.encode)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int64_t make_key(float score, int node) {
+    int32_t b = __float_as_int(score);
+    int32_t s = b ^ ((b >> 31) & 0x7fffffff);
+    return (int64_t)(((uint64_t)(uint32_t)s << 32) | (uint64_t)(uint32_t)(~node));
+}
+__device__ __forceinline__ float key_score(int64_t k) {
+    int32_t s = (int32_t)(k >> 32);
+    return __int_as_float(s ^ ((s >> 31) & 0x7fffffff));
+}
+__device__ __forceinline__ int key_node(int64_t k) { return ~(int32_t)(uint32_t)(k & 0xFFFFFFFFll); }
+
+// ---------------------------------------------------------------------------------------------
+// cross-lane helpers
+// ---------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+// adjacent-pair tree over the 16 lanes of a DPP row: lane^1, lane^2, then the sibling quads, then the
+// sibling octets (mirrors deliver the sibling group's identical partial; fp add is commutative).
+__device__ __forceinline__ float row16_tree_sum(float v) {
+    v = v + dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+    v = v + dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+    v = v + dpp_mov<0x141>(v);  // row_half_mirror
+    v = v + dpp_mov<0x140>(v);  // row_mirror
+    return v;
+}
+
+__device__ __forceinline__ void wave_argmax(int64_t& k, int& idx) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        int64_t ok = __shfl_xor(k, off, 64);
+        int oi = __shfl_xor(idx, off, 64);
+        if (ok > k) {
+            k = ok;
+            idx = oi;
+        }
+    }
+}
+__device__ __forceinline__ void wave_argmin(int64_t& k, int& idx) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        int64_t ok = __shfl_xor(k, off, 64);
+        int oi = __shfl_xor(idx, off, 64);
+        if (ok < k) {
+            k = ok;
+            idx = oi;
+        }
+    }
+}
+__device__ __forceinline__ void scan_max(const int64_t* arr, int n, int lane, int64_t& best, int& bi) {
+    best = KEY_MIN;
+    bi = -1;
+    for (int i = lane; i < n; i += JV_WAVE) {
+        int64_t k = arr[i];
+        if (k > best) {
+            best = k;
+            bi = i;
+        }
+    }
+    wave_argmax(best, bi);
+}
+__device__ __forceinline__ void scan_min(const int64_t* arr, int n, int lane, int64_t& best, int& bi) {
+    best = KEY_MAX;
+    bi = -1;
+    for (int i = lane; i < n; i += JV_WAVE) {
+        int64_t k = arr[i];
+        if (k < best) {
+            best = k;
+            bi = i;
+        }
+    }
+    wave_argmin(best, bi);
+}
+
+__device__ __forceinline__ float map_score(int sim, float raw) {
+    if (sim == 0) return 1.0f / (1.0f + raw);
+    return (1.0f + raw) / 2.0f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Exact scoring of up to 64 rows: the canonical accumulation.
+// Lane t of a 16-lane group owns elements 64j + 4t .. 4t+3 of its row (one 16-B load per chunk j):
+// 4 accumulators per lane = the 64 strided partials P[m], m = 4t + e; then (P0+P1)+(P2+P3) in the
+// lane and the adjacent-pair tree across the 16 lanes — the same tree as oracle/jv_oracle.c tree64.
+// SIM: 0 L2, 1 dot, 2 cosine.  Follows jvector VectorSimilarityFunction.compare.
+// ---------------------------------------------------------------------------------------------
+template <int SIM>
+__device__ __forceinline__ void score_rows_t(const JvIndexDev& ix, const float* q_lds, const int32_t* todo,
+                                             int m, float* todo_score, float qnorm2, float scale, int lane) {
+    constexpr int U = 4;   // row-groups in flight: 4 x 4 = 16 rows
+    constexpr int JU = 4;  // chunks in flight per row
+    const int g = lane >> 4, t = lane & 15;
+    const int nch = ix.nch, stride = ix.stride;
+    for (int base = 0; base < m; base += 4 * U) {
+        float acc[U][4], nrm[U][4];
+        const float* rp[U];
+        bool val[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            int r = base + 4 * u + g;
+            val[u] = r < m;
+            int node = todo[val[u] ? r : 0];
+            rp[u] = ix.vectors + (size_t)node * (size_t)stride + 4 * t;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                acc[u][e] = 0.0f;
+                nrm[u][e] = 0.0f;
+            }
+        }
+        for (int j0 = 0; j0 < nch; j0 += JU) {
+            f32x4 v[U][JU];
+#pragma unroll
+            for (int jj = 0; jj < JU; jj++) {
+                const int j = j0 + jj;
+                const bool okj = j < nch && (j * 64 + 4 * t) < stride;
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    if (okj && val[u]) v[u][jj] = *(const f32x4*)(rp[u] + j * 64);
+                    else v[u][jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < JU; jj++) {
+                const int j = j0 + jj;
+                if (j < nch && (j * 64 + 4 * t) < stride) {
+                    const f32x4 qv = *(const f32x4*)(q_lds + j * 64 + 4 * t);
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            if (SIM == 0) {
+                                float df = qv[e] - v[u][jj][e];
+                                acc[u][e] = fmaf(df, df, acc[u][e]);
+                            } else {
+                                acc[u][e] = fmaf(qv[e], v[u][jj][e], acc[u][e]);
+                                if (SIM == 2) nrm[u][e] = fmaf(v[u][jj][e], v[u][jj][e], nrm[u][e]);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            float s = (acc[u][0] + acc[u][1]) + (acc[u][2] + acc[u][3]);
+            s = row16_tree_sum(s);
+            float score;
+            if (SIM == 2) {
+                float nv = (nrm[u][0] + nrm[u][1]) + (nrm[u][2] + nrm[u][3]);
+                nv = row16_tree_sum(nv);
+                score = map_score(2, s / sqrtf(qnorm2 * nv));
+            } else {
+                score = map_score(SIM, s);
+            }
+            if (scale != 1.0f) score = score * scale;
+            if (t == 0 && val[u]) todo_score[base + 4 * u + g] = score;
+        }
+    }
+}
+
+__device__ __forceinline__ void score_rows(const JvIndexDev& ix, const float* q_lds, const int32_t* todo, int m,
+                                           float* todo_score, float qnorm2, float scale, int lane) {
+    if (ix.sim == 0) score_rows_t<0>(ix, q_lds, todo, m, todo_score, qnorm2, scale, lane);
+    else if (ix.sim == 1) score_rows_t<1>(ix, q_lds, todo, m, todo_score, qnorm2, scale, lane);
+    else score_rows_t<2>(ix, q_lds, todo, m, todo_score, qnorm2, scale, lane);
+}
+
+// canonical dot(q,q) for cosine: the row is the query itself (in LDS)
+__device__ __forceinline__ float query_norm2(const JvIndexDev& ix, const float* q_lds, int lane) {
+    const int t = lane & 15;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < ix.nch; j++) {
+        if (j * 64 + 4 * t < ix.stride) {
+            const f32x4 qv = *(const f32x4*)(q_lds + j * 64 + 4 * t);
+#pragma unroll
+            for (int e = 0; e < 4; e++) a[e] = fmaf(qv[e], qv[e], a[e]);
+        }
+    }
+    float s = (a[0] + a[1]) + (a[2] + a[3]);
+    return row16_tree_sum(s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// PQ: per-query look-up table in LDS, ADC scoring (jvector PQVectors.precomputedScoreFunctionFor /
+// PQDecoder).  lut[m][c] is a sequential fmaf chain over the subspace.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void build_lut(const JvIndexDev& ix, const float* q_lds, float* lut, int lane) {
+    const int M = ix.pq_M;
+    const bool l2 = ix.sim == 0;
+    for (int m = 0; m < M; m++) {
+        const int d0 = ix.pq_sub_off[m], d1 = ix.pq_sub_off[m + 1];
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int dim = d0; dim < d1; dim++) {
+            float qc = q_lds[dim];
+            if (ix.pq_centroid) qc = qc - ix.pq_centroid[dim];
+            const f32x4 cb = *(const f32x4*)(ix.pq_cbT + (size_t)dim * 256 + 4 * lane);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                if (l2) {
+                    float df = qc - cb[e];
+                    a[e] = fmaf(df, df, a[e]);
+                } else {
+                    a[e] = fmaf(qc, cb[e], a[e]);
+                }
+            }
+        }
+        *(f32x4*)(lut + m * 256 + 4 * lane) = (f32x4){a[0], a[1], a[2], a[3]};
+    }
+}
+
+// tree over the `lpn` (power of two) adjacent lanes that share one node
+__device__ __forceinline__ float lanes_tree_sum(float v, int lpn) {
+    if (lpn >= 2) v = v + dpp_mov<0xB1>(v);
+    if (lpn >= 4) v = v + dpp_mov<0x4E>(v);
+    if (lpn >= 8) v = v + dpp_mov<0x141>(v);
+    if (lpn >= 16) v = v + dpp_mov<0x140>(v);
+    if (lpn >= 32) v = v + __shfl_xor(v, 16, 64);
+    if (lpn >= 64) v = v + __shfl_xor(v, 32, 64);
+    return v;
+}
+
+// 16 consecutive subspaces per lane, summed left to right; chunk sums combined by the lane tree.
+__device__ __forceinline__ float adc_chunk(const float* lut, const u32x4 cw, int m0, int M) {
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int mi = m0 + i;
+        if (mi < M) {
+            const uint32_t code = (cw[i >> 2] >> ((i & 3) * 8)) & 0xFFu;
+            s = s + lut[mi * 256 + code];
+        }
+    }
+    return s;
+}
+
+__device__ __forceinline__ void score_nodes_pq(const JvIndexDev& ix, const float* lut, const int32_t* todo, int m,
+                                               float* todo_score, float qnorm2, int lane) {
+    const int lpn = ix.pq_lanes;
+    const int npp = JV_WAVE / lpn;  // nodes per pass
+    const int c = lane & (lpn - 1);
+    const int M = ix.pq_M, cs = ix.pq_code_stride;
+    for (int base = 0; base < m; base += npp) {
+        const int r = base + lane / lpn;
+        const bool val = r < m;
+        const int node = todo[val ? r : 0];
+        u32x4 cw = (u32x4){0, 0, 0, 0};
+        const bool have = val && c * 16 < M;
+        if (have) cw = *(const u32x4*)(ix.pq_codes + (size_t)node * cs + c * 16);
+        float s = have ? adc_chunk(lut, cw, c * 16, M) : 0.0f;
+        s = lanes_tree_sum(s, lpn);
+        float score;
+        if (ix.sim == 2) {
+            float na = have ? adc_chunk(ix.pq_norm_lut, cw, c * 16, M) : 0.0f;
+            na = lanes_tree_sum(na, lpn);
+            score = map_score(2, s / sqrtf(qnorm2 * na));
+        } else {
+            score = map_score(ix.sim, s);
+        }
+        if (c == 0 && val) todo_score[r] = score;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// visited set
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool visited_insert_lds(uint32_t* tab, uint32_t mask, int shift, uint32_t node) {
+    uint32_t h = (node * 0x9E3779B1u) >> shift;
+    for (;;) {
+        uint32_t old = atomicCAS(&tab[h], HASH_EMPTY, node);
+        if (old == HASH_EMPTY) return true;
+        if (old == node) return false;
+        h = (h + 1) & mask;
+    }
+}
+__device__ __forceinline__ bool visited_insert_bits(uint32_t* bits, uint32_t node) {
+    const uint32_t bit = 1u << (node & 31);
+    uint32_t old = atomicOr(&bits[node >> 5], bit);
+    return (old & bit) == 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the search
+// ---------------------------------------------------------------------------------------------
+struct QState {
+    int ncand;       // live candidates: cand[0..ncand)
+    int nhand;       // upper-layer hand-back entries: cand[cap-1-i]
+    int nres;        // results: res[0..nres)
+    int64_t worst;   // min key of res (valid when nres == rk_cur)
+    int worst_idx;
+    int nvisited_set;  // entries in the visited set (incl. entry point)
+    int visited, expanded, expanded_base, reranked;
+    bool overflow;
+};
+
+template <bool PQ, bool BIG>
+__device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, unsigned char* smem,
+                           int64_t* big_cand, uint32_t* big_bits) {
+    const int lane = threadIdx.x;
+    const int rk = a.rk, topK = a.topK;
+
+    // ---- LDS carve (all offsets multiples of 16 B) ----
+    float* q_lds = (float*)smem;
+    size_t off = (size_t)ix.nch * 64 * sizeof(float);
+    float* todo_score = (float*)(smem + off);
+    off += JV_TODO * sizeof(float);
+    int32_t* todo = (int32_t*)(smem + off);
+    off += JV_TODO * sizeof(int32_t);
+    float* lut = nullptr;
+    if (PQ) {
+        lut = (float*)(smem + off);
+        off += (size_t)ix.pq_M * 256 * sizeof(float);
+    }
+    int64_t* res;
+    int64_t* cand;
+    uint32_t* hash = nullptr;
+    int cand_cap;
+    if (BIG) {
+        res = big_cand;
+        cand = big_cand + a.res_cap;
+        cand_cap = a.big_cand_cap - a.res_cap;
+    } else {
+        res = (int64_t*)(smem + off);
+        off += (size_t)a.res_cap * sizeof(int64_t);
+        cand = (int64_t*)(smem + off);
+        off += (size_t)a.cand_cap * sizeof(int64_t);
+        hash = (uint32_t*)(smem + off);
+        cand_cap = a.cand_cap;
+    }
+    const uint32_t hmask = (uint32_t)a.hash_slots - 1u;
+    const int hshift = 32 - (31 - __clz(a.hash_slots));
+    const int hash_limit = (a.hash_slots / 4) * 3;
+
+    // ---- stage the query; clear the visited set ----
+    const float* qg = a.queries + (size_t)qi * ix.d;
+    for (int i = lane; i < ix.nch * 64; i += JV_WAVE) q_lds[i] = i < ix.d ? qg[i] : 0.0f;
+    if (BIG) {
+        const int words = (ix.n + 31) >> 5;
+        for (int i = lane; i < words; i += JV_WAVE) big_bits[i] = 0u;
+    } else {
+        for (int i = lane; i < a.hash_slots; i += JV_WAVE) hash[i] = HASH_EMPTY;
+    }
+    __syncthreads();
+    float qnorm2 = 0.0f;
+    if (ix.sim == 2) qnorm2 = query_norm2(ix, q_lds, lane), qnorm2 = __shfl(qnorm2, 0, 64);
+    if (PQ) {
+        build_lut(ix, q_lds, lut, lane);
+        __syncthreads();
+    }
+    // exact-provider path carries the Lucene MIP x2 wrap (J/JVectorReader.java:220-239,359-364);
+    // the PQ provider's reranker is not wrapped (:353-356)
+    const float search_scale = PQ ? 1.0f : ix.score_scale;
+
+    QState st;
+    st.ncand = st.nhand = st.nres = 0;
+    st.worst = KEY_MAX;
+    st.worst_idx = -1;
+    st.nvisited_set = 0;
+    st.visited = st.expanded = st.expanded_base = st.reranked = 0;
+    st.overflow = false;
+
+    auto score_todo = [&](int m) {
+        if (PQ) score_nodes_pq(ix, lut, todo, m, todo_score, qnorm2, lane);
+        else score_rows(ix, q_lds, todo, m, todo_score, qnorm2, search_scale, lane);
+        __syncthreads();
+    };
+
+    // ---- initializeInternal: score the entry point, mark visited (not counted), push ----
+    {
+        const int ep = ix.entry;
+        if (lane == 0) {
+            todo[0] = ep;
+            if (BIG) visited_insert_bits(big_bits, (uint32_t)ep);
+            else visited_insert_lds(hash, hmask, hshift, (uint32_t)ep);
+        }
+        st.nvisited_set = 1;
+        __syncthreads();
+        score_todo(1);
+        if (lane == 0) cand[0] = make_key(todo_score[0], ep);
+        st.ncand = 1;
+        __syncthreads();
+    }
+
+    // ---- searchOneLayer for lvl = top .. 0 ----
+    for (int lvl = ix.num_upper; lvl >= 0 && !st.overflow; lvl--) {
+        const int rk_cur = lvl > 0 ? 1 : rk;
+        const float thr = lvl > 0 ? 0.0f : a.threshold;
+        const bool accept_all = lvl > 0 || a.accept == nullptr;
+        while (st.ncand > 0) {
+            int64_t best;
+            int bi;
+            scan_max(cand, st.ncand, lane, best, bi);
+            const float sc = key_score(best);
+            if (st.nres >= rk_cur && sc < key_score(st.worst)) break;
+            // pop
+            const int c = key_node(best);
+            if (lane == 0) cand[bi] = cand[st.ncand - 1];
+            st.ncand--;
+            // adjacency row (issued early: it is the first dependent HBM access of the expansion)
+            const int32_t* row;
+            int deg;
+            if (lvl == 0) {
+                row = ix.adj + (size_t)c * ix.R;
+                deg = ix.R;
+            } else {
+                const JvLayerDev& L = ix.upper[lvl - 1];
+                int lo = 0, hi = L.count - 1, pos = -1;
+                while (lo <= hi) {
+                    int mid = (lo + hi) >> 1;
+                    int v = L.nodes[mid];
+                    if (v == c) {
+                        pos = mid;
+                        break;
+                    }
+                    if (v < c) lo = mid + 1;
+                    else hi = mid - 1;
+                }
+                row = pos >= 0 ? L.adj + (size_t)pos * L.degree : nullptr;
+                deg = pos >= 0 ? L.degree : 0;
+            }
+            int nb0 = (lane < deg) ? row[lane] : -1;
+            // accept test (J/JVectorReader.java:157-163)
+            bool acc = true;
+            if (!accept_all) {
+                int doc = ix.ord2doc ? ix.ord2doc[c] : c;
+                acc = doc >= 0 && (int64_t)doc < a.accept_docs && ((a.accept[doc >> 6] >> (doc & 63)) & 1ull);
+            }
+            // addTopCandidate: a full queue only admits a STRICTLY better score
+            if (acc && sc >= thr) {
+                if (st.nres < rk_cur) {
+                    if (lane == 0) res[st.nres] = best;
+                    st.nres++;
+                    __syncthreads();
+                    if (st.nres == rk_cur) scan_min(res, st.nres, lane, st.worst, st.worst_idx);
+                } else if (sc > key_score(st.worst)) {
+                    if (lvl > 0) {  // evicted -> handed back to the next layer
+                        if (lane == 0) cand[cand_cap - 1 - st.nhand] = st.worst;
+                        st.nhand++;
+                    }
+                    if (lane == 0) res[st.worst_idx] = best;
+                    __syncthreads();
+                    scan_min(res, st.nres, lane, st.worst, st.worst_idx);
+                } else if (lvl > 0) {
+                    if (lane == 0) cand[cand_cap - 1 - st.nhand] = best;
+                    st.nhand++;
+                }
+            }
+            // neighbours, 64 at a time, in stored order
+            for (int cb = 0; cb < deg; cb += JV_WAVE) {
+                const int nn = cb == 0 ? nb0 : ((cb + lane < deg) ? row[cb + lane] : -1);
+                if (!BIG && st.nvisited_set + JV_WAVE > hash_limit) {
+                    st.overflow = true;
+                    break;
+                }
+                bool is_new = false;
+                if (nn >= 0) {
+                    is_new = BIG ? visited_insert_bits(big_bits, (uint32_t)nn)
+                                 : visited_insert_lds(hash, hmask, hshift, (uint32_t)nn);
+                }
+                const unsigned long long mask = __ballot(is_new);
+                const int m = __popcll(mask);
+                if (is_new) todo[__popcll(mask & ((1ull << lane) - 1ull))] = nn;
+                __syncthreads();
+                if (m == 0) continue;
+                st.nvisited_set += m;
+                st.visited += m;
+                score_todo(m);
+                // push (level 0: a candidate already below a full result queue's worst can never be
+                // popped before the loop breaks, so it is not stored)
+                bool keep = lane < m;
+                float s = keep ? todo_score[lane] : 0.0f;
+                if (keep && lvl == 0 && st.nres >= rk_cur && s < key_score(st.worst)) keep = false;
+                const unsigned long long km = __ballot(keep);
+                const int nk = __popcll(km);
+                if (st.ncand + nk + st.nhand > cand_cap) {
+                    // compact: drop candidates that can no longer be popped, then re-check
+                    if (lvl == 0 && st.nres >= rk_cur) {
+                        const float ws = key_score(st.worst);
+                        int w = 0;
+                        for (int b0 = 0; b0 < st.ncand; b0 += JV_WAVE) {
+                            const int i = b0 + lane;
+                            int64_t k = i < st.ncand ? cand[i] : KEY_MIN;
+                            const bool kp = i < st.ncand && !(key_score(k) < ws);
+                            const unsigned long long pm = __ballot(kp);
+                            __syncthreads();
+                            if (kp) cand[w + __popcll(pm & ((1ull << lane) - 1ull))] = k;
+                            w += __popcll(pm);
+                            __syncthreads();
+                        }
+                        st.ncand = w;
+                    }
+                    if (st.ncand + nk + st.nhand > cand_cap) {
+                        st.overflow = true;
+                        break;
+                    }
+                }
+                if (keep) cand[st.ncand + __popcll(km & ((1ull << lane) - 1ull))] = make_key(s, todo[lane]);
+                st.ncand += nk;
+                __syncthreads();
+            }
+            if (st.overflow) break;
+            st.expanded++;
+            if (lvl == 0) st.expanded_base++;
+        }
+        if (lvl > 0 && !st.overflow) {
+            // setEntryPointsFromPreviousLayer: results + evicted go back onto the candidate queue
+            const int total = st.nres + st.nhand;
+            if (st.ncand + total > cand_cap - st.nhand) {
+                st.overflow = true;
+                break;
+            }
+            __syncthreads();
+            for (int i = lane; i < st.nhand; i += JV_WAVE) cand[st.ncand + i] = cand[cand_cap - 1 - i];
+            for (int i = lane; i < st.nres; i += JV_WAVE) cand[st.ncand + st.nhand + i] = res[i];
+            st.ncand += total;
+            st.nhand = 0;
+            st.nres = 0;
+            st.worst = KEY_MAX;
+            __syncthreads();
+        }
+    }
+
+    int32_t* o_nodes = a.out_nodes + (size_t)qi * topK;
+    int32_t* o_docs = a.out_docs ? a.out_docs + (size_t)qi * topK : nullptr;
+    float* o_scores = a.out_scores + (size_t)qi * topK;
+    if (st.overflow) {
+        if (lane == 0) {
+            a.out_flags[qi] = BIG ? (int32_t)(JV_FLAG_FAILED | JV_FLAG_BIG) : (int32_t)JV_FLAG_OVERFLOW;
+            a.out_count[qi] = 0;
+        }
+        for (int i = lane; i < topK; i += JV_WAVE) {
+            o_nodes[i] = -1;
+            if (o_docs) o_docs[i] = -1;
+            o_scores[i] = 0.0f;
+        }
+        return;
+    }
+
+    // ---- result assembly ----
+    int64_t* fin = res;
+    int nfin = st.nres;
+    if (PQ) {
+        // NodeQueue.rerank: exact-rescore entries with approx >= rerankFloor, or only the best one
+        fin = cand;  // the candidate queue is dead now; cand_cap >= rk
+        nfin = 0;
+        int above = 0;
+        for (int i = lane; i < st.nres; i += JV_WAVE) above += key_score(res[i]) >= a.rerank_floor ? 1 : 0;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) above += __shfl_xor(above, o, 64);
+        int64_t bk;
+        int bidx;
+        scan_max(res, st.nres, lane, bk, bidx);
+        for (int b0 = 0; b0 < st.nres; b0 += JV_WAVE) {
+            const int i = b0 + lane;
+            bool take = false;
+            int node = 0;
+            if (i < st.nres) {
+                const int64_t k = res[i];
+                node = key_node(k);
+                take = above > 0 ? key_score(k) >= a.rerank_floor : i == bidx;
+            }
+            const unsigned long long tm = __ballot(take);
+            const int m = __popcll(tm);
+            if (take) todo[__popcll(tm & ((1ull << lane) - 1ull))] = node;
+            __syncthreads();
+            if (m > 0) {
+                score_rows(ix, q_lds, todo, m, todo_score, qnorm2, 1.0f, lane);
+                __syncthreads();
+                if (lane < m) fin[nfin + lane] = make_key(todo_score[lane], todo[lane]);
+                nfin += m;
+                st.reranked += m;
+            }
+            __syncthreads();
+        }
+    }
+    // top-K by key, descending (score desc, ordinal asc)
+    int cnt = 0;
+    for (; cnt < topK && nfin > 0; cnt++) {
+        int64_t bk;
+        int bidx;
+        scan_max(fin, nfin, lane, bk, bidx);
+        if (lane == 0) {
+            const int node = key_node(bk);
+            o_nodes[cnt] = node;
+            if (o_docs) o_docs[cnt] = ix.ord2doc ? ix.ord2doc[node] : node;
+            o_scores[cnt] = key_score(bk);
+            fin[bidx] = fin[nfin - 1];
+        }
+        nfin--;
+        __syncthreads();
+    }
+    for (int i = cnt + lane; i < topK; i += JV_WAVE) {
+        o_nodes[i] = -1;
+        if (o_docs) o_docs[i] = -1;
+        o_scores[i] = 0.0f;
+    }
+    if (lane == 0) {
+        a.out_count[qi] = cnt;
+        int32_t* s = a.out_stats + (size_t)qi * 4;
+        s[0] = st.visited;
+        s[1] = st.reranked;
+        s[2] = st.expanded;
+        s[3] = st.expanded_base;
+        a.out_flags[qi] = BIG ? (int32_t)JV_FLAG_BIG : 0;
+    }
+}
+
+// Fast path: one query per workgroup, all scratch in LDS.
+template <bool PQ>
+__global__ __launch_bounds__(JV_WAVE) void jv_search_lds_kernel(const JvIndexDev ix, const JvSearchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int qi = blockIdx.x;
+    if (qi >= a.nq) return;
+    search_one<PQ, false>(ix, a, qi, smem, nullptr, nullptr);
+}
+
+// Big path: queues and visited bitset in HBM scratch; each resident workgroup dequeues the queries the
+// fast path flagged as overflowed.  Exact in all cases the fast path cannot hold on chip.
+template <bool PQ>
+__global__ __launch_bounds__(JV_WAVE) void jv_search_big_kernel(const JvIndexDev ix, const JvSearchArgs a,
+                                                                 const int force_all) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int words = (ix.n + 31) >> 5;
+    int64_t* my_cand = a.big_cand + (size_t)blockIdx.x * a.big_cand_cap;
+    uint32_t* my_bits = a.big_visited + (size_t)blockIdx.x * words;
+    for (;;) {
+        int next = 0;
+        if (threadIdx.x == 0) next = atomicAdd(a.work_counter, 1);
+        const int qi = __shfl(next, 0, JV_WAVE);
+        if (qi >= a.nq) break;
+        if (!force_all && !((uint32_t)a.out_flags[qi] & JV_FLAG_OVERFLOW)) continue;
+        search_one<PQ, true>(ix, a, qi, smem, my_cand, my_bits);
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Exact scorer over an ordinal list (JVectorVectorScorer.score, J/JVectorVectorScorer.java:36-53):
+// one wave scores 64 ordinals per step with the same canonical accumulation.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(JV_WAVE) void jv_score_ordinals_kernel(const JvIndexDev ix, const float* query,
+                                                                     const int32_t* ordinals, int count,
+                                                                     float* out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    float* q_lds = (float*)smem;
+    size_t off = (size_t)ix.nch * 64 * sizeof(float);
+    float* todo_score = (float*)(smem + off);
+    off += JV_TODO * sizeof(float);
+    int32_t* todo = (int32_t*)(smem + off);
+    for (int i = lane; i < ix.nch * 64; i += JV_WAVE) q_lds[i] = i < ix.d ? query[i] : 0.0f;
+    __syncthreads();
+    float qnorm2 = 0.0f;
+    if (ix.sim == 2) qnorm2 = query_norm2(ix, q_lds, lane), qnorm2 = __shfl(qnorm2, 0, 64);
+    for (int base = blockIdx.x * JV_WAVE; base < count; base += gridDim.x * JV_WAVE) {
+        const int i = base + lane;
+        const int o = i < count ? ordinals[i] : -1;
+        const bool ok = o >= 0 && o < ix.n;
+        const unsigned long long mk = __ballot(ok);
+        const int m = __popcll(mk);
+        const int pos = __popcll(mk & ((1ull << lane) - 1ull));
+        if (ok) todo[pos] = o;
+        __syncthreads();
+        if (m > 0) score_rows(ix, q_lds, todo, m, todo_score, qnorm2, ix.score_scale, lane);
+        __syncthreads();
+        if (i < count) out[i] = ok ? todo_score[pos] : 0.0f;  // NO_VECTOR_OR_DELETED_DOC -> 0
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Merge of per-shard top-k lists (TopDocs.merge; the exchange step after the RCCL all-gather):
+// one wave per query, lists*k candidates -> k best by (score desc, doc asc).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(JV_WAVE) void jv_merge_topk_kernel(const int32_t* docs, const float* scores, int nq,
+                                                                 int lists, int k, int32_t* out_docs,
+                                                                 float* out_scores) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int64_t* keys = (int64_t*)smem;
+    const int lane = threadIdx.x;
+    const int qi = blockIdx.x;
+    if (qi >= nq) return;
+    const int total = lists * k;
+    for (int i = lane; i < total; i += JV_WAVE) {
+        const int doc = docs[(size_t)qi * total + i];
+        keys[i] = doc >= 0 ? make_key(scores[(size_t)qi * total + i], doc) : KEY_MIN;
+    }
+    __syncthreads();
+    int n = total;
+    for (int r = 0; r < k; r++) {
+        int64_t bk;
+        int bi;
+        scan_max(keys, n, lane, bk, bi);
+        if (lane == 0) {
+            const bool ok = n > 0 && bk != KEY_MIN;
+            out_docs[(size_t)qi * k + r] = ok ? key_node(bk) : -1;
+            out_scores[(size_t)qi * k + r] = ok ? key_score(bk) : 0.0f;
+            if (n > 0) keys[bi] = keys[n - 1];
+        }
+        if (n > 0) n--;
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launch wrappers (called from jv_abi.cpp)
+// ---------------------------------------------------------------------------------------------
+extern "C" hipError_t jvk_set_max_lds(int pq, int big, int bytes) {
+    const void* f;
+    if (!big) f = pq ? (const void*)jv_search_lds_kernel<true> : (const void*)jv_search_lds_kernel<false>;
+    else f = pq ? (const void*)jv_search_big_kernel<true> : (const void*)jv_search_big_kernel<false>;
+    return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+extern "C" hipError_t jvk_launch_search_lds(const JvIndexDev* ix, const JvSearchArgs* a, int pq, int lds_bytes,
+                                            hipStream_t stream) {
+    if (a->nq <= 0) return hipSuccess;
+    if (pq) jv_search_lds_kernel<true><<<a->nq, JV_WAVE, lds_bytes, stream>>>(*ix, *a);
+    else jv_search_lds_kernel<false><<<a->nq, JV_WAVE, lds_bytes, stream>>>(*ix, *a);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t jvk_launch_search_big(const JvIndexDev* ix, const JvSearchArgs* a, int pq, int blocks,
+                                            int lds_bytes, int force_all, hipStream_t stream) {
+    if (a->nq <= 0) return hipSuccess;
+    if (pq) jv_search_big_kernel<true><<<blocks, JV_WAVE, lds_bytes, stream>>>(*ix, *a, force_all);
+    else jv_search_big_kernel<false><<<blocks, JV_WAVE, lds_bytes, stream>>>(*ix, *a, force_all);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t jvk_launch_score_ordinals(const JvIndexDev* ix, const float* d_query,
+                                                const int32_t* d_ordinals, int count, float* d_out,
+                                                hipStream_t stream) {
+    if (count <= 0) return hipSuccess;
+    int blocks = (count + JV_WAVE - 1) / JV_WAVE;
+    if (blocks > 2048) blocks = 2048;
+    int lds = ix->nch * 64 * 4 + JV_TODO * 8;
+    jv_score_ordinals_kernel<<<blocks, JV_WAVE, lds, stream>>>(*ix, d_query, d_ordinals, count, d_out);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t jvk_launch_merge_topk(const int32_t* d_docs, const float* d_scores, int nq, int lists,
+                                            int k, int32_t* d_out_docs, float* d_out_scores,
+                                            hipStream_t stream) {
+    if (nq <= 0) return hipSuccess;
+    int lds = lists * k * 8;
+    jv_merge_topk_kernel<<<nq, JV_WAVE, lds, stream>>>(d_docs, d_scores, nq, lists, k, d_out_docs, d_out_scores);
+    return hipGetLastError();
+}

@@ -1,0 +1,46 @@
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import __graft_entry__ as graft  # noqa: E402
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    graft.load_package()
+
+    class P:
+        binding = importlib.import_module("opensearch_jvector_amd.binding")
+        builder = importlib.import_module("opensearch_jvector_amd.builder")
+        datagen = importlib.import_module("opensearch_jvector_amd.datagen")
+    if not os.path.exists(P.builder.LIB_PATH) or not os.path.exists(P.binding.LIB_PATH):
+        graft.build()
+    return P
+
+
+@pytest.fixture(scope="session")
+def pyoracle():
+    return graft.load_oracle()
+
+
+def recall_at_k(found: np.ndarray, truth: np.ndarray) -> float:
+    """size(approx ∩ truth)/size(truth), averaged — the reference harness's definition
+    (scripts/jvector_index_and_search/jvector_utils/recall_measurement.py:89-108)."""
+    tot = 0.0
+    for f, t in zip(found, truth):
+        ts = set(int(x) for x in t if x >= 0)
+        if not ts:
+            continue
+        tot += len(ts & set(int(x) for x in f if x >= 0)) / len(ts)
+    return tot / len(found)

@@ -1,0 +1,79 @@
+"""The C-ABI library loads and exports every symbol include/jvgpu.h declares (no compute calls: no
+GPU here); the product path fails loudly without a device; input generators are reproducible."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = pkg.binding.load_library()
+    with open(os.path.join(ROOT, "include", "jvgpu.h")) as f:
+        hdr = f.read()
+    declared = sorted(set(re.findall(r"\b(jv_[a-z_]+)\s*\(", hdr)))
+    assert declared, "no declarations found"
+    assert sorted(pkg.binding.ABI_SYMBOLS) == declared, "binding.ABI_SYMBOLS must list exactly the header's functions"
+    for sym in declared:
+        assert hasattr(lib, sym), f"{sym} is declared in include/jvgpu.h but not exported"
+    assert lib.jv_abi_version() == 1
+
+
+def test_desc_struct_layout_matches_header(pkg):
+    # 64-bit layout of jv_index_desc: 10 x 4 B + pad, pointers 8-aligned
+    assert ctypes.sizeof(pkg.binding.JvIndexDesc) == 120
+    assert pkg.binding.JvIndexDesc.vectors.offset == 48
+    assert pkg.binding.JvIndexDesc.ord2doc.offset == 104
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="GPU present")
+def test_no_cpu_fallback_without_gpu(pkg):
+    """Without a HIP device the product path must fail loudly (JV_EDEVICE), never compute on the CPU."""
+    b = pkg.binding
+    ix = b.IndexData(vectors=np.zeros((4, 2), np.float32), adj=np.full((4, 2), -1, np.int32), entry_node=0)
+    with pytest.raises(b.JvError) as ei:
+        b.GpuIndex(ix)
+    assert ei.value.code == b.JV_EDEVICE
+
+
+def test_argument_validation_without_gpu(pkg):
+    b = pkg.binding
+    lib = b.load_library()
+    h = ctypes.c_void_p()
+    assert lib.jv_index_create(None, ctypes.byref(h)) == b.JV_EINVAL
+    desc, keep = b.make_desc(b.IndexData(vectors=np.zeros((4, 2), np.float32), adj=np.full((4, 2), -1, np.int32), entry_node=0))
+    desc.similarity = 7  # VectorSimilarityMapper.ordToDistFunc -> IllegalArgumentException
+    assert lib.jv_index_create(ctypes.byref(desc), ctypes.byref(h)) == b.JV_EINVAL
+    assert b"similarity" in lib.jv_last_error()
+    desc.similarity = 0
+    desc.struct_size = 8
+    assert lib.jv_index_create(ctypes.byref(desc), ctypes.byref(h)) == b.JV_EINVAL
+    assert lib.jv_set_option(b"no_such_option", 1) == b.JV_EINVAL
+    lib.jv_index_destroy(None)  # NULL is a no-op
+
+
+def test_java_random_known_answers(pkg):
+    """java.util.Random known values: new Random(42).nextFloat() = 0.7275637, Random(0) = 0.73096776."""
+    dg = pkg.datagen
+    assert dg.java_random_floats(42, 1)[0] == np.float32(0.7275637)
+    assert dg.java_random_floats(0, 1)[0] == np.float32(0.73096776)
+    x = dg.java_random_floats(1, 70000)
+    y = dg.java_random_floats(1, 10)
+    assert np.array_equal(x[:10], y) and 0 <= x.min() and x.max() < 1
+    # scalar restatement
+    s = (1 ^ 0x5DEECE66D) & ((1 << 48) - 1)
+    for i in range(70000):
+        s = (s * 0x5DEECE66D + 0xB) & ((1 << 48) - 1)
+    assert x[-1] == np.float32((s >> 24) / float(1 << 24))
+
+
+def test_splitmix_generator_is_counter_based(pkg):
+    dg = pkg.datagen
+    a = dg.splitmix_uniform(42, 100, 16)
+    b = dg.splitmix_uniform(42, 40, 16, row_offset=60)
+    assert np.array_equal(a[60:], b)  # shards can generate their own doc range independently
+    assert a.dtype == np.float32 and 0 <= a.min() and a.max() < 1
+    assert abs(a.mean() - 0.5) < 0.05

@@ -1,0 +1,145 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on identical seeded inputs.
+Bar: neighbour ids bit-exact, the four counters exact, score BITS equal (the kernels and the oracle
+share one canonical fp32 order; the north star only asks for 1e-4 relative)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-4  # the north-star tolerance; asserted in addition to bit equality
+
+
+def _assert_same(got, want, what=""):
+    assert np.array_equal(got.count, want.count), f"{what}: result counts differ"
+    assert np.array_equal(got.nodes, want.nodes), f"{what}: neighbour ids differ"
+    assert np.array_equal(got.docs, want.docs), f"{what}: doc ids differ"
+    assert np.array_equal(got.stats, want.stats), f"{what}: visited/reranked/expanded counters differ"
+    np.testing.assert_allclose(got.scores, want.scores, rtol=REL_TOL, atol=0)
+    assert np.array_equal(got.scores.view(np.uint32), want.scores.view(np.uint32)), f"{what}: score bits differ"
+
+
+@pytest.fixture(scope="module")
+def small_sets(pkg):
+    dg = pkg.datagen
+    return {
+        "base64": dg.splitmix_uniform(42, 6000, 64),
+        "q64": dg.splitmix_uniform(43, 64, 64),
+    }
+
+
+@pytest.mark.parametrize("sim", [0, 1, 2])
+@pytest.mark.parametrize("d", [2, 16, 100, 128, 200])
+def test_exact_search_parity_dims(pkg, pyoracle, sim, d):
+    dg, b, bl = pkg.datagen, pkg.binding, pkg.builder
+    n = 1500
+    base = dg.splitmix_uniform(42 + d, n, d) - np.float32(0.3)
+    if sim == 1:
+        base = dg.l2_normalize(base)
+    q = dg.splitmix_uniform(43 + d, 24, d) - np.float32(0.3)
+    ix = bl.build_index_cpu(base, sim, R=12, L=40)
+    gpu = b.GpuIndex(ix)
+    want = pyoracle.Oracle(b, ix).search_batch(q, 10, 40)
+    got = gpu.search_batch(q, 10, 40)
+    _assert_same(got, want, f"sim={sim} d={d}")
+    gpu.close()
+
+
+@pytest.mark.parametrize("sim", [0, 1, 2])
+@pytest.mark.parametrize("M", [8, 16, 32, 24])
+def test_pq_search_parity(pkg, pyoracle, small_sets, sim, M):
+    b, bl = pkg.binding, pkg.builder
+    base, q = small_sets["base64"][:3000], small_sets["q64"][:32]
+    ix = bl.build_index_cpu(base, sim, R=16, L=50, pq_M=M)
+    gpu = b.GpuIndex(ix)
+    for (k, rk, floor) in [(10, 50, 0.0), (5, 5, 0.0), (10, 30, 0.9), (10, 30, 100.0)]:
+        want = pyoracle.Oracle(b, ix).search_batch(q, k, rk, rerank_floor=floor)
+        got = gpu.search_batch(q, k, rk, rerank_floor=floor)
+        _assert_same(got, want, f"sim={sim} M={M} k={k} rk={rk} floor={floor}")
+    gpu.close()
+
+
+def test_single_query_and_batch_agree(pkg, pyoracle, small_sets):
+    b, bl = pkg.binding, pkg.builder
+    base, q = small_sets["base64"], small_sets["q64"]
+    ix = bl.build_index_cpu(base, 0, R=32, L=100)
+    gpu = b.GpuIndex(ix)
+    batch = gpu.search_batch(q, 10, 100)
+    want = pyoracle.Oracle(b, ix).search_batch(q, 10, 100)
+    _assert_same(batch, want, "batch")
+    for i in range(4):
+        one = gpu.search(q[i], 10, 100)
+        assert np.array_equal(one.nodes[0], batch.nodes[i])
+        assert np.array_equal(one.stats[0], batch.stats[i])
+    gpu.close()
+
+
+def test_filter_and_docmap_parity(pkg, pyoracle, small_sets):
+    b, bl = pkg.binding, pkg.builder
+    base, q = small_sets["base64"][:4000], small_sets["q64"][:32]
+    n = base.shape[0]
+    rng = np.random.default_rng(5)
+    # ordinals map to a permuted, sparse doc-id space; 3 % of ordinals are deleted (-1)
+    max_doc = 2 * n
+    ord2doc = rng.permutation(max_doc)[:n].astype(np.int32)
+    ord2doc[rng.random(n) < 0.03] = -1
+    ix = bl.build_index_cpu(base, 0, R=16, L=60, ord2doc=ord2doc, max_doc=max_doc)
+    gpu = b.GpuIndex(ix)
+    orc = pyoracle.Oracle(b, ix)
+    for frac in (0.5, 0.1, 0.01):
+        acc_docs = np.nonzero(rng.random(max_doc) < frac)[0]
+        words = b.accept_words(acc_docs, max_doc)
+        want = orc.search_batch(q, 10, 50, accept=words, accept_num_docs=max_doc)
+        got = gpu.search_batch(q, 10, 50, accept=words, accept_num_docs=max_doc)
+        _assert_same(got, want, f"filter frac={frac}")
+        ok = set(acc_docs.tolist())
+        assert all(int(dd) in ok for dd in got.docs.reshape(-1) if dd >= 0)
+    gpu.close()
+
+
+def test_hierarchy_parity(pkg, pyoracle, small_sets):
+    b, bl = pkg.binding, pkg.builder
+    base, q = small_sets["base64"][:5000], small_sets["q64"][:32]
+    ix = bl.build_index_cpu(base, 0, R=16, L=60, hierarchy_layers=3)
+    assert len(ix.upper_nodes) == 3 and all(len(x) > 0 for x in ix.upper_nodes)
+    gpu = b.GpuIndex(ix)
+    want = pyoracle.Oracle(b, ix).search_batch(q, 10, 50)
+    got = gpu.search_batch(q, 10, 50)
+    _assert_same(got, want, "hierarchy")
+    assert (got.stats[:, 2] > got.stats[:, 3]).all(), "upper-layer expansions must be counted in expanded only"
+    gpu.close()
+
+
+def test_big_path_parity_forced_and_on_overflow(pkg, pyoracle, small_sets):
+    """The HBM-scratch variant must return exactly what the LDS variant and the oracle return."""
+    b, bl = pkg.binding, pkg.builder
+    base, q = small_sets["base64"], small_sets["q64"][:32]
+    ix = bl.build_index_cpu(base, 0, R=32, L=100)
+    gpu = b.GpuIndex(ix)
+    want = pyoracle.Oracle(b, ix).search_batch(q, 10, 100)
+    try:
+        b.set_option("force_big_path", 1)
+        _assert_same(gpu.search_batch(q, 10, 100), want, "forced big path")
+        b.set_option("force_big_path", 0)
+        b.set_option("lds_visited_slots", 512)   # far too small: every query overflows and is retried
+        _assert_same(gpu.search_batch(q, 10, 100), want, "visited overflow -> big path")
+        b.set_option("lds_visited_slots", 0)
+        b.set_option("lds_candidates", 100)      # candidate array too small
+        _assert_same(gpu.search_batch(q, 10, 100), want, "candidate overflow -> big path")
+    finally:
+        b.set_option("force_big_path", 0)
+        b.set_option("lds_visited_slots", 0)
+        b.set_option("lds_candidates", 0)
+    gpu.close()
+
+
+def test_score_ordinals_parity(pkg, pyoracle, small_sets):
+    b, bl = pkg.binding, pkg.builder
+    base, q = small_sets["base64"][:2000], small_sets["q64"][0]
+    for sim, scale in [(0, 1.0), (1, 2.0), (2, 1.0)]:
+        ix = bl.build_index_cpu(base, sim, R=8, L=20, score_scale=scale)
+        gpu = b.GpuIndex(ix)
+        ords = np.concatenate([np.arange(0, 2000, 3), [-1, 1999, -1, 0]]).astype(np.int32)
+        got = gpu.score_ordinals(q, ords)
+        want = pyoracle.Oracle(b, ix).score_ordinals(q, ords)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        gpu.close()
