@@ -142,6 +142,40 @@ def make_desc(ix: IndexData, device: int = 0, flags: int = 0):
     return desc, keep
 
 
+def make_desc_device(n: int, d: int, R: int, vectors_ptr: int, adj_ptr: int, entry_node: int, similarity: int,
+                     device: int = 0, score_scale: float = 1.0, pq_M: int = 0, pq_K: int = 0,
+                     pq_codebooks: Optional[np.ndarray] = None, pq_centroid: Optional[np.ndarray] = None,
+                     pq_codes_ptr: int = 0, ord2doc_ptr: int = 0, max_doc: int = 0, borrow: bool = True,
+                     extra_flags: int = 0):
+    """jv_index_desc over arrays that already live in HBM (raw device pointers, e.g. torch data_ptr()).
+    Codebooks/centroid stay host arrays (tiny). Returns (desc, keepalive)."""
+    keep = []
+    desc = JvIndexDesc()
+    desc.struct_size = C.sizeof(JvIndexDesc)
+    desc.flags = DESC_DEVICE_POINTERS | (DESC_BORROW if borrow else 0) | extra_flags
+    desc.device = device
+    desc.n, desc.d, desc.R = n, d, R
+    desc.similarity = similarity
+    desc.score_scale = score_scale
+    desc.entry_node = entry_node
+    desc.vectors = vectors_ptr or None
+    desc.adj = adj_ptr or None
+    desc.num_upper_layers = 0
+    desc.pq_M, desc.pq_K = pq_M, pq_K
+    if pq_M:
+        cb = np.ascontiguousarray(pq_codebooks, dtype=np.float32)
+        keep.append(cb)
+        desc.pq_codebooks = cb.ctypes.data
+        if pq_centroid is not None:
+            cen = np.ascontiguousarray(pq_centroid, dtype=np.float32)
+            keep.append(cen)
+            desc.pq_centroid = cen.ctypes.data
+        desc.pq_codes = pq_codes_ptr or None
+    desc.ord2doc = ord2doc_ptr or None
+    desc.max_doc = max_doc if max_doc else n
+    return desc, keep
+
+
 def accept_words(doc_ids, num_docs: int) -> np.ndarray:
     """doc-space bitset (bit i = doc i accepted) as uint64 words, like Lucene's FixedBitSet.getBits()."""
     words = np.zeros((num_docs + 63) // 64, dtype=np.uint64)

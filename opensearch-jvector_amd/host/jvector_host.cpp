@@ -1,0 +1,326 @@
+// jvector_host.cpp — see jvector_host.hpp. C++ mirror of the reference's Java host side of the hot
+// path; every search goes through the C ABI (include/jvgpu.h) to the HIP engine.
+#include "jvector_host.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+
+namespace jvector_amd {
+
+std::atomic<int64_t> KNNCounter::KNN_QUERY_VISITED_NODES{0};
+std::atomic<int64_t> KNNCounter::KNN_QUERY_RERANKED_COUNT{0};
+std::atomic<int64_t> KNNCounter::KNN_QUERY_EXPANDED_NODES{0};
+std::atomic<int64_t> KNNCounter::KNN_QUERY_EXPANDED_BASE_LAYER_NODES{0};
+std::atomic<int64_t> KNNCounter::KNN_QUERY_GRAPH_SEARCH_TIME{0};
+
+void throwForStatus(int status) {
+    if (status == JV_OK) return;
+    std::string msg = jv_last_error();
+    switch (status) {
+        case JV_EINVAL: throw IllegalArgumentException(msg);
+        case JV_EUNSUPPORTED: throw UnsupportedOperationException(msg);
+        default: throw IOException(msg);  // JV_ENOMEM / JV_EDEVICE / JV_EINTERNAL
+    }
+}
+
+// JVECTOR_SUPPORTED_SIMILARITY_FUNCTIONS = [EUCLIDEAN, DOT_PRODUCT, COSINE, DOT_PRODUCT] (J/JVectorReader.java:389-394)
+jv_similarity VectorSimilarityMapper::ordToDistFunc(int ord) {
+    static const jv_similarity table[4] = {JV_SIM_EUCLIDEAN, JV_SIM_DOT_PRODUCT, JV_SIM_COSINE, JV_SIM_DOT_PRODUCT};
+    if (ord < 0 || ord >= 4) throw IllegalArgumentException("Invalid ordinal: " + std::to_string(ord));
+    return table[ord];
+}
+// indexOf(LUCENE_TO_JVECTOR_MAP.get(func)): MAXIMUM_INNER_PRODUCT -> DOT_PRODUCT -> 1
+int VectorSimilarityMapper::distFuncToOrd(LuceneSimilarity s) {
+    switch (s) {
+        case LuceneSimilarity::EUCLIDEAN: return 0;
+        case LuceneSimilarity::DOT_PRODUCT: return 1;
+        case LuceneSimilarity::COSINE: return 2;
+        case LuceneSimilarity::MAXIMUM_INNER_PRODUCT: return 1;
+    }
+    throw IllegalArgumentException("invalid distance function");
+}
+
+int FixedBitSet::cardinality() const {
+    int c = 0;
+    for (uint64_t w : words_) c += __builtin_popcountll(w);
+    return c;
+}
+
+// ---- TopKnnCollector (Lucene NeighborQueue min-heap of encoded longs) ----
+namespace {
+inline int32_t sortableInt(float f) {
+    int32_t b;
+    std::memcpy(&b, &f, 4);
+    return b ^ ((b >> 31) & 0x7fffffff);
+}
+inline float fromSortable(int32_t s) {
+    int32_t b = s ^ ((s >> 31) & 0x7fffffff);
+    float f;
+    std::memcpy(&f, &b, 4);
+    return f;
+}
+inline int64_t encode(int doc, float score) {
+    return (int64_t)(((uint64_t)(uint32_t)sortableInt(score) << 32) | (uint64_t)(uint32_t)(~doc));
+}
+struct MinCmp {
+    bool operator()(int64_t a, int64_t b) const { return a > b; }
+};
+}  // namespace
+
+bool TopKnnCollector::collect(int docId, float similarity) {
+    int64_t e = encode(docId, similarity);
+    if ((int)heap_.size() < k_) {
+        heap_.push_back(e);
+        std::push_heap(heap_.begin(), heap_.end(), MinCmp());
+        return true;
+    }
+    if (k_ == 0 || e <= heap_.front()) return false;
+    std::pop_heap(heap_.begin(), heap_.end(), MinCmp());
+    heap_.back() = e;
+    std::push_heap(heap_.begin(), heap_.end(), MinCmp());
+    return true;
+}
+float TopKnnCollector::minCompetitiveSimilarity() const {
+    return (int)heap_.size() >= k_ && k_ > 0 ? fromSortable((int32_t)(heap_.front() >> 32)) : -INFINITY;
+}
+TopDocs TopKnnCollector::topDocs() {
+    std::vector<int64_t> h = heap_;
+    std::sort(h.begin(), h.end(), [](int64_t a, int64_t b) { return a > b; });
+    TopDocs t;
+    for (int64_t e : h) t.scoreDocs.push_back({~(int32_t)(uint32_t)(e & 0xFFFFFFFFll), fromSortable((int32_t)(e >> 32))});
+    t.totalHits = visited_;
+    t.totalHitsIsLowerBound = earlyTerminated();
+    return t;
+}
+
+// ---- GraphNodeIdToDocMap ----
+GraphNodeIdToDocMap::GraphNodeIdToDocMap(const std::vector<int>& ord2doc, int maxDocId) {
+    if (ord2doc.empty()) return;
+    graphNodeIdsToDocIds_ = ord2doc;
+    int observed = *std::max_element(ord2doc.begin(), ord2doc.end());
+    if (maxDocId < observed)
+        throw IllegalArgumentException("The maxDocId is incorrect, provided " + std::to_string(maxDocId) +
+                                       ", expected at least " + std::to_string(observed));
+    docIdsToGraphNodeIds_.assign((size_t)maxDocId + 1, NO_VECTOR_OR_DELETED_DOC);
+    for (size_t ord = 0; ord < ord2doc.size(); ord++)
+        if (ord2doc[ord] != NO_VECTOR_OR_DELETED_DOC) docIdsToGraphNodeIds_[(size_t)ord2doc[ord]] = (int)ord;
+}
+
+namespace {
+void writeVInt(std::vector<uint8_t>& out, int32_t v) {  // Lucene DataOutput.writeVInt
+    uint32_t i = (uint32_t)v;
+    while ((i & ~0x7Fu) != 0) {
+        out.push_back((uint8_t)((i & 0x7F) | 0x80));
+        i >>= 7;
+    }
+    out.push_back((uint8_t)i);
+}
+int32_t readVInt(const std::vector<uint8_t>& in, size_t& pos) {
+    uint32_t v = 0;
+    for (int shift = 0; shift < 35; shift += 7) {
+        if (pos >= in.size()) throw IOException("read past EOF");
+        uint8_t b = in[pos++];
+        v |= (uint32_t)(b & 0x7F) << shift;
+        if (!(b & 0x80)) return (int32_t)v;
+    }
+    throw IOException("Invalid vInt detected (too many bits)");
+}
+}  // namespace
+
+std::vector<uint8_t> GraphNodeIdToDocMap::toOutput() const {
+    std::vector<uint8_t> out;
+    const int32_t version = 1;  // writeInt: little-endian since Lucene 9
+    for (int i = 0; i < 4; i++) out.push_back((uint8_t)((uint32_t)version >> (8 * i)));
+    writeVInt(out, (int32_t)graphNodeIdsToDocIds_.size());
+    writeVInt(out, (int32_t)docIdsToGraphNodeIds_.size());
+    for (int doc : graphNodeIdsToDocIds_) writeVInt(out, doc);  // -1 is written as a 5-byte vint, as in Java
+    return out;
+}
+
+GraphNodeIdToDocMap GraphNodeIdToDocMap::fromBytes(const std::vector<uint8_t>& in) {
+    if (in.size() < 4) throw IOException("read past EOF");
+    int32_t version = (int32_t)((uint32_t)in[0] | (uint32_t)in[1] << 8 | (uint32_t)in[2] << 16 | (uint32_t)in[3] << 24);
+    if (version != 1) throw IOException("Unsupported version: " + std::to_string(version));
+    size_t pos = 4;
+    int size = readVInt(in, pos);
+    int maxDocId = readVInt(in, pos);
+    GraphNodeIdToDocMap m;
+    m.graphNodeIdsToDocIds_.assign((size_t)size, NO_VECTOR_OR_DELETED_DOC);
+    m.docIdsToGraphNodeIds_.assign((size_t)maxDocId, NO_VECTOR_OR_DELETED_DOC);
+    for (int ord = 0; ord < size; ord++) {
+        int doc = readVInt(in, pos);
+        if (doc != NO_VECTOR_OR_DELETED_DOC) {
+            m.graphNodeIdsToDocIds_[(size_t)ord] = doc;
+            m.docIdsToGraphNodeIds_.at((size_t)doc) = ord;
+        }
+    }
+    return m;
+}
+
+void GraphNodeIdToDocMap::update(const std::vector<int>& oldToNew) {
+    int maxNew = -1;
+    for (int doc : graphNodeIdsToDocIds_) maxNew = std::max(maxNew, oldToNew.at((size_t)doc));
+    int maxDocs = maxNew + 1;
+    if (maxDocs < (int)graphNodeIdsToDocIds_.size())
+        throw std::logic_error("Max docs " + std::to_string(maxDocs) + " is less than the number of ordinals " +
+                               std::to_string(graphNodeIdsToDocIds_.size()));
+    std::vector<int> newDoc2Ord((size_t)maxDocs, -1), newOrd2Doc(graphNodeIdsToDocIds_.size(), 0);
+    for (size_t oldDoc = 0; oldDoc < docIdsToGraphNodeIds_.size(); oldDoc++) {
+        int oldOrd = docIdsToGraphNodeIds_[oldDoc];
+        if (oldOrd == -1) continue;
+        int newDoc = oldToNew.at(oldDoc);
+        newDoc2Ord[(size_t)newDoc] = oldOrd;
+        newOrd2Doc[(size_t)oldOrd] = newDoc;
+    }
+    docIdsToGraphNodeIds_.swap(newDoc2Ord);
+    graphNodeIdsToDocIds_.swap(newOrd2Doc);
+}
+
+// ---- JVectorReader ----
+JVectorReader::FieldEntry::~FieldEntry() { jv_index_destroy(index); }
+
+void JVectorReader::addField(const std::string& field, const jv_index_desc& flattened, LuceneSimilarity sim,
+                             GraphNodeIdToDocMap map) {
+    auto fe = std::make_unique<FieldEntry>();
+    jv_index_desc desc = flattened;
+    // similarityFunction = VectorSimilarityMapper.ordToDistFunc(distFuncToOrd(luceneSim))  (:286-288)
+    fe->luceneSimilarity = sim;
+    fe->similarityFunction = VectorSimilarityMapper::ordToDistFunc(VectorSimilarityMapper::distFuncToOrd(sim));
+    desc.similarity = fe->similarityFunction;
+    // the MIP fix-up of wrapExactScoreFunction / JVectorVectorScorer (:220-239; JVectorVectorScorer.java:46-50)
+    desc.score_scale = sim == LuceneSimilarity::MAXIMUM_INNER_PRODUCT ? 2.0f : 1.0f;
+    fe->graphNodeIdToDocMap = std::move(map);
+    desc.ord2doc = fe->graphNodeIdToDocMap.size() ? fe->graphNodeIdToDocMap.ordToDoc().data() : nullptr;
+    desc.max_doc = fe->graphNodeIdToDocMap.maxDoc();
+    fe->dimension = desc.d;
+    fe->size = desc.n;
+    fe->hasPQ = desc.pq_M > 0;
+    throwForStatus(jv_index_create(&desc, &fe->index));
+    fieldEntryMap_[field] = std::move(fe);
+}
+
+const JVectorReader::FieldEntry* JVectorReader::fieldEntry(const std::string& field) const {
+    auto it = fieldEntryMap_.find(field);
+    return it == fieldEntryMap_.end() ? nullptr : it->second.get();
+}
+
+void JVectorReader::search(const std::string& field, const float* target, KnnCollector& knnCollector,
+                           const AcceptDocs* acceptDocs) {
+    const FieldEntry* fieldEntry = this->fieldEntry(field);
+    if (!fieldEntry) throw IllegalArgumentException("field not found: " + field);
+    // :132-144 — foreign collectors are re-wrapped with the defaults
+    JVectorKnnCollector* jvectorKnnCollector = dynamic_cast<JVectorKnnCollector*>(&knnCollector);
+    std::unique_ptr<JVectorKnnCollector> rewrapped;
+    if (!jvectorKnnCollector) {
+        rewrapped = std::make_unique<JVectorKnnCollector>(knnCollector, KNNConstants::DEFAULT_QUERY_SIMILARITY_THRESHOLD,
+                                                          KNNConstants::DEFAULT_QUERY_RERANK_FLOOR,
+                                                          KNNConstants::DEFAULT_OVER_QUERY_FACTOR);
+        jvectorKnnCollector = rewrapped.get();
+    }
+    const auto graphSearchStart = std::chrono::steady_clock::now();
+    // :157-163 — acceptDocs == null or bits == null accepts every ordinal; otherwise the engine tests
+    // ord2doc[ord] != -1 && bits.get(ord2doc[ord]) on the device
+    const FixedBitSet* b = acceptDocs ? acceptDocs->bits() : nullptr;
+    const int topK = jvectorKnnCollector->k();
+    const int rerankK = topK * jvectorKnnCollector->getOverQueryFactor();
+    std::vector<int32_t> nodes((size_t)std::max(topK, 1)), docs((size_t)std::max(topK, 1));
+    std::vector<float> scores((size_t)std::max(topK, 1));
+    int32_t count = 0, stats[JV_NUM_STATS] = {0, 0, 0, 0};
+    // :165-173 — graphSearcher.search(ssp, k, k * overQueryFactor, threshold, rerankFloor, compatibleBits)
+    throwForStatus(jv_search(fieldEntry->index, target, topK, rerankK, jvectorKnnCollector->getThreshold(),
+                             jvectorKnnCollector->getRerankFloor(), b ? b->getBits() : nullptr, b ? b->length() : 0,
+                             nodes.data(), docs.data(), scores.data(), &count, stats));
+    // :175-177
+    for (int i = 0; i < count; i++) jvectorKnnCollector->collect(docs[(size_t)i], scores[(size_t)i]);
+    const auto searchTime = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - graphSearchStart).count();
+    // :183-193
+    KNNCounter::KNN_QUERY_VISITED_NODES += stats[JV_STAT_VISITED];
+    KNNCounter::KNN_QUERY_RERANKED_COUNT += stats[JV_STAT_RERANKED];
+    KNNCounter::KNN_QUERY_EXPANDED_NODES += stats[JV_STAT_EXPANDED];
+    KNNCounter::KNN_QUERY_EXPANDED_BASE_LAYER_NODES += stats[JV_STAT_EXPANDED_BASE];
+    KNNCounter::KNN_QUERY_GRAPH_SEARCH_TIME += searchTime;
+    // :202-207
+    const int visitedCount = stats[JV_STAT_VISITED] + stats[JV_STAT_EXPANDED];
+    if (visitedCount > 0) jvectorKnnCollector->incVisitedCount(visitedCount);
+}
+
+void JVectorReader::search(const std::string&, const int8_t*, KnnCollector&, const AcceptDocs*) {
+    throw UnsupportedOperationException("Byte vector search is not supported yet with jVector");
+}
+
+std::vector<float> JVectorReader::scoreDocs(const std::string& field, const float* target, const std::vector<int>& docIds) {
+    const FieldEntry* fe = fieldEntry(field);
+    if (!fe) throw IllegalArgumentException("field not found: " + field);
+    std::vector<int32_t> ords(docIds.size());
+    for (size_t i = 0; i < docIds.size(); i++) {
+        int doc = docIds[i];
+        ords[i] = doc >= 0 && doc < fe->graphNodeIdToDocMap.maxDoc() ? fe->graphNodeIdToDocMap.getJVectorNodeId(doc)
+                                                                        : GraphNodeIdToDocMap::NO_VECTOR_OR_DELETED_DOC;
+    }
+    std::vector<float> out(docIds.size(), 0.0f);
+    if (!docIds.empty()) throwForStatus(jv_score_ordinals(fe->index, target, ords.data(), (int32_t)ords.size(), out.data()));
+    return out;
+}
+
+// ---- JVectorKnnFloatVectorQuery ----
+TopDocs JVectorKnnFloatVectorQuery::approximateSearch(JVectorReader& reader, const AcceptDocs* acceptDocs,
+                                                      int64_t visitedLimit) const {
+    TopKnnCollector delegateCollector(k_, visitedLimit);
+    JVectorKnnCollector knnCollector(delegateCollector, threshold_, rerankFloor_, overQueryFactor_);
+    const JVectorReader::FieldEntry* fe = reader.fieldEntry(field_);
+    if (!fe) return TopDocs();                                     // :58-61 NO_RESULTS
+    if (std::min(knnCollector.k(), fe->size) == 0) return TopDocs();  // :62-64
+    std::vector<float> targetCopy = target_;                       // getTargetCopy()
+    reader.search(field_, targetCopy.data(), knnCollector, acceptDocs);
+    return knnCollector.topDocs();
+}
+
+TopDocs JVectorKnnFloatVectorQuery::exactSearch(JVectorReader& reader, const FixedBitSet& accept) const {
+    const JVectorReader::FieldEntry* fe = reader.fieldEntry(field_);
+    std::vector<int> docs;
+    for (int doc = 0; doc < accept.length(); doc++)
+        if (accept.get(doc) && doc < fe->graphNodeIdToDocMap.maxDoc() &&
+            fe->graphNodeIdToDocMap.getJVectorNodeId(doc) != GraphNodeIdToDocMap::NO_VECTOR_OR_DELETED_DOC)
+            docs.push_back(doc);
+    std::vector<float> sc = reader.scoreDocs(field_, target_.data(), docs);
+    TopKnnCollector top(k_, INT64_MAX);
+    for (size_t i = 0; i < docs.size(); i++) top.collect(docs[i], sc[i]);
+    TopDocs t = top.topDocs();
+    t.totalHits = (int64_t)t.scoreDocs.size();
+    return t;
+}
+
+TopDocs JVectorKnnFloatVectorQuery::searchLeaf(JVectorReader& reader, const FixedBitSet* filter,
+                                               const FixedBitSet* liveDocs, int maxDoc, bool* usedExact) const {
+    if (usedExact) *usedExact = false;
+    const JVectorReader::FieldEntry* fe = reader.fieldEntry(field_);
+    if (!fe) return TopDocs();
+    // AbstractKnnVectorQuery.getLeafResults: no filter -> approximateSearch(liveDocs, Integer.MAX_VALUE)
+    if (!filter) {
+        AcceptDocs ad{liveDocs};
+        TopDocs t = approximateSearch(reader, liveDocs ? &ad : nullptr, INT32_MAX);
+        t.totalHits = (int64_t)t.scoreDocs.size();
+        return t;
+    }
+    FixedBitSet accept(maxDoc);
+    for (int doc = 0; doc < maxDoc; doc++)
+        if (filter->get(doc) && (!liveDocs || liveDocs->get(doc))) accept.set(doc);
+    const int cost = accept.cardinality();
+    if (cost <= k_) {  // fewer matches than k: exact search
+        if (usedExact) *usedExact = true;
+        return exactSearch(reader, accept);
+    }
+    AcceptDocs ad{&accept};
+    TopKnnCollector probe(k_, cost);
+    TopDocs t = approximateSearch(reader, &ad, cost);
+    if (!t.totalHitsIsLowerBound) {  // collector did not early-terminate
+        t.totalHits = (int64_t)t.scoreDocs.size();
+        return t;
+    }
+    if (usedExact) *usedExact = true;
+    return exactSearch(reader, accept);  // visited limit reached -> exact fallback
+}
+
+}  // namespace jvector_amd
