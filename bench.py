@@ -137,6 +137,7 @@ def main():
     graft.load_package()
     binding = importlib.import_module("opensearch_jvector_amd.binding")
     builder = importlib.import_module("opensearch_jvector_amd.builder")
+    sharding = importlib.import_module("opensearch_jvector_amd.sharding")
 
     wl = dict(WORKLOADS[args.workload])
     n = args.n if args.n > 0 else wl["n"]
@@ -197,22 +198,21 @@ def main():
         merged_docs = torch.empty((B, k), dtype=torch.int32, device=device)
         merged_scores = torch.empty((B, k), dtype=torch.float32, device=device)
 
+    def gpu_merge(gd, gs, kk):
+        nqm = gd.shape[0]
+        binding.merge_topk_device(local_rank, gd.data_ptr(), gs.data_ptr(), nqm, world, kk, merged_docs.data_ptr(),
+                                  merged_scores.data_ptr(), stream=stream.cuda_stream)
+        return merged_docs[:nqm], merged_scores[:nqm]
+
     def run_step(qbatch, rk, nq=B):
         """one pass of the hot path over one batch; returns the final (docs, scores) tensors"""
-        index.search_batch_device(qbatch.data_ptr(), nq, k, rk, out_nodes.data_ptr(), out_docs.data_ptr(),
-                                  out_scores.data_ptr(), out_count.data_ptr(), out_stats.data_ptr(),
-                                  out_flags.data_ptr(), stream=stream.cuda_stream)
-        if world == 1:
-            return out_docs, out_scores
+        def local_search(q):
+            index.search_batch_device(q.data_ptr(), nq, k, rk, out_nodes.data_ptr(), out_docs.data_ptr(),
+                                      out_scores.data_ptr(), out_count.data_ptr(), out_stats.data_ptr(),
+                                      out_flags.data_ptr(), stream=stream.cuda_stream)
+            return out_docs[:nq], out_scores[:nq]
         with torch.cuda.stream(stream):
-            dist.all_gather_into_tensor(gather_docs.view(-1), out_docs.view(-1))
-            dist.all_gather_into_tensor(gather_scores.view(-1), out_scores.view(-1))
-            # [world][B][k] -> per query `world` lists of k: the merge kernel takes [B][world*k]
-            gd = gather_docs.permute(1, 0, 2).contiguous()
-            gs = gather_scores.permute(1, 0, 2).contiguous()
-            binding.merge_topk_device(local_rank, gd.data_ptr(), gs.data_ptr(), nq, world, k, merged_docs.data_ptr(),
-                                      merged_scores.data_ptr(), stream=stream.cuda_stream)
-        return merged_docs, merged_scores
+            return sharding.sharded_search(dist, torch, local_search, gpu_merge, qbatch, k, world)
 
     # ---- ground truth + rerankK selection (recall@10 >= 0.95) ----
     n_gt = 256
@@ -273,12 +273,8 @@ def main():
         evs[s][1].record(stream)
         if world > 1:
             with torch.cuda.stream(stream):
-                dist.all_gather_into_tensor(gather_docs.view(-1), out_docs.view(-1))
-                dist.all_gather_into_tensor(gather_scores.view(-1), out_scores.view(-1))
-                gd = gather_docs.permute(1, 0, 2).contiguous()
-                gs = gather_scores.permute(1, 0, 2).contiguous()
-                binding.merge_topk_device(local_rank, gd.data_ptr(), gs.data_ptr(), B, world, k, merged_docs.data_ptr(),
-                                          merged_scores.data_ptr(), stream=stream.cuda_stream)
+                gd, gs = sharding.gather_topk(dist, torch, out_docs, out_scores, world, gather_docs, gather_scores)
+                gpu_merge(gd, gs, k)
         with torch.cuda.stream(stream):
             stat_sums += out_stats.to(torch.int64).sum(0)  # per-query counters -> algorithmic bytes
     barrier()

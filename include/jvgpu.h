@@ -171,7 +171,7 @@ typedef struct jv_index_info {
 int jv_index_get_info(const jv_index* index, jv_index_info* out);
 
 /* Tunables (process-wide, read at call time): name = "lds_visited_slots", "lds_candidates",
- * "max_resident_queries", "force_big_path". Returns JV_EINVAL for unknown names. */
+ * "force_big_path", "force_general_path", "big_blocks", "big_cand_cap". Returns JV_EINVAL for unknown names. */
 int jv_set_option(const char* name, int64_t value);
 
 /* Thread-local message of the calling thread's most recent failing call ("" if none). */

@@ -6,6 +6,7 @@
 // device or the kernels are unavailable every call fails with JV_EDEVICE.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdarg>
@@ -19,8 +20,8 @@
 #include "jv_device.h"
 
 extern "C" {
-hipError_t jvk_set_max_lds(int pq, int big, int bytes);
-hipError_t jvk_launch_search_lds(const JvIndexDev* ix, const JvSearchArgs* a, int pq, int lds_bytes, hipStream_t s);
+hipError_t jvk_set_max_lds(int bytes);
+hipError_t jvk_launch_search_lds(const JvIndexDev* ix, const JvSearchArgs* a, int pq, int pool, int lds_bytes, hipStream_t s);
 hipError_t jvk_launch_search_big(const JvIndexDev* ix, const JvSearchArgs* a, int pq, int blocks, int lds_bytes,
                                  int force_all, hipStream_t s);
 hipError_t jvk_launch_score_ordinals(const JvIndexDev* ix, const float* d_query, const int32_t* d_ordinals,
@@ -57,7 +58,9 @@ int fail(int code, const char* fmt, ...) {
 std::atomic<int64_t> opt_lds_visited_slots{0};  // 0 = auto
 std::atomic<int64_t> opt_lds_candidates{0};     // 0 = auto
 std::atomic<int64_t> opt_force_big{0};
-std::atomic<int64_t> opt_big_blocks{32};
+std::atomic<int64_t> opt_force_general{0};
+std::atomic<int64_t> opt_no_escalation{0};
+std::atomic<int64_t> opt_big_blocks{256};
 std::atomic<int64_t> opt_big_cand_cap{65536};
 
 int next_pow2(int v) {
@@ -183,28 +186,42 @@ struct Geometry {
     int hash_slots, cand_cap, res_cap;
     int lds_fast, lds_big;
     bool fast_ok;
+    bool pool;
 };
 
 // LDS carve of the fast path (must mirror search_one in jv_kernels.hip)
-Geometry plan_geometry(const jv_index* ix, int rk) {
+Geometry plan_geometry(const jv_index* ix, int rk, bool pool_ok, int force_slots = 0) {
     Geometry g{};
     const JvIndexDev& d = ix->dev;
     const bool pq = d.pq_M > 0;
-    int fixed = d.nch * 64 * 4 + JV_TODO * 8 + (pq ? d.pq_M * 256 * 4 : 0);
+    int fixed = d.nch * 64 * 4 + JV_TODO * 16 + (pq ? d.pq_M * 256 * 4 : 0);
     g.lds_big = fixed;
-    g.res_cap = (rk + 1) & ~1;
-    if (g.res_cap < 2) g.res_cap = 2;
     int64_t hs = opt_lds_visited_slots.load();
     int64_t cc = opt_lds_candidates.load();
-    // visited ~ 25 x rerankK at R=32; keep the table <= 75 % full
-    g.hash_slots = hs > 0 ? next_pow2((int)hs) : next_pow2(rk * 40 < 1024 ? 1024 : rk * 40);
+    g.pool = pool_ok && opt_force_general.load() == 0;
+    // visited set: ~10-25 x rerankK nodes at R=32; the table may fill to 75 %.  Overflow is not an error:
+    // the query is re-run exactly on the HBM-scratch path.
+    g.hash_slots = hs > 0 ? next_pow2((int)hs) : next_pow2(rk * 24 < 1024 ? 1024 : rk * 24);
+    if (force_slots > 0) g.hash_slots = force_slots;
     if (g.hash_slots > 32768) g.hash_slots = 32768;
-    g.cand_cap = cc > 0 ? (int)cc : (rk * 4 < 512 ? 512 : rk * 4);
-    if (g.cand_cap > 4096 && cc <= 0) g.cand_cap = 4096;
-    if (g.cand_cap < rk) g.cand_cap = rk;
-    g.cand_cap = (g.cand_cap + 1) & ~1;
+    if (g.pool) {
+        // two pool buffers: rk entries + 64 boundary ties + one chunk of 64 new keys
+        g.res_cap = (rk + 128 + 1) & ~1;
+        g.cand_cap = g.res_cap;
+        if (cc > 0) g.cand_cap = g.res_cap = ((int)cc + 1) & ~1;
+    } else {
+        g.res_cap = (rk + 1) & ~1;
+        if (g.res_cap < 2) g.res_cap = 2;
+        // two-queue form: the candidate queue can hold every visited node until the result queue fills
+        g.cand_cap = cc > 0 ? (int)cc : (g.hash_slots / 4) * 3;
+        if (g.cand_cap < rk) g.cand_cap = rk;
+        g.cand_cap = (g.cand_cap + 1) & ~1;
+    }
     auto total = [&]() { return (int64_t)fixed + (int64_t)g.res_cap * 8 + (int64_t)g.cand_cap * 8 + (int64_t)g.hash_slots * 4; };
-    while (total() > kMaxLds && g.hash_slots > 256 && hs <= 0) g.hash_slots >>= 1;
+    while (total() > kMaxLds && g.hash_slots > 256 && hs <= 0) {
+        g.hash_slots >>= 1;
+        if (!g.pool && cc <= 0) g.cand_cap = std::max(rk, (g.hash_slots / 4) * 3) & ~1;
+    }
     g.fast_ok = total() <= kMaxLds && fixed <= kMaxLds;
     g.lds_fast = (int)total();
     return g;
@@ -240,7 +257,8 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
                   float thr, float floor_, const uint64_t* d_accept, int64_t accept_docs, int32_t* d_nodes,
                   int32_t* d_docs, float* d_scores, int32_t* d_count, int32_t* d_stats, int32_t* d_flags) {
     const bool pq = ix->dev.pq_M > 0;
-    Geometry g = plan_geometry(ix, rk);
+    // the single-pool form is exact only without a filter and with threshold <= 0 (kernel re-checks scores)
+    Geometry g = plan_geometry(ix, rk, d_accept == nullptr && thr <= 0.0f);
     if (g.lds_big > kMaxLds)
         return fail(JV_EUNSUPPORTED, "query + PQ look-up table need %d B of LDS (> %d): pq_M=%d too large", g.lds_big,
                     kMaxLds, ix->dev.pq_M);
@@ -269,9 +287,25 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
     a.big_cand = c->big_cand;
     a.big_cand_cap = c->big_cand_cap;
     a.work_counter = c->work_counter;
+    a.retry_only = 0;
     const bool force_big = opt_force_big.load() != 0 || !g.fast_ok;
     HIPCHK(hipMemsetAsync(c->work_counter, 0, sizeof(int32_t), stream));
-    if (!force_big) HIPCHK(jvk_launch_search_lds(&ix->dev, &a, pq ? 1 : 0, g.lds_fast, stream));
+    if (!force_big) {
+        HIPCHK(jvk_launch_search_lds(&ix->dev, &a, pq ? 1 : 0, g.pool ? 1 : 0, g.lds_fast, stream));
+        // escalation: queries that overflowed the on-chip visited set are retried with a 4x larger table
+        // (fewer resident queries, but only the flagged few run) before the HBM-scratch path
+        if (opt_lds_visited_slots.load() <= 0 && opt_no_escalation.load() == 0) {
+            Geometry g2 = plan_geometry(ix, rk, g.pool, g.hash_slots * 4);
+            if (g2.fast_ok && g2.hash_slots > g.hash_slots) {
+                JvSearchArgs a2 = a;
+                a2.hash_slots = g2.hash_slots;
+                a2.cand_cap = g2.cand_cap;
+                a2.res_cap = g2.res_cap;
+                a2.retry_only = 1;
+                HIPCHK(jvk_launch_search_lds(&ix->dev, &a2, pq ? 1 : 0, g2.pool ? 1 : 0, g2.lds_fast, stream));
+            }
+        }
+    }
     HIPCHK(jvk_launch_search_big(&ix->dev, &a, pq ? 1 : 0, c->big_blocks, g.lds_big, force_big ? 1 : 0, stream));
     return JV_OK;
 }
@@ -301,6 +335,8 @@ int jv_set_option(const char* name, int64_t value) {
     if (n == "lds_visited_slots") opt_lds_visited_slots = value;
     else if (n == "lds_candidates") opt_lds_candidates = value;
     else if (n == "force_big_path") opt_force_big = value;
+    else if (n == "force_general_path") opt_force_general = value;
+    else if (n == "no_escalation") opt_no_escalation = value;
     else if (n == "big_blocks") opt_big_blocks = value;
     else if (n == "big_cand_cap") opt_big_cand_cap = value;
     else return fail(JV_EINVAL, "unknown option '%s'", name);
@@ -503,8 +539,7 @@ int jv_index_create(const jv_index_desc* desc, jv_index** out) {
                 }
             }
         }
-        for (int pq = 0; pq < 2; pq++)
-            for (int big = 0; big < 2; big++) TRYHIP(jvk_set_max_lds(pq, big, kMaxLds));
+        TRYHIP(jvk_set_max_lds(kMaxLds));
         TRY(ctx_create(ix, &ix->async_ctx));
     }
     ix->info.n = n;

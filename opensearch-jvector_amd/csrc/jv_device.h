@@ -62,6 +62,7 @@ struct JvSearchArgs {
     int64_t* big_cand;       // [blocks][big_cand_cap]
     int32_t big_cand_cap;
     int32_t* work_counter;   // big path: dynamic query dequeue
+    int32_t retry_only;      // LDS kernel: process only queries whose flag has JV_FLAG_OVERFLOW
 };
 
 #define JV_FLAG_OVERFLOW 0x80000000u /* on-chip scratch overflow: query must be re-run on the big path */

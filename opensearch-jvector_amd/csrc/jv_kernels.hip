@@ -192,11 +192,92 @@ __device__ __forceinline__ void score_rows_t(const JvIndexDev& ix, const float* 
     }
 }
 
+// Same arithmetic, specialised for rows of exactly NCH 64-float chunks: every 16-B load of U row-groups
+// (4U rows) is issued before the first fma, so one pass costs one HBM round trip.
+template <int SIM, int NCH, int U, bool FULL>
+__device__ __forceinline__ void score_rows_fixed(const JvIndexDev& ix, const float* q_lds, const int32_t* todo,
+                                                 int m, float* todo_score, float qnorm2, float scale, int lane) {
+    const int g = lane >> 4, t = lane & 15;
+    const int stride = ix.stride;  // FULL: stride == NCH * 64, no partial chunk
+    for (int base = 0; base < m; base += 4 * U) {
+        f32x4 v[U][NCH];
+        bool val[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int r = base + 4 * u + g;
+            val[u] = r < m;
+            if (val[u]) {
+                const float* rp = ix.vectors + (size_t)todo[r] * (size_t)stride + 4 * t;
+#pragma unroll
+                for (int j = 0; j < NCH; j++) {
+                    if (FULL || (j * 64 + 4 * t) < stride) v[u][j] = *(const f32x4*)(rp + j * 64);
+                    else v[u][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NCH; j++) v[u][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        float acc[U][4], nrm[U][4];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) acc[u][e] = 0.0f, nrm[u][e] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NCH; j++) {
+            if (FULL || (j * 64 + 4 * t) < stride) {
+                const f32x4 qv = *(const f32x4*)(q_lds + j * 64 + 4 * t);
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        if (SIM == 0) {
+                            const float df = qv[e] - v[u][j][e];
+                            acc[u][e] = fmaf(df, df, acc[u][e]);
+                        } else {
+                            acc[u][e] = fmaf(qv[e], v[u][j][e], acc[u][e]);
+                            if (SIM == 2) nrm[u][e] = fmaf(v[u][j][e], v[u][j][e], nrm[u][e]);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            float s = (acc[u][0] + acc[u][1]) + (acc[u][2] + acc[u][3]);
+            s = row16_tree_sum(s);
+            float score;
+            if (SIM == 2) {
+                float nv = (nrm[u][0] + nrm[u][1]) + (nrm[u][2] + nrm[u][3]);
+                nv = row16_tree_sum(nv);
+                score = map_score(2, s / sqrtf(qnorm2 * nv));
+            } else {
+                score = map_score(SIM, s);
+            }
+            if (scale != 1.0f) score = score * scale;
+            if (t == 0 && val[u]) todo_score[base + 4 * u + g] = score;
+        }
+    }
+}
+
+// NCHT = number of 64-float chunks per row known at compile time (kernel template parameter; 0 = any d)
+template <int NCHT>
+struct RowsInFlight { static constexpr int U = NCHT <= 6 ? 4 : (NCHT <= 12 ? 2 : 1); };
+
+template <int NCHT>
 __device__ __forceinline__ void score_rows(const JvIndexDev& ix, const float* q_lds, const int32_t* todo, int m,
                                            float* todo_score, float qnorm2, float scale, int lane) {
-    if (ix.sim == 0) score_rows_t<0>(ix, q_lds, todo, m, todo_score, qnorm2, scale, lane);
-    else if (ix.sim == 1) score_rows_t<1>(ix, q_lds, todo, m, todo_score, qnorm2, scale, lane);
-    else score_rows_t<2>(ix, q_lds, todo, m, todo_score, qnorm2, scale, lane);
+    if (NCHT == 0) {
+        if (ix.sim == 0) score_rows_t<0>(ix, q_lds, todo, m, todo_score, qnorm2, scale, lane);
+        else if (ix.sim == 1) score_rows_t<1>(ix, q_lds, todo, m, todo_score, qnorm2, scale, lane);
+        else score_rows_t<2>(ix, q_lds, todo, m, todo_score, qnorm2, scale, lane);
+    } else {
+        constexpr int N = NCHT == 0 ? 1 : NCHT;
+        constexpr int U = RowsInFlight<N>::U;
+        if (ix.sim == 0) score_rows_fixed<0, N, U, true>(ix, q_lds, todo, m, todo_score, qnorm2, scale, lane);
+        else if (ix.sim == 1) score_rows_fixed<1, N, U, true>(ix, q_lds, todo, m, todo_score, qnorm2, scale, lane);
+        else score_rows_fixed<2, N, U, true>(ix, q_lds, todo, m, todo_score, qnorm2, scale, lane);
+    }
 }
 
 // canonical dot(q,q) for cosine: the row is the query itself (in LDS)
@@ -326,7 +407,39 @@ struct QState {
     bool overflow;
 };
 
-template <bool PQ, bool BIG>
+// pool keys: NodeQueue key with the constant bit 31 of the low word dropped and bit 0 = "not yet expanded";
+// the order between two different nodes is unchanged (score desc, ordinal asc)
+__device__ __forceinline__ int64_t make_pool_key(float score, int node) {
+    int32_t b = __float_as_int(score);
+    int32_t s = b ^ ((b >> 31) & 0x7fffffff);
+    return (int64_t)(((uint64_t)(uint32_t)s << 32) | ((uint64_t)((uint32_t)(~node) & 0x7FFFFFFFu) << 1) | 1ull);
+}
+__device__ __forceinline__ int64_t key_to_pool(int64_t k) {
+    return (int64_t)(((uint64_t)k & 0xFFFFFFFF00000000ull) | (((uint64_t)k & 0x7FFFFFFFull) << 1) | 1ull);
+}
+__device__ __forceinline__ int64_t pool_to_key(int64_t pk) {
+    return (int64_t)(((uint64_t)pk & 0xFFFFFFFF00000000ull) | 0x80000000ull | (((uint64_t)pk >> 1) & 0x7FFFFFFFull));
+}
+__device__ __forceinline__ int pool_node(int64_t pk) { return key_node(pool_to_key(pk)); }
+
+// keep the best rk entries of a descending pool plus every entry tied (equal score) with the rk-th
+__device__ __forceinline__ int pool_trim(const int64_t* pool, int np, int rk, int lane) {
+    if (np <= rk) return np;
+    const float b = key_score(pool[rk - 1]);
+    int extra = 0;
+    for (int b0 = rk; b0 < np; b0 += JV_WAVE) {
+        const int i = b0 + lane;
+        const bool tie = i < np && key_score(pool[i]) == b;
+        const unsigned long long tm = __ballot(tie);
+        extra += __popcll(tm);
+        if (tm != ~0ull) break;
+    }
+    return rk + extra;
+}
+
+// POOL: level 0 runs on one sorted pool (exact when there is no filter and threshold <= 0, ties included:
+// DESIGN.md "Single-pool search"); otherwise the two-queue form of jvector is executed literally.
+template <bool PQ, bool BIG, bool POOL, int NCHT>
 __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, unsigned char* smem,
                            int64_t* big_cand, uint32_t* big_bits) {
     const int lane = threadIdx.x;
@@ -339,6 +452,8 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
     off += JV_TODO * sizeof(float);
     int32_t* todo = (int32_t*)(smem + off);
     off += JV_TODO * sizeof(int32_t);
+    int64_t* newk = (int64_t*)(smem + off);
+    off += JV_TODO * sizeof(int64_t);
     float* lut = nullptr;
     if (PQ) {
         lut = (float*)(smem + off);
@@ -394,7 +509,7 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
 
     auto score_todo = [&](int m) {
         if (PQ) score_nodes_pq(ix, lut, todo, m, todo_score, qnorm2, lane);
-        else score_rows(ix, q_lds, todo, m, todo_score, qnorm2, search_scale, lane);
+        else score_rows<NCHT>(ix, q_lds, todo, m, todo_score, qnorm2, search_scale, lane);
         __syncthreads();
     };
 
@@ -415,7 +530,7 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
     }
 
     // ---- searchOneLayer for lvl = top .. 0 ----
-    for (int lvl = ix.num_upper; lvl >= 0 && !st.overflow; lvl--) {
+    for (int lvl = ix.num_upper; lvl >= (POOL ? 1 : 0) && !st.overflow; lvl--) {
         const int rk_cur = lvl > 0 ? 1 : rk;
         const float thr = lvl > 0 ? 0.0f : a.threshold;
         const bool accept_all = lvl > 0 || a.accept == nullptr;
@@ -553,6 +668,117 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
         }
     }
 
+    if (POOL && !st.overflow) {
+        // ---- level 0 on a single sorted pool ----
+        // The pool holds every scored node whose score >= the rk-th best score seen so far (so ties at the
+        // boundary stay), in NodeQueue order, with an "unexpanded" bit.  jvector pops the best unexpanded
+        // candidate and stops when it is worse than the rk-th best expanded one: with no filter and every
+        // score >= threshold that is exactly "expand the first unexpanded pool entry until none is left".
+        const int pool_limit = cand_cap - JV_WAVE;  // room for one chunk of 64 new keys beyond the trimmed pool
+        int64_t* cur = res;
+        int64_t* nxt = cand;
+        int np = st.ncand;
+        if (np > pool_limit) st.overflow = true;
+        if (!st.overflow) {
+            for (int i = lane; i < np; i += JV_WAVE) {
+                const int64_t v = cand[i];
+                int r = 0;
+                for (int j = 0; j < np; j++) r += cand[j] > v ? 1 : 0;
+                cur[r] = key_to_pool(v);
+            }
+            __syncthreads();
+            np = pool_trim(cur, np, rk, lane);
+        }
+        while (!st.overflow) {
+            int idx = -1;
+            for (int b0 = 0; b0 < np; b0 += JV_WAVE) {
+                const int i = b0 + lane;
+                const bool un = i < np && (cur[i] & 1ll);
+                const unsigned long long um = __ballot(un);
+                if (um) {
+                    idx = b0 + __ffsll((long long)um) - 1;
+                    break;
+                }
+            }
+            if (idx < 0) break;
+            const int64_t pk = cur[idx];
+            const float sc = key_score(pk);
+            if (sc < a.threshold) {  // a node the two-queue form would expand but not collect: take the general path
+                st.overflow = true;
+                break;
+            }
+            const int c = pool_node(pk);
+            const int32_t* row = ix.adj + (size_t)c * ix.R;
+            const int deg = ix.R;
+            int nb0 = (lane < deg) ? row[lane] : -1;
+            if (lane == 0) cur[idx] = pk & ~1ll;
+            for (int cb = 0; cb < deg; cb += JV_WAVE) {
+                const int nn = cb == 0 ? nb0 : ((cb + lane < deg) ? row[cb + lane] : -1);
+                if (st.nvisited_set + JV_WAVE > hash_limit) {
+                    st.overflow = true;
+                    break;
+                }
+                bool is_new = false;
+                if (nn >= 0) is_new = visited_insert_lds(hash, hmask, hshift, (uint32_t)nn);
+                const unsigned long long mask = __ballot(is_new);
+                const int m = __popcll(mask);
+                if (is_new) todo[__popcll(mask & ((1ull << lane) - 1ull))] = nn;
+                __syncthreads();
+                if (m == 0) continue;
+                st.nvisited_set += m;
+                st.visited += m;
+                score_todo(m);
+                bool keep = lane < m;
+                const float s = keep ? todo_score[lane] : 0.0f;
+                if (keep && np >= rk && s < key_score(cur[rk - 1])) keep = false;  // below the boundary for good
+                const unsigned long long km = __ballot(keep);
+                const int nk = __popcll(km);
+                if (nk == 0) continue;
+                if (keep) newk[__popcll(km & ((1ull << lane) - 1ull))] = make_pool_key(s, todo[lane]);
+                __syncthreads();
+                // rank merge of cur[0..np) and newk[0..nk) into nxt
+                if (lane < nk) {
+                    const int64_t v = newk[lane];
+                    int lo = 0, hi = np;
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (cur[mid] > v) lo = mid + 1;
+                        else hi = mid;
+                    }
+                    int r = lo;
+                    for (int j = 0; j < nk; j++) r += newk[j] > v ? 1 : 0;
+                    nxt[r] = v;
+                }
+                for (int i = lane; i < np; i += JV_WAVE) {
+                    const int64_t v = cur[i];
+                    int cnt = 0;
+                    for (int j = 0; j < nk; j++) cnt += newk[j] > v ? 1 : 0;
+                    nxt[i + cnt] = v;
+                }
+                __syncthreads();
+                int64_t* t = cur;
+                cur = nxt;
+                nxt = t;
+                np = pool_trim(cur, np + nk, rk, lane);
+                if (np > pool_limit) {  // more boundary ties than the pool has room for
+                    st.overflow = true;
+                    break;
+                }
+            }
+            if (st.overflow) break;
+            st.expanded++;
+            st.expanded_base++;
+        }
+        if (!st.overflow) {
+            // approximateResults = the best rk expanded nodes = the first rk pool entries
+            st.nres = np < rk ? np : rk;
+            for (int i = lane; i < st.nres; i += JV_WAVE) nxt[i] = pool_to_key(cur[i]);
+            __syncthreads();
+            res = nxt;
+            cand = cur;
+        }
+    }
+
     int32_t* o_nodes = a.out_nodes + (size_t)qi * topK;
     int32_t* o_docs = a.out_docs ? a.out_docs + (size_t)qi * topK : nullptr;
     float* o_scores = a.out_scores + (size_t)qi * topK;
@@ -597,7 +823,7 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
             if (take) todo[__popcll(tm & ((1ull << lane) - 1ull))] = node;
             __syncthreads();
             if (m > 0) {
-                score_rows(ix, q_lds, todo, m, todo_score, qnorm2, 1.0f, lane);
+                score_rows<NCHT>(ix, q_lds, todo, m, todo_score, qnorm2, 1.0f, lane);
                 __syncthreads();
                 if (lane < m) fin[nfin + lane] = make_key(todo_score[lane], todo[lane]);
                 nfin += m;
@@ -639,17 +865,19 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
 }
 
 // Fast path: one query per workgroup, all scratch in LDS.
-template <bool PQ>
+template <bool PQ, bool POOL, int NCHT>
 __global__ __launch_bounds__(JV_WAVE) void jv_search_lds_kernel(const JvIndexDev ix, const JvSearchArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int qi = blockIdx.x;
     if (qi >= a.nq) return;
-    search_one<PQ, false>(ix, a, qi, smem, nullptr, nullptr);
+    // escalation launch: only the queries an earlier (smaller) launch flagged as overflowed
+    if (a.retry_only && !((uint32_t)a.out_flags[qi] & JV_FLAG_OVERFLOW)) return;
+    search_one<PQ, false, POOL, NCHT>(ix, a, qi, smem, nullptr, nullptr);
 }
 
 // Big path: queues and visited bitset in HBM scratch; each resident workgroup dequeues the queries the
 // fast path flagged as overflowed.  Exact in all cases the fast path cannot hold on chip.
-template <bool PQ>
+template <bool PQ, int NCHT>
 __global__ __launch_bounds__(JV_WAVE) void jv_search_big_kernel(const JvIndexDev ix, const JvSearchArgs a,
                                                                  const int force_all) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -662,7 +890,7 @@ __global__ __launch_bounds__(JV_WAVE) void jv_search_big_kernel(const JvIndexDev
         const int qi = __shfl(next, 0, JV_WAVE);
         if (qi >= a.nq) break;
         if (!force_all && !((uint32_t)a.out_flags[qi] & JV_FLAG_OVERFLOW)) continue;
-        search_one<PQ, true>(ix, a, qi, smem, my_cand, my_bits);
+        search_one<PQ, true, false, NCHT>(ix, a, qi, smem, my_cand, my_bits);
         __syncthreads();
     }
 }
@@ -694,7 +922,7 @@ __global__ __launch_bounds__(JV_WAVE) void jv_score_ordinals_kernel(const JvInde
         const int pos = __popcll(mk & ((1ull << lane) - 1ull));
         if (ok) todo[pos] = o;
         __syncthreads();
-        if (m > 0) score_rows(ix, q_lds, todo, m, todo_score, qnorm2, ix.score_scale, lane);
+        if (m > 0) score_rows<0>(ix, q_lds, todo, m, todo_score, qnorm2, ix.score_scale, lane);
         __syncthreads();
         if (i < count) out[i] = ok ? todo_score[pos] : 0.0f;  // NO_VECTOR_OR_DELETED_DOC -> 0
         __syncthreads();
@@ -738,26 +966,48 @@ __global__ __launch_bounds__(JV_WAVE) void jv_merge_topk_kernel(const int32_t* d
 // ---------------------------------------------------------------------------------------------
 // launch wrappers (called from jv_abi.cpp)
 // ---------------------------------------------------------------------------------------------
-extern "C" hipError_t jvk_set_max_lds(int pq, int big, int bytes) {
-    const void* f;
-    if (!big) f = pq ? (const void*)jv_search_lds_kernel<true> : (const void*)jv_search_lds_kernel<false>;
-    else f = pq ? (const void*)jv_search_big_kernel<true> : (const void*)jv_search_big_kernel<false>;
-    return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+// kernel table: [pq][variant 0 = two-queue LDS, 1 = single-pool LDS, 2 = HBM scratch][nch slot]
+// nch slots: 0 -> any d (runtime chunk loop), 1 -> d = 128, 2 -> d = 768, 3 -> d = 1536
+typedef void (*lds_kernel_t)(const JvIndexDev, const JvSearchArgs);
+typedef void (*big_kernel_t)(const JvIndexDev, const JvSearchArgs, const int);
+#define JV_LDS_ROW(PQ, POOL) \
+    { jv_search_lds_kernel<PQ, POOL, 0>, jv_search_lds_kernel<PQ, POOL, 2>, jv_search_lds_kernel<PQ, POOL, 12>, jv_search_lds_kernel<PQ, POOL, 24> }
+static const lds_kernel_t g_lds_kernels[2][2][4] = {{JV_LDS_ROW(false, false), JV_LDS_ROW(false, true)},
+                                                    {JV_LDS_ROW(true, false), JV_LDS_ROW(true, true)}};
+static const big_kernel_t g_big_kernels[2][4] = {
+    {jv_search_big_kernel<false, 0>, jv_search_big_kernel<false, 2>, jv_search_big_kernel<false, 12>, jv_search_big_kernel<false, 24>},
+    {jv_search_big_kernel<true, 0>, jv_search_big_kernel<true, 2>, jv_search_big_kernel<true, 12>, jv_search_big_kernel<true, 24>}};
+
+static int nch_slot(const JvIndexDev* ix) {
+    if (ix->stride != ix->nch * 64) return 0;
+    return ix->nch == 2 ? 1 : ix->nch == 12 ? 2 : ix->nch == 24 ? 3 : 0;
 }
 
-extern "C" hipError_t jvk_launch_search_lds(const JvIndexDev* ix, const JvSearchArgs* a, int pq, int lds_bytes,
-                                            hipStream_t stream) {
+extern "C" hipError_t jvk_set_max_lds(int bytes) {
+    for (int pq = 0; pq < 2; pq++)
+        for (int s = 0; s < 4; s++) {
+            for (int v = 0; v < 2; v++) {
+                hipError_t e = hipFuncSetAttribute((const void*)g_lds_kernels[pq][v][s],
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+                if (e != hipSuccess) return e;
+            }
+            hipError_t e = hipFuncSetAttribute((const void*)g_big_kernels[pq][s], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            if (e != hipSuccess) return e;
+        }
+    return hipSuccess;
+}
+
+extern "C" hipError_t jvk_launch_search_lds(const JvIndexDev* ix, const JvSearchArgs* a, int pq, int pool,
+                                            int lds_bytes, hipStream_t stream) {
     if (a->nq <= 0) return hipSuccess;
-    if (pq) jv_search_lds_kernel<true><<<a->nq, JV_WAVE, lds_bytes, stream>>>(*ix, *a);
-    else jv_search_lds_kernel<false><<<a->nq, JV_WAVE, lds_bytes, stream>>>(*ix, *a);
+    g_lds_kernels[pq ? 1 : 0][pool ? 1 : 0][nch_slot(ix)]<<<a->nq, JV_WAVE, lds_bytes, stream>>>(*ix, *a);
     return hipGetLastError();
 }
 
 extern "C" hipError_t jvk_launch_search_big(const JvIndexDev* ix, const JvSearchArgs* a, int pq, int blocks,
                                             int lds_bytes, int force_all, hipStream_t stream) {
     if (a->nq <= 0) return hipSuccess;
-    if (pq) jv_search_big_kernel<true><<<blocks, JV_WAVE, lds_bytes, stream>>>(*ix, *a, force_all);
-    else jv_search_big_kernel<false><<<blocks, JV_WAVE, lds_bytes, stream>>>(*ix, *a, force_all);
+    g_big_kernels[pq ? 1 : 0][nch_slot(ix)]<<<blocks, JV_WAVE, lds_bytes, stream>>>(*ix, *a, force_all);
     return hipGetLastError();
 }
 

