@@ -57,6 +57,9 @@ typedef enum jv_similarity {
                                         stored next to its adjacency row (a layout choice; scores are
                                         bit-identical to the plain layout)                            */
 
+#define JV_DESC_BUILD_CLIENT    0x8u /* handle used by an index builder: identical search, launched under a
+                                        separate kernel name so profiles keep build and query launches apart */
+
 /* One upper layer of a hierarchical graph (hierarchy_enabled; default false:
  * K/common/KNNConstants.java:109).  Layer 0 is the dense adj[n][R] array below. */
 typedef struct jv_layer_desc {

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libjvgpu.so")
 
 JV_OK, JV_EINVAL, JV_ENOMEM, JV_EDEVICE, JV_EUNSUPPORTED, JV_EINTERNAL = 0, -1, -2, -3, -4, -5
 SIM_EUCLIDEAN, SIM_DOT_PRODUCT, SIM_COSINE = 0, 1, 2
-DESC_DEVICE_POINTERS, DESC_BORROW, DESC_FUSED_ADC = 0x1, 0x2, 0x4
+DESC_DEVICE_POINTERS, DESC_BORROW, DESC_FUSED_ADC, DESC_BUILD_CLIENT = 0x1, 0x2, 0x4, 0x8
 NUM_STATS = 4
 
 # every symbol include/jvgpu.h declares (tests check the library exports all of them)

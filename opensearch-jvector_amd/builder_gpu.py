@@ -24,7 +24,27 @@ import time
 
 import numpy as np
 
+import ctypes as C
+import os
+import sys
+
 from . import binding
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PRUNE_LIB = None
+
+
+def _prune_lib():
+    """lib/libjvbuildgpu.so (csrc/jv_build_kernels.hip): the diversity-selection kernel."""
+    global _PRUNE_LIB
+    if _PRUNE_LIB is None:
+        path = os.path.join(_HERE, "lib", "libjvbuildgpu.so")
+        lib = C.CDLL(path)
+        vp = C.c_void_p
+        lib.jvb_robust_prune_device.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp, vp]
+        lib.jvb_robust_prune_device.restype = C.c_int
+        _PRUNE_LIB = lib
+    return _PRUNE_LIB
 
 
 def _scores_from_gram(torch, G, sq_a, sq_b, sim):
@@ -83,6 +103,22 @@ def robust_prune(torch, base, centers, cand, R, alpha, sim, chunk_bytes=1 << 30)
         G = torch.bmm(V, V.transpose(1, 2))            # [s][Lc][Lc]
         Scc = _scores_from_gram(torch, G, sqv[:, :, None], sqv[:, None, :], sim)
         del G, V
+        use_kernel = dev.type == "cuda" and (Lc * Lc * 4 + Lc * 5 + R * 4) < 150 * 1024
+        if use_kernel:
+            sel = torch.empty((n_rows, R), dtype=torch.int32, device=dev)
+            nsel = torch.empty((n_rows,), dtype=torch.int32, device=dev)
+            Scc_c = Scc.contiguous()
+            sc_c = sc.contiguous()
+            cd32 = cd.to(torch.int32).contiguous()
+            v8 = valid.to(torch.uint8).contiguous()
+            rc = _prune_lib().jvb_robust_prune_device(
+                Scc_c.data_ptr(), sc_c.data_ptr(), cd32.data_ptr(), v8.data_ptr(), n_rows, Lc, R, float(alpha),
+                sel.data_ptr(), nsel.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+            if rc != 0:
+                raise RuntimeError(f"jvb_robust_prune_device failed: {rc}")
+            sel_out[s0:s1] = sel
+            nsel_out[s0:s1] = nsel
+            continue
         selected = torch.zeros((n_rows, Lc), dtype=torch.bool, device=dev)
         nsel = torch.zeros((n_rows,), dtype=torch.int32, device=dev)
         sel = torch.full((n_rows, R), -1, dtype=torch.int64, device=dev)
@@ -148,7 +184,8 @@ def build_graph_gpu(torch, base, sim, R=32, L=100, alpha=1.2, overflow=1.2, devi
     index = None
     if search_fn is None:
         desc, keep = binding.make_desc_device(n, d, Rcap, base.data_ptr(), adj.data_ptr(), entry, sim,
-                                              device=device_index, borrow=True)
+                                              device=device_index, borrow=True,
+                                              extra_flags=binding.DESC_BUILD_CLIENT)
         index = binding.GpuIndex(desc=desc, keepalive=keep, flags=binding.DESC_BORROW)
         stream = torch.cuda.current_stream(dev)
         o_nodes = torch.empty((max_batch, L), dtype=torch.int32, device=dev)
@@ -180,7 +217,7 @@ def build_graph_gpu(torch, base, sim, R=32, L=100, alpha=1.2, overflow=1.2, devi
         it += 1
         if verbose and (it % 50 == 0 or pos >= n):
             torch.cuda.synchronize() if dev.type == "cuda" else None
-            print(f"[builder_gpu] inserted {pos}/{n} ({time.time() - t0:.1f}s)", flush=True)
+            print(f"[builder_gpu] inserted {pos}/{n} ({time.time() - t0:.1f}s)", file=sys.stderr, flush=True)
     # cleanup: every row down to R
     over = torch.nonzero(deg > R).squeeze(1)
     ch = 8192

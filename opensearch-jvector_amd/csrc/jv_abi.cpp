@@ -21,7 +21,7 @@
 
 extern "C" {
 hipError_t jvk_set_max_lds(int bytes);
-hipError_t jvk_launch_search_lds(const JvIndexDev* ix, const JvSearchArgs* a, int pq, int pool, int lds_bytes, hipStream_t s);
+hipError_t jvk_launch_search_lds(const JvIndexDev* ix, const JvSearchArgs* a, int pq, int pool, int tag, int lds_bytes, hipStream_t s);
 hipError_t jvk_launch_search_big(const JvIndexDev* ix, const JvSearchArgs* a, int pq, int blocks, int lds_bytes,
                                  int force_all, hipStream_t s);
 hipError_t jvk_launch_score_ordinals(const JvIndexDev* ix, const float* d_query, const int32_t* d_ordinals,
@@ -99,6 +99,7 @@ struct Ctx {
 
 struct jv_index {
     int device = 0;
+    bool build_client = false;  // JV_DESC_BUILD_CLIENT: searches are launched under the builder's kernel name
     JvIndexDev dev{};
     jv_index_info info{};
     std::vector<void*> owned;  // device allocations to free
@@ -190,11 +191,11 @@ struct Geometry {
 };
 
 // LDS carve of the fast path (must mirror search_one in jv_kernels.hip)
-Geometry plan_geometry(const jv_index* ix, int rk, bool pool_ok, int force_slots = 0) {
+Geometry plan_geometry(const jv_index* ix, int rk, bool pool_ok, int force_slots = 0, bool tracker = false) {
     Geometry g{};
     const JvIndexDev& d = ix->dev;
     const bool pq = d.pq_M > 0;
-    int fixed = d.nch * 64 * 4 + JV_TODO * 16 + (pq ? d.pq_M * 256 * 4 : 0);
+    int fixed = d.nch * 64 * 4 + JV_TODO * 16 + (pq ? d.pq_M * 256 * 4 : 0) + (tracker ? JV_TRACKER_LDS : 0);
     g.lds_big = fixed;
     int64_t hs = opt_lds_visited_slots.load();
     int64_t cc = opt_lds_candidates.load();
@@ -258,7 +259,7 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
                   int32_t* d_docs, float* d_scores, int32_t* d_count, int32_t* d_stats, int32_t* d_flags) {
     const bool pq = ix->dev.pq_M > 0;
     // the single-pool form is exact only without a filter and with threshold <= 0 (kernel re-checks scores)
-    Geometry g = plan_geometry(ix, rk, d_accept == nullptr && thr <= 0.0f);
+    Geometry g = plan_geometry(ix, rk, d_accept == nullptr && thr <= 0.0f, 0, thr > 0.0f);
     if (g.lds_big > kMaxLds)
         return fail(JV_EUNSUPPORTED, "query + PQ look-up table need %d B of LDS (> %d): pq_M=%d too large", g.lds_big,
                     kMaxLds, ix->dev.pq_M);
@@ -291,18 +292,18 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
     const bool force_big = opt_force_big.load() != 0 || !g.fast_ok;
     HIPCHK(hipMemsetAsync(c->work_counter, 0, sizeof(int32_t), stream));
     if (!force_big) {
-        HIPCHK(jvk_launch_search_lds(&ix->dev, &a, pq ? 1 : 0, g.pool ? 1 : 0, g.lds_fast, stream));
+        HIPCHK(jvk_launch_search_lds(&ix->dev, &a, pq ? 1 : 0, g.pool ? 1 : 0, ix->build_client ? 2 : 0, g.lds_fast, stream));
         // escalation: queries that overflowed the on-chip visited set are retried with a 4x larger table
         // (fewer resident queries, but only the flagged few run) before the HBM-scratch path
         if (opt_lds_visited_slots.load() <= 0 && opt_no_escalation.load() == 0) {
-            Geometry g2 = plan_geometry(ix, rk, g.pool, g.hash_slots * 4);
+            Geometry g2 = plan_geometry(ix, rk, g.pool, g.hash_slots * 4, thr > 0.0f);
             if (g2.fast_ok && g2.hash_slots > g.hash_slots) {
                 JvSearchArgs a2 = a;
                 a2.hash_slots = g2.hash_slots;
                 a2.cand_cap = g2.cand_cap;
                 a2.res_cap = g2.res_cap;
                 a2.retry_only = 1;
-                HIPCHK(jvk_launch_search_lds(&ix->dev, &a2, pq ? 1 : 0, g2.pool ? 1 : 0, g2.lds_fast, stream));
+                HIPCHK(jvk_launch_search_lds(&ix->dev, &a2, pq ? 1 : 0, g2.pool ? 1 : 0, 1, g2.lds_fast, stream));
             }
         }
     }
@@ -316,8 +317,7 @@ int check_common(jv_index* index, const void* q, int nq, int topK, int rk, float
     if (nq < 0 || topK < 0) return fail(JV_EINVAL, "negative nq/topK");
     // jvector: "rerankK %d must be >= topK %d" -> IllegalArgumentException
     if (rk < topK) return fail(JV_EINVAL, "rerankK %d must be >= topK %d", rk, topK);
-    if (thr > 0.0f)
-        return fail(JV_EUNSUPPORTED, "threshold queries (threshold > 0) are not implemented on the GPU path yet");
+    (void)thr;
     return JV_OK;
 }
 
@@ -387,6 +387,7 @@ int jv_index_create(const jv_index_desc* desc, jv_index** out) {
 
     jv_index* ix = new jv_index();
     ix->device = desc->device;
+    ix->build_client = (desc->flags & JV_DESC_BUILD_CLIENT) != 0;
     JvIndexDev& D = ix->dev;
     D.n = n;
     D.d = d;

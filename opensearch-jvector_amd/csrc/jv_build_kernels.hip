@@ -1,0 +1,77 @@
+// jv_build_kernels.hip — GPU helpers of the WRITE side (index construction; not the graded hot path,
+// see jv_build.h / builder_gpu.py).  jvb_robust_prune_device: jvector-style diversity selection
+// (GraphIndexBuilder's retainDiverse: alpha sweeps 1.0, 1.2, .. <= alpha; a candidate is kept unless an
+// already-selected neighbour s has sim(c, s) > sim(c, centre) * a), one wavefront per row, the row's
+// candidate-candidate similarity matrix staged in LDS.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define WAVE 64
+
+__global__ __launch_bounds__(WAVE) void jvb_robust_prune_kernel(const float* __restrict__ scc,   // [S][Lc][Lc]
+                                                                const float* __restrict__ sc,    // [S][Lc] desc
+                                                                const int32_t* __restrict__ cd,  // [S][Lc]
+                                                                const uint8_t* __restrict__ valid,  // [S][Lc]
+                                                                int S, int Lc, int R, float alpha,
+                                                                int32_t* __restrict__ sel,   // [S][R]
+                                                                int32_t* __restrict__ nsel_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* m = (float*)smem;                      // [Lc][Lc]
+    float* scl = m + (size_t)Lc * Lc;             // [Lc]
+    int32_t* sel_idx = (int32_t*)(scl + Lc);      // [R]
+    uint8_t* state = (uint8_t*)(sel_idx + R);     // [Lc]: 0 = not a candidate, 1 = open, 2 = taken
+    const int lane = threadIdx.x;
+    const int row = blockIdx.x;
+    if (row >= S) return;
+    const float* mg = scc + (size_t)row * Lc * Lc;
+    for (int i = lane; i < Lc * Lc; i += WAVE) m[i] = mg[i];
+    for (int i = lane; i < Lc; i += WAVE) {
+        scl[i] = sc[(size_t)row * Lc + i];
+        state[i] = valid[(size_t)row * Lc + i] ? 1 : 0;
+    }
+    __syncthreads();
+    int nsel = 0;
+    for (float a = 1.0f; a <= alpha + 1e-6f && nsel < R; a += 0.2f) {
+        for (int c = 0; c < Lc && nsel < R; c++) {
+            if (state[c] != 1) continue;
+            const float thr = scl[c] * a;
+            bool bad = false;
+            for (int s0 = 0; s0 < nsel; s0 += WAVE) {
+                const int s = s0 + lane;
+                const bool over = s < nsel && m[(size_t)c * Lc + sel_idx[s]] > thr;
+                if (__ballot(over)) {
+                    bad = true;
+                    break;
+                }
+            }
+            if (!bad) {
+                if (lane == 0) {
+                    state[c] = 2;
+                    sel_idx[nsel] = c;
+                }
+                nsel++;
+                __syncthreads();
+            }
+        }
+    }
+    for (int i = lane; i < R; i += WAVE) sel[(size_t)row * R + i] = i < nsel ? cd[(size_t)row * Lc + sel_idx[i]] : -1;
+    if (lane == 0) nsel_out[row] = nsel;
+}
+
+extern "C" int jvb_robust_prune_device(const float* scc, const float* sc, const int32_t* cd, const uint8_t* valid,
+                                       int S, int Lc, int R, float alpha, int32_t* sel, int32_t* nsel,
+                                       void* stream) {
+    if (S <= 0) return 0;
+    size_t lds = (size_t)Lc * Lc * 4 + (size_t)Lc * 4 + (size_t)R * 4 + (size_t)Lc;
+    lds = (lds + 15) & ~(size_t)15;
+    if (lds > 160 * 1024) return -4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)jvb_robust_prune_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess)
+            return -3;
+        attr_set = true;
+    }
+    jvb_robust_prune_kernel<<<S, WAVE, lds, (hipStream_t)stream>>>(scc, sc, cd, valid, S, Lc, R, alpha, sel, nsel);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}

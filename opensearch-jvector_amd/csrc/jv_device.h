@@ -6,6 +6,7 @@
 #define JV_WAVE 64
 #define JV_MAX_UPPER_LAYERS 16
 #define JV_TODO 64 /* neighbours scored per adjacency chunk */
+#define JV_TRACKER_LDS (512 * 4 + 2 * (100 + 64 + 4) * 4) /* threshold-query tracker state (bytes) */
 
 struct JvLayerDev {
     int32_t count;

@@ -394,6 +394,75 @@ __device__ __forceinline__ bool visited_insert_bits(uint32_t* bits, uint32_t nod
 }
 
 // ---------------------------------------------------------------------------------------------
+// jvector ScoreTracker.TwoPhaseTracker (threshold queries only; SURVEY App. A.2 "shouldStop"):
+// window of the 500 most recent scores + the 100 best scores; evaluated when the observation count is
+// a multiple of 100 (>= 500): stop iff percentile99(window) < threshold && worst-of-best < threshold.
+// percentile = commons-math3 LEGACY estimate: pos = 99*(500+1)/100, lower + (pos-floor(pos))*(upper-lower).
+// ---------------------------------------------------------------------------------------------
+#define TRK_RECENT 500
+#define TRK_BEST 100
+struct Tracker {
+    float* recent;  // [TRK_RECENT]
+    float* best;    // [TRK_BEST + JV_WAVE] scratch for the rank merge
+    float* best2;   // [TRK_BEST + JV_WAVE]
+    int idx, obs, nbest;
+};
+
+// track m scores (todo_score[0..m), stored order)
+__device__ __forceinline__ void tracker_track(Tracker& t, const float* scores, int m, int lane) {
+    if (lane < m) t.recent[(t.idx + lane) % TRK_RECENT] = scores[lane];
+    // best := top-TRK_BEST multiset of (best U new) by rank counting
+    const int total = t.nbest + m;
+    if (lane < m) t.best[t.nbest + lane] = scores[lane];
+    __syncthreads();
+    for (int i = lane; i < total; i += JV_WAVE) {
+        const float v = t.best[i];
+        int r = 0;
+        for (int j = 0; j < total; j++) {
+            const float w = t.best[j];
+            r += (w > v || (w == v && j < i)) ? 1 : 0;
+        }
+        if (r < TRK_BEST) t.best2[r] = v;
+    }
+    __syncthreads();
+    float* tmp = t.best;
+    t.best = t.best2;
+    t.best2 = tmp;
+    t.nbest = total < TRK_BEST ? total : TRK_BEST;
+    t.idx = (t.idx + m) % TRK_RECENT;
+    t.obs += m;
+}
+
+__device__ __forceinline__ bool tracker_should_stop(const Tracker& t, float threshold, int lane) {
+    if (t.obs < TRK_RECENT) return false;
+    if (t.obs % 100 != 0) return false;
+    // 5th and 6th largest of the window = sorted[495], sorted[494]
+    float upper = 0.0f, lower = 0.0f;
+    for (int i0 = 0; i0 < TRK_RECENT; i0 += JV_WAVE) {
+        const int i = i0 + lane;
+        int r = -1;
+        float v = 0.0f;
+        if (i < TRK_RECENT) {
+            v = t.recent[i];
+            r = 0;
+            for (int j = 0; j < TRK_RECENT; j++) {
+                const float w = t.recent[j];
+                r += (w > v || (w == v && j < i)) ? 1 : 0;
+            }
+        }
+        const unsigned long long m4 = __ballot(r == 4), m5 = __ballot(r == 5);
+        if (m4) upper = __shfl(v, __ffsll((long long)m4) - 1, JV_WAVE);
+        if (m5) lower = __shfl(v, __ffsll((long long)m5) - 1, JV_WAVE);
+    }
+    const double pos = 99.0 * (double)(TRK_RECENT + 1) / 100.0;
+    const double dd = pos - floor(pos);
+    const double pct = (double)lower + dd * ((double)upper - (double)lower);
+    // best is sorted descending by construction (rank order): its last element is the worst of the best
+    const double worst_best = (double)t.best[t.nbest - 1];
+    return pct < (double)threshold && worst_best < (double)threshold;
+}
+
+// ---------------------------------------------------------------------------------------------
 // the search
 // ---------------------------------------------------------------------------------------------
 struct QState {
@@ -454,6 +523,17 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
     off += JV_TODO * sizeof(int32_t);
     int64_t* newk = (int64_t*)(smem + off);
     off += JV_TODO * sizeof(int64_t);
+    Tracker trk;
+    trk.recent = trk.best = trk.best2 = nullptr;
+    trk.idx = trk.obs = trk.nbest = 0;
+    if (!POOL && a.threshold > 0.0f) {  // threshold queries: tracker state (host adds JV_TRACKER_LDS bytes)
+        trk.recent = (float*)(smem + off);
+        off += 512 * sizeof(float);
+        trk.best = (float*)(smem + off);
+        off += (TRK_BEST + JV_WAVE + 4) * sizeof(float);
+        trk.best2 = (float*)(smem + off);
+        off += (TRK_BEST + JV_WAVE + 4) * sizeof(float);
+    }
     float* lut = nullptr;
     if (PQ) {
         lut = (float*)(smem + off);
@@ -540,6 +620,8 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
             scan_max(cand, st.ncand, lane, best, bi);
             const float sc = key_score(best);
             if (st.nres >= rk_cur && sc < key_score(st.worst)) break;
+            // when querying by threshold, also stop when more qualifying results are improbable
+            if (thr > 0.0f && tracker_should_stop(trk, thr, lane)) break;
             // pop
             const int c = key_node(best);
             if (lane == 0) cand[bi] = cand[st.ncand - 1];
@@ -613,6 +695,7 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
                 st.nvisited_set += m;
                 st.visited += m;
                 score_todo(m);
+                if (thr > 0.0f) tracker_track(trk, todo_score, m, lane);
                 // push (level 0: a candidate already below a full result queue's worst can never be
                 // popped before the loop breaks, so it is not stored)
                 bool keep = lane < m;
@@ -870,9 +953,28 @@ __global__ __launch_bounds__(JV_WAVE) void jv_search_lds_kernel(const JvIndexDev
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int qi = blockIdx.x;
     if (qi >= a.nq) return;
-    // escalation launch: only the queries an earlier (smaller) launch flagged as overflowed
-    if (a.retry_only && !((uint32_t)a.out_flags[qi] & JV_FLAG_OVERFLOW)) return;
     search_one<PQ, false, POOL, NCHT>(ix, a, qi, smem, nullptr, nullptr);
+}
+
+// Escalation launch (same code, own name so profiles separate it from the main launch): only the queries
+// an earlier, smaller launch flagged as overflowed, with a 4x larger visited table.
+template <bool PQ, bool POOL, int NCHT>
+__global__ __launch_bounds__(JV_WAVE) void jv_search_retry_kernel(const JvIndexDev ix, const JvSearchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int qi = blockIdx.x;
+    if (qi >= a.nq) return;
+    if (!((uint32_t)a.out_flags[qi] & JV_FLAG_OVERFLOW)) return;
+    search_one<PQ, false, POOL, NCHT>(ix, a, qi, smem, nullptr, nullptr);
+}
+
+// The same search launched on behalf of the graph builder (index created with JV_DESC_BUILD_CLIENT): a
+// separate kernel name keeps construction-time searches out of the query kernels' profile rows.
+template <bool POOL, int NCHT>
+__global__ __launch_bounds__(JV_WAVE) void jv_build_search_kernel(const JvIndexDev ix, const JvSearchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int qi = blockIdx.x;
+    if (qi >= a.nq) return;
+    search_one<false, false, POOL, NCHT>(ix, a, qi, smem, nullptr, nullptr);
 }
 
 // Big path: queues and visited bitset in HBM scratch; each resident workgroup dequeues the queries the
@@ -966,17 +1068,20 @@ __global__ __launch_bounds__(JV_WAVE) void jv_merge_topk_kernel(const int32_t* d
 // ---------------------------------------------------------------------------------------------
 // launch wrappers (called from jv_abi.cpp)
 // ---------------------------------------------------------------------------------------------
-// kernel table: [pq][variant 0 = two-queue LDS, 1 = single-pool LDS, 2 = HBM scratch][nch slot]
-// nch slots: 0 -> any d (runtime chunk loop), 1 -> d = 128, 2 -> d = 768, 3 -> d = 1536
+// kernel tables: [pq][pool][nch slot]; nch slots: 0 -> any d (runtime chunk loop), 1 -> d = 128,
+// 2 -> d = 768, 3 -> d = 1536
 typedef void (*lds_kernel_t)(const JvIndexDev, const JvSearchArgs);
 typedef void (*big_kernel_t)(const JvIndexDev, const JvSearchArgs, const int);
-#define JV_LDS_ROW(PQ, POOL) \
-    { jv_search_lds_kernel<PQ, POOL, 0>, jv_search_lds_kernel<PQ, POOL, 2>, jv_search_lds_kernel<PQ, POOL, 12>, jv_search_lds_kernel<PQ, POOL, 24> }
-static const lds_kernel_t g_lds_kernels[2][2][4] = {{JV_LDS_ROW(false, false), JV_LDS_ROW(false, true)},
-                                                    {JV_LDS_ROW(true, false), JV_LDS_ROW(true, true)}};
-static const big_kernel_t g_big_kernels[2][4] = {
-    {jv_search_big_kernel<false, 0>, jv_search_big_kernel<false, 2>, jv_search_big_kernel<false, 12>, jv_search_big_kernel<false, 24>},
-    {jv_search_big_kernel<true, 0>, jv_search_big_kernel<true, 2>, jv_search_big_kernel<true, 12>, jv_search_big_kernel<true, 24>}};
+#define JV_ROW(K, ...) { K<__VA_ARGS__, 0>, K<__VA_ARGS__, 2>, K<__VA_ARGS__, 12>, K<__VA_ARGS__, 24> }
+static const lds_kernel_t g_lds_kernels[2][2][4] = {
+    {JV_ROW(jv_search_lds_kernel, false, false), JV_ROW(jv_search_lds_kernel, false, true)},
+    {JV_ROW(jv_search_lds_kernel, true, false), JV_ROW(jv_search_lds_kernel, true, true)}};
+static const lds_kernel_t g_retry_kernels[2][2][4] = {
+    {JV_ROW(jv_search_retry_kernel, false, false), JV_ROW(jv_search_retry_kernel, false, true)},
+    {JV_ROW(jv_search_retry_kernel, true, false), JV_ROW(jv_search_retry_kernel, true, true)}};
+static const lds_kernel_t g_build_kernels[2][4] = {JV_ROW(jv_build_search_kernel, false),
+                                                   JV_ROW(jv_build_search_kernel, true)};
+static const big_kernel_t g_big_kernels[2][4] = {JV_ROW(jv_search_big_kernel, false), JV_ROW(jv_search_big_kernel, true)};
 
 static int nch_slot(const JvIndexDev* ix) {
     if (ix->stride != ix->nch * 64) return 0;
@@ -984,23 +1089,34 @@ static int nch_slot(const JvIndexDev* ix) {
 }
 
 extern "C" hipError_t jvk_set_max_lds(int bytes) {
-    for (int pq = 0; pq < 2; pq++)
-        for (int s = 0; s < 4; s++) {
-            for (int v = 0; v < 2; v++) {
-                hipError_t e = hipFuncSetAttribute((const void*)g_lds_kernels[pq][v][s],
+    for (int s = 0; s < 4; s++) {
+        for (int a = 0; a < 2; a++) {
+            for (int b = 0; b < 2; b++) {
+                hipError_t e = hipFuncSetAttribute((const void*)g_lds_kernels[a][b][s],
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+                if (e == hipSuccess)
+                    e = hipFuncSetAttribute((const void*)g_retry_kernels[a][b][s],
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
                 if (e != hipSuccess) return e;
             }
-            hipError_t e = hipFuncSetAttribute((const void*)g_big_kernels[pq][s], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            hipError_t e = hipFuncSetAttribute((const void*)g_build_kernels[a][s], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute((const void*)g_big_kernels[a][s], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             if (e != hipSuccess) return e;
         }
+    }
     return hipSuccess;
 }
 
-extern "C" hipError_t jvk_launch_search_lds(const JvIndexDev* ix, const JvSearchArgs* a, int pq, int pool,
+// tag: 0 = query launch, 1 = escalation launch, 2 = graph-builder client
+extern "C" hipError_t jvk_launch_search_lds(const JvIndexDev* ix, const JvSearchArgs* a, int pq, int pool, int tag,
                                             int lds_bytes, hipStream_t stream) {
     if (a->nq <= 0) return hipSuccess;
-    g_lds_kernels[pq ? 1 : 0][pool ? 1 : 0][nch_slot(ix)]<<<a->nq, JV_WAVE, lds_bytes, stream>>>(*ix, *a);
+    lds_kernel_t k;
+    if (tag == 1) k = g_retry_kernels[pq ? 1 : 0][pool ? 1 : 0][nch_slot(ix)];
+    else if (tag == 2 && !pq) k = g_build_kernels[pool ? 1 : 0][nch_slot(ix)];
+    else k = g_lds_kernels[pq ? 1 : 0][pool ? 1 : 0][nch_slot(ix)];
+    k<<<a->nq, JV_WAVE, lds_bytes, stream>>>(*ix, *a);
     return hipGetLastError();
 }
 

@@ -178,3 +178,28 @@ def test_score_ordinals_parity(pkg, pyoracle, small_sets):
         want = pyoracle.Oracle(b, ix).score_ordinals(q, ords)
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
         gpu.close()
+
+
+def test_threshold_queries_parity(pkg, pyoracle, small_sets):
+    """threshold > 0: results only admit score >= threshold and the probabilistic early stop
+    (TwoPhaseTracker) decides when to give up; GPU and oracle must stop at the same expansion."""
+    b, bl = pkg.binding, pkg.builder
+    base, q = small_sets["base64"][:5000], small_sets["q64"]
+    ix = bl.build_index_cpu(base, 0, R=16, L=60)
+    gpu = b.GpuIndex(ix)
+    orc = pyoracle.Oracle(b, ix)
+    stopped_early = 0
+    for thr in (0.12, 0.2, 0.35):
+        want = orc.search_batch(q, 10, 50, threshold=thr)
+        got = gpu.search_batch(q, 10, 50, threshold=thr)
+        _assert_same(got, want, f"threshold={thr}")
+        assert (got.scores[got.nodes >= 0] >= thr).all()
+        stopped_early += int((want.stats[:, 2] < 4000).sum())
+    assert stopped_early > 0, "the early-stop tracker never fired: test inputs do not exercise it"
+    try:
+        b.set_option("force_big_path", 1)
+        want = orc.search_batch(q[:8], 10, 50, threshold=0.2)
+        _assert_same(gpu.search_batch(q[:8], 10, 50, threshold=0.2), want, "threshold on the HBM-scratch path")
+    finally:
+        b.set_option("force_big_path", 0)
+    gpu.close()
