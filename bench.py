@@ -141,15 +141,17 @@ def recall_of(found_docs, truth):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=os.environ.get("JV_BENCH_WORKLOAD", "c3"), choices=sorted(WORKLOADS))
     ap.add_argument("--n", type=int, default=int(os.environ.get("JV_BENCH_N", "0")), help="docs per GPU (0 = workload default)")
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("JV_BENCH_BATCH", "16384")), help="queries per step")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("JV_BENCH_BATCH", "65536")), help="queries per step")
     ap.add_argument("--rerankk", type=int, default=int(os.environ.get("JV_BENCH_RERANKK", "0")), help="0 = sweep for recall>=0.95")
     ap.add_argument("--builder", default=os.environ.get("JV_BENCH_BUILDER", "gpu"), choices=["gpu", "cpu"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--profile-mode", action="store_true",
+                    help="only warm-up + timed launches of the query kernel (needs --rerankk): no recall sweep, no p50, no CPU leg")
     args = ap.parse_args()
 
     import torch
@@ -188,7 +190,7 @@ def main():
     # ---- data in HBM ----
     t0 = time.time()
     centres = max(64, min(4096, n // 256))
-    nq_pool = args.batch * 4
+    nq_pool = args.batch * 2
     if pq_M:
         sigma = float(os.environ.get("JV_BENCH_SIGMA", "0.35"))
         zc, Bl, Bg = make_block_generators(torch, d, device, centres, M=pq_M, per=2)
@@ -226,7 +228,8 @@ def main():
         n, d, R, base.data_ptr(), adj_t.data_ptr(), entry, sim, device=local_rank,
         pq_M=pq_M, pq_K=(pq["K"] if pq else 0), pq_codebooks=(pq["codebooks"] if pq else None),
         pq_centroid=(pq["centroid"] if pq else None), pq_codes_ptr=(pq["codes"].data_ptr() if pq else 0),
-        ord2doc_ptr=(ord2doc.data_ptr() if ord2doc is not None else 0), max_doc=n * world, borrow=True)
+        ord2doc_ptr=(ord2doc.data_ptr() if ord2doc is not None else 0), max_doc=n * world, borrow=True,
+        extra_flags=(binding.DESC_FUSED_ADC if (pq and os.environ.get("JV_BENCH_FUSED", "1") == "1") else 0))
     index = binding.GpuIndex(desc=desc, keepalive=keep, flags=binding.DESC_BORROW)
 
     # ---- search plumbing: everything device-resident, own stream ----
@@ -286,6 +289,10 @@ def main():
         gt = gt_local
     sweep = [args.rerankk] if args.rerankk > 0 else [20, 30, 50, 70, 100, 150, 200, 300, 400]
     chosen, chosen_recall, sweep_log = None, 0.0, []
+    if args.profile_mode:
+        if args.rerankk <= 0:
+            raise SystemExit("--profile-mode needs --rerankk")
+        sweep, chosen, chosen_recall = [], args.rerankk, float("nan")
     for rk in sweep:
         docs, _ = run_step(queries[:n_gt], rk, nq=n_gt)
         stream.synchronize()
@@ -348,16 +355,18 @@ def main():
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tpath):
+        # HBM bytes per launch from the PMC passes of the same command (tools/profile_bench.sh ->
+        # tools/summarize_profile.py); used only when workload, n, batch and rerankK all match this run
         try:
-            tj = json.load(open(tpath))
-            if tj.get("workload") == args.workload and tj.get("n") == n and tj.get("batch") == B and tj.get("rerankK") == rk:
+            tj = json.load(open(tpath)).get("entries", {}).get(args.workload)
+            if tj and tj.get("n") == n and tj.get("batch") == B and tj.get("rerankK") == rk:
                 traffic = tj.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
 
     # ---- p50 latency: one query in flight through the host-pointer API ----
-    qh = queries[:200].cpu().numpy()
-    lat = []
+    qh = queries[:(0 if args.profile_mode else 200)].cpu().numpy()
+    lat = [0.0] * 21
     for i in range(len(qh)):
         t1 = time.perf_counter()
         index.search(qh[i], k, rk)
@@ -382,9 +391,9 @@ def main():
             "docs_per_gpu": n, "total_docs": n * world, "dim": d, "similarity": ["l2", "dot", "cosine"][sim],
             "R": R, "ef_construction": L, "k": k, "rerankK": rk, "pq_M": pq_M, "queries_per_step": B,
             "sharding": "doc-id range, RCCL all-gather of per-shard top-k + GPU merge" if world > 1 else "single GPU",
-            "graph_builder": args.builder,
+            "graph_builder": args.builder, "pq_layout": ("fused" if (pq_M and os.environ.get("JV_BENCH_FUSED", "1") == "1") else ("plain" if pq_M else None)),
         },
-        "recall_at_10": round(chosen_recall, 4),
+        "recall_at_10": (None if chosen_recall != chosen_recall else round(chosen_recall, 4)),
         "recall_sweep": sweep_log,
         "p50_latency_ms": round(p50, 4),
         "per_query": {"visited": round(visited / total_queries, 1), "expanded": round(expanded / total_queries, 1),
@@ -399,7 +408,7 @@ def main():
     }
 
     # ---- CPU baseline: the oracle (a port/restatement, NOT real jVector) on this box's host cores ----
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.profile_mode:
         try:
             result["cpu_baseline"] = cpu_baseline(torch, binding, base, adj_t, entry, sim, pq, queries, k, rk, out_nodes,
                                                   index, run_step, stream, args.cpu_seconds)

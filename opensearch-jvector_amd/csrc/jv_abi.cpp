@@ -21,6 +21,7 @@
 
 extern "C" {
 hipError_t jvk_set_max_lds(int bytes);
+hipError_t jvk_build_fused(const uint8_t* codes, const int32_t* adj, uint8_t* fused, long long n, int R, int cs, hipStream_t s);
 hipError_t jvk_launch_search_lds(const JvIndexDev* ix, const JvSearchArgs* a, int pq, int pool, int tag, int lds_bytes, hipStream_t s);
 hipError_t jvk_launch_search_big(const JvIndexDev* ix, const JvSearchArgs* a, int pq, int blocks, int lds_bytes,
                                  int force_all, hipStream_t s);
@@ -60,6 +61,7 @@ std::atomic<int64_t> opt_lds_candidates{0};     // 0 = auto
 std::atomic<int64_t> opt_force_big{0};
 std::atomic<int64_t> opt_force_general{0};
 std::atomic<int64_t> opt_no_escalation{0};
+std::atomic<int64_t> opt_dbg_ptr{0};
 std::atomic<int64_t> opt_big_blocks{256};
 std::atomic<int64_t> opt_big_cand_cap{65536};
 
@@ -195,7 +197,7 @@ Geometry plan_geometry(const jv_index* ix, int rk, bool pool_ok, int force_slots
     Geometry g{};
     const JvIndexDev& d = ix->dev;
     const bool pq = d.pq_M > 0;
-    int fixed = d.nch * 64 * 4 + JV_TODO * 16 + (pq ? d.pq_M * 256 * 4 : 0) + (tracker ? JV_TRACKER_LDS : 0);
+    int fixed = d.nch * 64 * 4 + JV_TODO * 16 + (pq ? d.pq_M * 256 * 4 + d.nch * 64 * 4 : 0) + (tracker ? JV_TRACKER_LDS : 0);
     g.lds_big = fixed;
     int64_t hs = opt_lds_visited_slots.load();
     int64_t cc = opt_lds_candidates.load();
@@ -289,6 +291,7 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
     a.big_cand_cap = c->big_cand_cap;
     a.work_counter = c->work_counter;
     a.retry_only = 0;
+    a.dbg = (int64_t*)(uintptr_t)opt_dbg_ptr.load();  // always 0 unless a diagnostic run set it
     const bool force_big = opt_force_big.load() != 0 || !g.fast_ok;
     HIPCHK(hipMemsetAsync(c->work_counter, 0, sizeof(int32_t), stream));
     if (!force_big) {
@@ -337,6 +340,7 @@ int jv_set_option(const char* name, int64_t value) {
     else if (n == "force_big_path") opt_force_big = value;
     else if (n == "force_general_path") opt_force_general = value;
     else if (n == "no_escalation") opt_no_escalation = value;
+    else if (n == "dbg_ptr") opt_dbg_ptr = value;
     else if (n == "big_blocks") opt_big_blocks = value;
     else if (n == "big_cand_cap") opt_big_cand_cap = value;
     else return fail(JV_EINVAL, "unknown option '%s'", name);
@@ -376,7 +380,6 @@ int jv_index_create(const jv_index_desc* desc, jv_index** out) {
     }
     const bool devptr = (desc->flags & JV_DESC_DEVICE_POINTERS) != 0;
     const bool borrow = devptr && (desc->flags & JV_DESC_BORROW) != 0;
-    if (desc->flags & JV_DESC_FUSED_ADC) return fail(JV_EUNSUPPORTED, "fused ADC layout not implemented yet");
 
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -540,6 +543,15 @@ int jv_index_create(const jv_index_desc* desc, jv_index** out) {
                 }
             }
         }
+        if (M > 0 && n > 0 && (desc->flags & JV_DESC_FUSED_ADC)) {
+            // fused layout: each node's neighbours' codes next to each other, in adjacency order
+            uint8_t* fused = nullptr;
+            TRY(dev_alloc(ix, &fused, (size_t)n * R * D.pq_code_stride));
+            TRYHIP(jvk_build_fused(D.pq_codes, D.adj, fused, (long long)n, R, D.pq_code_stride, nullptr));
+            TRYHIP(hipDeviceSynchronize());
+            D.pq_fused = fused;
+            ix->info.fused_adc = 1;
+        }
         TRYHIP(jvk_set_max_lds(kMaxLds));
         TRY(ctx_create(ix, &ix->async_ctx));
     }
@@ -552,7 +564,6 @@ int jv_index_create(const jv_index_desc* desc, jv_index** out) {
     ix->info.num_upper_layers = D.num_upper;
     ix->info.device = ix->device;
     ix->info.row_stride_floats = D.stride;
-    ix->info.fused_adc = 0;
     *out = ix;
     return JV_OK;
 error:

@@ -64,6 +64,7 @@ struct JvSearchArgs {
     int32_t big_cand_cap;
     int32_t* work_counter;   // big path: dynamic query dequeue
     int32_t retry_only;      // LDS kernel: process only queries whose flag has JV_FLAG_OVERFLOW
+    int64_t* dbg;            // diagnostic build (-DJV_STAMPS) only: 8 cycle accumulators; nullptr in the product
 };
 
 #define JV_FLAG_OVERFLOW 0x80000000u /* on-chip scratch overflow: query must be re-run on the big path */

@@ -24,6 +24,20 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+// Diagnostic build only (-DJV_STAMPS, lib/libjvgpu_stamps.so): per-phase cycle shares of the pool loop are
+// accumulated into a.dbg; never compiled into the product library and never read by the kernel itself.
+#ifdef JV_STAMPS
+#define STAMP_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_last = clock64();
+#define STAMP(i) { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = clock64(); st_acc[i] += t_ - st_last; st_last = t_; __builtin_amdgcn_sched_barrier(0); }
+#define STAMP_FLUSH if (a.dbg && lane == 0) { for (int i_ = 0; i_ < 8; i_++) atomicAdd((unsigned long long*)a.dbg + i_, st_acc[i_]); }
+#define STAMP_COUNT(i, v) { st_acc[i] += (v); }
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_FLUSH
+#define STAMP_COUNT(i, v)
+#endif
+
 #define KEY_MIN ((int64_t)0x8000000000000000ll)
 #define KEY_MAX ((int64_t)0x7fffffffffffffffll)
 #define HASH_EMPTY 0xFFFFFFFFu
@@ -299,23 +313,33 @@ __device__ __forceinline__ float query_norm2(const JvIndexDev& ix, const float* 
 // PQ: per-query look-up table in LDS, ADC scoring (jvector PQVectors.precomputedScoreFunctionFor /
 // PQDecoder).  lut[m][c] is a sequential fmaf chain over the subspace.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void build_lut(const JvIndexDev& ix, const float* q_lds, float* lut, int lane) {
+__device__ __forceinline__ void build_lut(const JvIndexDev& ix, const float* qc_lds, float* lut, int lane) {
     const int M = ix.pq_M;
     const bool l2 = ix.sim == 0;
+    constexpr int PF = 16;  // codebook rows in flight per lane (each a 1 KiB wave-wide read of the transposed codebook)
     for (int m = 0; m < M; m++) {
         const int d0 = ix.pq_sub_off[m], d1 = ix.pq_sub_off[m + 1];
         float a[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int dim = d0; dim < d1; dim++) {
-            float qc = q_lds[dim];
-            if (ix.pq_centroid) qc = qc - ix.pq_centroid[dim];
-            const f32x4 cb = *(const f32x4*)(ix.pq_cbT + (size_t)dim * 256 + 4 * lane);
+        for (int db = d0; db < d1; db += PF) {
+            f32x4 cb[PF];
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                if (l2) {
-                    float df = qc - cb[e];
-                    a[e] = fmaf(df, df, a[e]);
-                } else {
-                    a[e] = fmaf(qc, cb[e], a[e]);
+            for (int u = 0; u < PF; u++) {
+                if (db + u < d1) cb[u] = *(const f32x4*)(ix.pq_cbT + (size_t)(db + u) * 256 + 4 * lane);
+                else cb[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < PF; u++) {  // the fmaf chain stays in dimension order (canonical)
+                if (db + u < d1) {
+                    const float qc = qc_lds[db + u];  // q - globalCentroid (or q when there is no centroid)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        if (l2) {
+                            float df = qc - cb[u][e];
+                            a[e] = fmaf(df, df, a[e]);
+                        } else {
+                            a[e] = fmaf(qc, cb[u][e], a[e]);
+                        }
+                    }
                 }
             }
         }
@@ -535,9 +559,12 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
         off += (TRK_BEST + JV_WAVE + 4) * sizeof(float);
     }
     float* lut = nullptr;
+    float* qc_lds = nullptr;  // PQ: the centred query q' = q - globalCentroid
     if (PQ) {
         lut = (float*)(smem + off);
         off += (size_t)ix.pq_M * 256 * sizeof(float);
+        qc_lds = (float*)(smem + off);
+        off += (size_t)ix.nch * 64 * sizeof(float);
     }
     int64_t* res;
     int64_t* cand;
@@ -572,7 +599,13 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
     float qnorm2 = 0.0f;
     if (ix.sim == 2) qnorm2 = query_norm2(ix, q_lds, lane), qnorm2 = __shfl(qnorm2, 0, 64);
     if (PQ) {
-        build_lut(ix, q_lds, lut, lane);
+        for (int i = lane; i < ix.nch * 64; i += JV_WAVE) {
+            float v = q_lds[i];
+            if (ix.pq_centroid && i < ix.d) v = v - ix.pq_centroid[i];
+            qc_lds[i] = v;
+        }
+        __syncthreads();
+        build_lut(ix, qc_lds, lut, lane);
         __syncthreads();
     }
     // exact-provider path carries the Lucene MIP x2 wrap (J/JVectorReader.java:220-239,359-364);
@@ -772,18 +805,68 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
             __syncthreads();
             np = pool_trim(cur, np, rk, lane);
         }
+        // rank-merge `keep` lanes' (score, node) into the sorted pool; returns false on tie overflow
+        auto merge_keys = [&](bool keep, float s, int node) -> bool {
+            if (keep && np >= rk && s < key_score(cur[rk - 1])) keep = false;  // below the boundary for good
+            const unsigned long long km = __ballot(keep);
+            const int nk = __popcll(km);
+            if (nk == 0) return true;
+            if (keep) newk[__popcll(km & ((1ull << lane) - 1ull))] = make_pool_key(s, node);
+            __syncthreads();
+            if (lane < nk) {
+                const int64_t v = newk[lane];
+                int lo = 0, hi = np;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (cur[mid] > v) lo = mid + 1;
+                    else hi = mid;
+                }
+                int r = lo;
+                for (int j = 0; j < nk; j++) r += newk[j] > v ? 1 : 0;
+                nxt[r] = v;
+            }
+            for (int i = lane; i < np; i += JV_WAVE) {
+                const int64_t v = cur[i];
+                int cnt = 0;
+                for (int j = 0; j < nk; j++) cnt += newk[j] > v ? 1 : 0;
+                nxt[i + cnt] = v;
+            }
+            __syncthreads();
+            int64_t* t = cur;
+            cur = nxt;
+            nxt = t;
+            np = pool_trim(cur, np + nk, rk, lane);
+            return np <= pool_limit;  // false: more boundary ties than the pool has room for
+        };
+
+        // Fused ADC layout: node u's block holds its R neighbours' PQ codes in adjacency order, so one
+        // expansion is ONE dependent fetch (ids + codes) instead of two; scores are bit-identical.
+        const int lpn = PQ ? ix.pq_lanes : 1;
+        const bool fused = PQ && ix.pq_fused != nullptr && ix.R * lpn <= JV_WAVE;
+        const int my_j = fused ? lane / lpn : lane;        // stored-order neighbour slot this lane serves
+        const int my_c = fused ? lane & (lpn - 1) : 0;     // 16-subspace chunk this lane sums
+        const bool my_chunk = PQ && my_c * 16 < ix.pq_M;
+        // speculative prefetch of the runner-up's block: it is the next expansion unless a neighbour scored
+        // in this one beats it; a wrong guess only costs the (tiny) load
+        int pf_node = -1, pf_nn = -1;
+        u32x4 pf_cw = (u32x4){0, 0, 0, 0};
+        STAMP_DECL
+        STAMP(7)  // everything before the loop: staging, LUT build, entry point
         while (!st.overflow) {
-            int idx = -1;
-            for (int b0 = 0; b0 < np; b0 += JV_WAVE) {
+            int idx = -1, idx2 = -1;
+            for (int b0 = 0; b0 < np && idx2 < 0; b0 += JV_WAVE) {
                 const int i = b0 + lane;
                 const bool un = i < np && (cur[i] & 1ll);
-                const unsigned long long um = __ballot(un);
-                if (um) {
-                    idx = b0 + __ffsll((long long)um) - 1;
-                    break;
+                unsigned long long um = __ballot(un);
+                while (um && idx2 < 0) {
+                    const int p = b0 + __ffsll((long long)um) - 1;
+                    um &= um - 1ull;
+                    if (idx < 0) idx = p;
+                    else idx2 = p;
                 }
             }
             if (idx < 0) break;
+            STAMP(0)  // find the best / runner-up unexpanded entries
             const int64_t pk = cur[idx];
             const float sc = key_score(pk);
             if (sc < a.threshold) {  // a node the two-queue form would expand but not collect: take the general path
@@ -791,67 +874,90 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
                 break;
             }
             const int c = pool_node(pk);
-            const int32_t* row = ix.adj + (size_t)c * ix.R;
             const int deg = ix.R;
-            int nb0 = (lane < deg) ? row[lane] : -1;
+            const int32_t* row = ix.adj + (size_t)c * ix.R;
+            int nn;
+            u32x4 cw = (u32x4){0, 0, 0, 0};
+            if (c == pf_node) {
+                nn = pf_nn;
+                cw = pf_cw;
+                STAMP_COUNT(6, 1)  // prefetch hits
+            } else {
+                nn = my_j < deg ? row[my_j] : -1;
+                if (fused && my_j < deg && my_chunk)
+                    cw = *(const u32x4*)(ix.pq_fused + ((size_t)c * ix.R + my_j) * ix.pq_code_stride + my_c * 16);
+            }
+            pf_node = idx2 >= 0 ? pool_node(cur[idx2]) : -1;
+            if (pf_node >= 0) {
+                pf_nn = my_j < deg ? ix.adj[(size_t)pf_node * ix.R + my_j] : -1;
+                if (fused && my_j < deg && my_chunk)
+                    pf_cw = *(const u32x4*)(ix.pq_fused + ((size_t)pf_node * ix.R + my_j) * ix.pq_code_stride + my_c * 16);
+            }
             if (lane == 0) cur[idx] = pk & ~1ll;
-            for (int cb = 0; cb < deg; cb += JV_WAVE) {
-                const int nn = cb == 0 ? nb0 : ((cb + lane < deg) ? row[cb + lane] : -1);
+#ifdef JV_STAMPS
+            asm volatile("" ::"v"(nn), "v"(cw[0]), "v"(cw[3]));  // force the block to have arrived
+#endif
+            STAMP(1)  // issue + wait for this expansion's block
+            if (fused) {
                 if (st.nvisited_set + JV_WAVE > hash_limit) {
                     st.overflow = true;
                     break;
                 }
+                // ADC for every stored neighbour at once (lanes of a visited neighbour just idle later)
+                const bool have = nn >= 0 && my_chunk;
+                float s = have ? adc_chunk(lut, cw, my_c * 16, ix.pq_M) : 0.0f;
+                s = lanes_tree_sum(s, lpn);
+                float score;
+                if (ix.sim == 2) {
+                    float na = have ? adc_chunk(ix.pq_norm_lut, cw, my_c * 16, ix.pq_M) : 0.0f;
+                    na = lanes_tree_sum(na, lpn);
+                    score = map_score(2, s / sqrtf(qnorm2 * na));
+                } else {
+                    score = map_score(ix.sim, s);
+                }
+                STAMP(2)  // ADC: LUT gathers + lane tree + score map
                 bool is_new = false;
-                if (nn >= 0) is_new = visited_insert_lds(hash, hmask, hshift, (uint32_t)nn);
-                const unsigned long long mask = __ballot(is_new);
-                const int m = __popcll(mask);
-                if (is_new) todo[__popcll(mask & ((1ull << lane) - 1ull))] = nn;
-                __syncthreads();
-                if (m == 0) continue;
+                if (nn >= 0 && my_c == 0) is_new = visited_insert_lds(hash, hmask, hshift, (uint32_t)nn);
+                const int m = __popcll(__ballot(is_new));
                 st.nvisited_set += m;
                 st.visited += m;
-                score_todo(m);
-                bool keep = lane < m;
-                const float s = keep ? todo_score[lane] : 0.0f;
-                if (keep && np >= rk && s < key_score(cur[rk - 1])) keep = false;  // below the boundary for good
-                const unsigned long long km = __ballot(keep);
-                const int nk = __popcll(km);
-                if (nk == 0) continue;
-                if (keep) newk[__popcll(km & ((1ull << lane) - 1ull))] = make_pool_key(s, todo[lane]);
                 __syncthreads();
-                // rank merge of cur[0..np) and newk[0..nk) into nxt
-                if (lane < nk) {
-                    const int64_t v = newk[lane];
-                    int lo = 0, hi = np;
-                    while (lo < hi) {
-                        const int mid = (lo + hi) >> 1;
-                        if (cur[mid] > v) lo = mid + 1;
-                        else hi = mid;
-                    }
-                    int r = lo;
-                    for (int j = 0; j < nk; j++) r += newk[j] > v ? 1 : 0;
-                    nxt[r] = v;
-                }
-                for (int i = lane; i < np; i += JV_WAVE) {
-                    const int64_t v = cur[i];
-                    int cnt = 0;
-                    for (int j = 0; j < nk; j++) cnt += newk[j] > v ? 1 : 0;
-                    nxt[i + cnt] = v;
-                }
-                __syncthreads();
-                int64_t* t = cur;
-                cur = nxt;
-                nxt = t;
-                np = pool_trim(cur, np + nk, rk, lane);
-                if (np > pool_limit) {  // more boundary ties than the pool has room for
+                STAMP(3)  // visited-set inserts
+                if (!merge_keys(is_new, score, nn)) {
                     st.overflow = true;
                     break;
+                }
+                STAMP(4)  // rank merge into the pool
+            } else {
+                for (int cb = 0; cb < deg; cb += JV_WAVE) {
+                    const int nv = cb == 0 ? nn : ((cb + lane < deg) ? row[cb + lane] : -1);
+                    if (st.nvisited_set + JV_WAVE > hash_limit) {
+                        st.overflow = true;
+                        break;
+                    }
+                    bool is_new = false;
+                    if (nv >= 0) is_new = visited_insert_lds(hash, hmask, hshift, (uint32_t)nv);
+                    const unsigned long long mask = __ballot(is_new);
+                    const int m = __popcll(mask);
+                    if (is_new) todo[__popcll(mask & ((1ull << lane) - 1ull))] = nv;
+                    __syncthreads();
+                    if (m == 0) continue;
+                    st.nvisited_set += m;
+                    st.visited += m;
+                    score_todo(m);
+                    const bool keep = lane < m;
+                    if (!merge_keys(keep, keep ? todo_score[lane] : 0.0f, keep ? todo[lane] : 0)) {
+                        st.overflow = true;
+                        break;
+                    }
                 }
             }
             if (st.overflow) break;
             st.expanded++;
             st.expanded_base++;
         }
+        STAMP(5)  // non-fused expansions / loop exit
+        STAMP_FLUSH
         if (!st.overflow) {
             // approximateResults = the best rk expanded nodes = the first rk pool entries
             st.nres = np < rk ? np : rk;
@@ -1063,6 +1169,30 @@ __global__ __launch_bounds__(JV_WAVE) void jv_merge_topk_kernel(const int32_t* d
         if (n > 0) n--;
         __syncthreads();
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused ADC layout builder: fused[u][j][:] = codes[adj[u][j]][:] (zeros for -1), 16 B per thread.
+// ---------------------------------------------------------------------------------------------
+__global__ void jv_build_fused_kernel(const uint8_t* codes, const int32_t* adj, uint8_t* fused, long long n, int R,
+                                      int cs) {
+    const int cpn = cs / 16;
+    const long long total = n * R * cpn;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long slot = i / cpn;
+        const int ch = (int)(i % cpn);
+        const int nb = adj[slot];
+        u32x4 v = (u32x4){0, 0, 0, 0};
+        if (nb >= 0) v = *(const u32x4*)(codes + (size_t)nb * cs + ch * 16);
+        *(u32x4*)(fused + (size_t)slot * cs + ch * 16) = v;
+    }
+}
+
+extern "C" hipError_t jvk_build_fused(const uint8_t* codes, const int32_t* adj, uint8_t* fused, long long n, int R, int cs,
+                                      hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    jv_build_fused_kernel<<<4096, 256, 0, stream>>>(codes, adj, fused, n, R, cs);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -203,3 +203,72 @@ def test_threshold_queries_parity(pkg, pyoracle, small_sets):
     finally:
         b.set_option("force_big_path", 0)
     gpu.close()
+
+
+@pytest.mark.parametrize("sim", [0, 1, 2])
+@pytest.mark.parametrize("M,R", [(32, 32), (16, 16), (32, 16), (64, 16), (24, 12)])
+def test_fused_adc_layout_parity(pkg, pyoracle, small_sets, sim, M, R):
+    """JV_DESC_FUSED_ADC (neighbours' PQ codes stored next to the adjacency row, one fetch per expansion,
+    plus the runner-up prefetch) must not change a single bit: ids, scores, counters == oracle."""
+    b, bl = pkg.binding, pkg.builder
+    base, q = small_sets["base64"][:3000], small_sets["q64"][:32]
+    ix = bl.build_index_cpu(base, sim, R=R, L=50, pq_M=M)
+    gpu = b.GpuIndex(ix, flags=b.DESC_FUSED_ADC)
+    assert gpu.info().fused_adc == 1
+    orc = pyoracle.Oracle(b, ix)
+    for (k, rk) in [(10, 50), (10, 10), (5, 120)]:
+        _assert_same(gpu.search_batch(q, k, rk), orc.search_batch(q, k, rk), f"fused sim={sim} M={M} R={R} k={k} rk={rk}")
+    gpu.close()
+
+
+def test_device_pointer_api_and_merge_kernel(pkg, pyoracle, small_sets):
+    """jv_search_batch_device (device pointers + caller stream, borrowed HBM arrays) and jv_merge_topk_device
+    against the oracle.  torch is only the device allocator here."""
+    import torch
+    b, bl = pkg.binding, pkg.builder
+    base, q = small_sets["base64"][:4000], small_sets["q64"]
+    ix = bl.build_index_cpu(base, 0, R=16, L=60)
+    dev = torch.device("cuda", 0)
+    t_base = torch.from_numpy(ix.vectors).to(dev)
+    t_adj = torch.from_numpy(ix.adj).to(dev)
+    desc, keep = b.make_desc_device(ix.n, ix.d, ix.R, t_base.data_ptr(), t_adj.data_ptr(), ix.entry_node, 0, borrow=True)
+    gpu = b.GpuIndex(desc=desc, keepalive=keep, flags=b.DESC_BORROW)
+    nq, k, rk = q.shape[0], 10, 50
+    tq = torch.from_numpy(q).to(dev)
+    o_nodes = torch.empty((nq, k), dtype=torch.int32, device=dev)
+    o_docs = torch.empty((nq, k), dtype=torch.int32, device=dev)
+    o_scores = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    o_count = torch.empty((nq,), dtype=torch.int32, device=dev)
+    o_stats = torch.empty((nq, 4), dtype=torch.int32, device=dev)
+    o_flags = torch.empty((nq,), dtype=torch.int32, device=dev)
+    stream = torch.cuda.Stream(device=dev)
+    gpu.search_batch_device(tq.data_ptr(), nq, k, rk, o_nodes.data_ptr(), o_docs.data_ptr(), o_scores.data_ptr(),
+                            o_count.data_ptr(), o_stats.data_ptr(), o_flags.data_ptr(), stream=stream.cuda_stream)
+    stream.synchronize()
+    want = pyoracle.Oracle(b, ix).search_batch(q, k, rk)
+    assert np.array_equal(o_nodes.cpu().numpy(), want.nodes)
+    assert np.array_equal(o_scores.cpu().numpy().view(np.uint32), want.scores.view(np.uint32))
+    assert np.array_equal(o_stats.cpu().numpy(), want.stats)
+    assert (o_flags.cpu().numpy() & 0xC0000000 == 0).all()
+    # merge kernel: 3 lists of k per query, with empty slots and score ties
+    rng = np.random.default_rng(2)
+    lists = 3
+    docs = rng.integers(0, 50, size=(nq, lists * k)).astype(np.int32)
+    scores = (rng.integers(0, 8, size=(nq, lists * k)) / 8.0).astype(np.float32)
+    docs[rng.random(docs.shape) < 0.2] = -1
+    # unique docs per row (a doc lives in exactly one shard)
+    for r in range(nq):
+        seen = set()
+        for c in range(lists * k):
+            if docs[r, c] in seen:
+                docs[r, c] = -1
+            seen.add(int(docs[r, c]))
+    td, ts = torch.from_numpy(docs).to(dev), torch.from_numpy(scores).to(dev)
+    od = torch.empty((nq, k), dtype=torch.int32, device=dev)
+    os_ = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    b.merge_topk_device(0, td.data_ptr(), ts.data_ptr(), nq, lists, k, od.data_ptr(), os_.data_ptr())
+    torch.cuda.synchronize()
+    wd, ws = pyoracle.merge_topk(b, docs, scores, k)
+    assert np.array_equal(od.cpu().numpy(), wd)
+    assert np.array_equal(os_.cpu().numpy(), ws)
+    gpu.close()

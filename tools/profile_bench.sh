@@ -11,13 +11,13 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/rp_kt /tmp/rp_f /tmp/rp_w
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_kt -- python3 $R/bench.py "$@" --no-cpu-baseline > $OUT/bench_under_trace.json 2> $OUT/bench_under_trace.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_kt -- python3 $R/bench.py "$@" --profile-mode > $OUT/bench_under_trace.json 2> $OUT/bench_under_trace.err
 f=$(find /tmp/rp_kt -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/kernel_stats.csv
 t=$(find /tmp/rp_kt -name "*kernel_trace.csv" | head -1)
 if [ -n "$t" ]; then head -1 $t > $OUT/jv_kernel_trace.csv; grep -E "jv_" $t | grep -v builder >> $OUT/jv_kernel_trace.csv; fi
 for C in FETCH_SIZE WRITE_SIZE; do
   d=/tmp/rp_$C; rm -rf $d
-  rocprofv3 --pmc $C --kernel-include-regex "jv_search" --output-format csv -d $d -- python3 $R/bench.py "$@" --no-cpu-baseline > $OUT/bench_under_pmc_$C.json 2> $OUT/bench_under_pmc_$C.err
+  rocprofv3 --pmc $C --kernel-include-regex "jv_search" --output-format csv -d $d -- python3 $R/bench.py "$@" --profile-mode > $OUT/bench_under_pmc_$C.json 2> $OUT/bench_under_pmc_$C.err
   c=$(find $d -name "*counter_collection.csv" | head -1)
   [ -n "$c" ] && cp $c $OUT/pmc_$C.csv
 done

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Per-phase cycle shares of the PQ pool loop from the diagnostic build (lib/libjvgpu_stamps.so).
+Shares only — the stamped build is slower than the product and its run time is never quoted."""
+import importlib, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import __graft_entry__ as g
+g.load_package()
+b = importlib.import_module("opensearch_jvector_amd.binding")
+b.LIB_PATH = os.path.join(os.path.dirname(b.LIB_PATH), "libjvgpu_stamps.so")
+b.load_library(b.LIB_PATH)
+gb = importlib.import_module("opensearch_jvector_amd.builder_gpu")
+import bench
+
+n = int(os.environ.get("N", 2_000_000)); d = 768; M = 32; rk = int(os.environ.get("RK", 200)); B = 65536
+dev = torch.device("cuda", 0)
+zc, Bl, Bg = bench.make_block_generators(torch, d, dev, max(64, min(4096, n // 256)), M=M, per=2)
+base = bench.gen_rows_block(torch, n, d, 42, 0, zc, Bl, Bg, 0.35, 0.1, 0.005, False, dev)
+q = bench.gen_rows_block(torch, B, d, 43, 0, zc, Bl, Bg, 0.35, 0.1, 0.005, False, dev)
+adj, entry = gb.build_graph_gpu(torch, base, 0, R=32, L=100, verbose=False)
+pq = gb.pq_train_encode_gpu(torch, base, M, 0)
+for fused in (1, 0):
+    desc, keep = b.make_desc_device(n, d, 32, base.data_ptr(), adj.data_ptr(), entry, 0, pq_M=M, pq_K=pq["K"],
+                                    pq_codebooks=pq["codebooks"], pq_centroid=pq["centroid"], pq_codes_ptr=pq["codes"].data_ptr(),
+                                    borrow=True, extra_flags=(b.DESC_FUSED_ADC if fused else 0))
+    ix = b.GpuIndex(desc=desc, keepalive=keep, flags=b.DESC_BORROW)
+    dbg = torch.zeros(8, dtype=torch.int64, device=dev)
+    o = [torch.empty((B, 10), dtype=torch.int32, device=dev), torch.empty((B, 10), dtype=torch.int32, device=dev),
+         torch.empty((B, 10), dtype=torch.float32, device=dev), torch.empty((B,), dtype=torch.int32, device=dev),
+         torch.empty((B, 4), dtype=torch.int32, device=dev), torch.empty((B,), dtype=torch.int32, device=dev)]
+    for it in range(2):
+        dbg.zero_()
+        b.set_option("dbg_ptr", dbg.data_ptr())
+        torch.cuda.synchronize(); t = time.time()
+        ix.search_batch_device(q.data_ptr(), B, 10, rk, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(),
+                               o[4].data_ptr(), o[5].data_ptr())
+        torch.cuda.synchronize(); dt = time.time() - t
+    b.set_option("dbg_ptr", 0)
+    v = dbg.cpu().numpy().astype(np.float64)
+    st = o[4].cpu().numpy().astype(np.float64).mean(0)
+    names = ["find-unexpanded", "block issue+wait", "ADC", "visited insert", "pool merge", "non-fused/exit", "prefetch hits", "pre-loop (LUT etc.)"]
+    cyc = v.copy(); hits = cyc[6]; cyc[6] = 0
+    print(f"fused={fused}: {B / dt:.0f} QPS (stamped build), expansions/query {st[2]:.1f}, prefetch hit rate {hits / (st[2] * B):.2f}")
+    for i, nme in enumerate(names):
+        if i != 6:
+            print(f"   {nme:24s} {100 * cyc[i] / cyc.sum():5.1f} %   {cyc[i] / B / max(st[2], 1):8.0f} cycles/expansion")
+    ix.close()

@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Summarise a tools/profile_bench.sh output directory into profiles/<name>/ (SUMMARY.md + the CSVs) and
+profiles/traffic_latest.json (read by bench.py for roofline.traffic).
+
+HBM bytes per launch follow MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE are reported in KiB by
+rocprofv3; on gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide (16 B/lane) loads, so the read side is
+doubled; WRITE_SIZE is exact.  Counters were collected in their own passes (one --pmc counter per run).
+"""
+import csv
+import json
+import os
+import shutil
+import sys
+
+
+def main(src, name):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dst = os.path.join(root, "profiles", name)
+    os.makedirs(dst, exist_ok=True)
+    for f in ("kernel_stats.csv", "jv_kernel_trace.csv", "pmc_FETCH_SIZE.csv", "pmc_WRITE_SIZE.csv", "bench_under_trace.json"):
+        if os.path.exists(os.path.join(src, f)):
+            shutil.copy(os.path.join(src, f), os.path.join(dst, f))
+    bench = json.loads(open(os.path.join(src, "bench_under_trace.json")).read().strip().splitlines()[-1])
+    steps, warm, B = bench["steps"], bench["warmup"], bench["config"]["queries_per_step"]
+    grid = str(B * 64)
+    lines = [f"# rocprofv3 summary — {name}", "",
+             f"command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --profile-mode "
+             f"--workload {bench['config']['workload'].split(':')[0]} --steps {steps} --warmup {warm} --rerankk {bench['config']['rerankK']}`",
+             "", f"bench line under the tracer: value = {bench['value']} {bench['unit']}, roofline = {json.dumps(bench['roofline'])}", "",
+             "## kernel_stats.csv rows of this repo's kernels", "", "| kernel | calls | avg ms | total ms |", "|---|---|---|---|"]
+    main_avg = None
+    for r in csv.DictReader(open(os.path.join(src, "kernel_stats.csv"))):
+        if "jv_" in r["Name"]:
+            avg = float(r["AverageNs"]) / 1e6
+            lines.append(f"| `{r['Name'].split('(')[0]}` | {r['Calls']} | {avg:.4f} | {float(r['TotalDurationNs']) / 1e6:.2f} |")
+            if "jv_search_lds_kernel" in r["Name"] and main_avg is None:
+                main_avg = avg
+    lines += ["", f"`jv_search_lds_kernel` is launched only by the {warm} warm-up + {steps} timed steps in --profile-mode "
+                  "(index construction uses `jv_build_search_kernel`, escalation passes `jv_search_retry_kernel`), so its "
+                  f"average ({main_avg:.4f} ms) is directly comparable with bench.py's `roofline.kernel_avg_ms` "
+                  f"({bench['roofline']['kernel_avg_ms']} ms, HIP events around launch + escalation + big-path launches).", ""]
+    traffic = {}
+    for cname in ("FETCH_SIZE", "WRITE_SIZE"):
+        p = os.path.join(src, f"pmc_{cname}.csv")
+        if not os.path.exists(p):
+            continue
+        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(p))
+                if "jv_search_lds_kernel" in r["Kernel_Name"] and r["Grid_Size"] == grid]
+        vals = vals[-steps:]
+        if vals:
+            traffic[cname] = sum(vals) / len(vals)
+    if "FETCH_SIZE" in traffic:
+        rd = traffic["FETCH_SIZE"] * 1024 * 2
+        wr = traffic.get("WRITE_SIZE", 0.0) * 1024
+        hbm = rd + wr
+        lines += ["## HBM traffic of the main kernel (PMC, separate passes)", "",
+                  f"* FETCH_SIZE mean over the {steps} timed launches: {traffic['FETCH_SIZE']:.1f} KiB -> x1024 x2 (gfx950 wide-load correction) = {rd / 1e9:.3f} GB",
+                  f"* WRITE_SIZE mean: {traffic.get('WRITE_SIZE', 0.0):.1f} KiB -> {wr / 1e9:.4f} GB",
+                  f"* **HBM bytes per launch = {hbm / 1e9:.3f} GB** vs algorithmic {bench['roofline']['algorithmic_bytes_per_launch'] / 1e9:.3f} GB",
+                  ""]
+        tj = {"workload": bench["config"]["workload"].split(":")[0], "n": bench["config"]["docs_per_gpu"], "batch": B,
+              "rerankK": bench["config"]["rerankK"], "hbm_bytes_per_launch": round(hbm, 1),
+              "fetch_size_kib": traffic["FETCH_SIZE"], "write_size_kib": traffic.get("WRITE_SIZE"), "source": f"profiles/{name}"}
+        path = os.path.join(root, "profiles", "traffic_latest.json")
+        allj = {}
+        if os.path.exists(path):
+            try:
+                allj = json.load(open(path))
+            except Exception:
+                allj = {}
+        if "entries" not in allj:
+            allj = {"entries": {}}
+        allj["entries"][tj["workload"]] = tj
+        json.dump(allj, open(path, "w"), indent=1)
+    open(os.path.join(dst, "SUMMARY.md"), "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
