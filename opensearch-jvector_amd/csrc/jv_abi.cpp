@@ -23,6 +23,7 @@ extern "C" {
 hipError_t jvk_set_max_lds(int bytes);
 hipError_t jvk_build_fused(const uint8_t* codes, const int32_t* adj, uint8_t* fused, long long n, int R, int cs, hipStream_t s);
 hipError_t jvk_launch_search_lds(const JvIndexDev* ix, const JvSearchArgs* a, int pq, int pool, int tag, int lds_bytes, hipStream_t s);
+hipError_t jvk_launch_search_pqf(const JvIndexDev* ix, const JvSearchArgs* a, int lds_bytes, hipStream_t s);
 hipError_t jvk_launch_search_big(const JvIndexDev* ix, const JvSearchArgs* a, int pq, int blocks, int lds_bytes,
                                  int force_all, hipStream_t s);
 hipError_t jvk_launch_score_ordinals(const JvIndexDev* ix, const float* d_query, const int32_t* d_ordinals,
@@ -62,6 +63,9 @@ std::atomic<int64_t> opt_force_big{0};
 std::atomic<int64_t> opt_force_general{0};
 std::atomic<int64_t> opt_no_escalation{0};
 std::atomic<int64_t> opt_dbg_ptr{0};
+std::atomic<int64_t> opt_no_pqf{0};
+std::atomic<int64_t> opt_spill_tables{2048};  // per context: 2048 x 8192 x 4 B = 64 MB
+std::atomic<int64_t> opt_spill_slots{8192};
 std::atomic<int64_t> opt_big_blocks{256};
 std::atomic<int64_t> opt_big_cand_cap{65536};
 
@@ -91,7 +95,9 @@ struct Ctx {
     // big-path HBM scratch
     uint32_t* big_visited = nullptr;
     int64_t* big_cand = nullptr;
-    int32_t* work_counter = nullptr;
+    int32_t* work_counter = nullptr;  // [0] big-path dequeue, [1] spill-table allocator
+    uint32_t* spill = nullptr;
+    int spill_tables = 0, spill_slots = 0;
     int big_blocks = 0;
     int big_cand_cap = 0;
     size_t big_words = 0;
@@ -140,7 +146,7 @@ int ctx_create(jv_index* ix, Ctx** out) {
     Ctx* c = new Ctx();
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->last_use, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipMalloc((void**)&c->work_counter, sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&c->work_counter, 2 * sizeof(int32_t));
     if (e != hipSuccess) {
         delete c;
         return fail(JV_EDEVICE, "context creation failed: %s", hipGetErrorString(e));
@@ -163,6 +169,7 @@ void ctx_destroy(Ctx* c) {
     hipFree(c->big_visited);
     hipFree(c->big_cand);
     hipFree(c->work_counter);
+    hipFree(c->spill);
     if (c->last_use) hipEventDestroy(c->last_use);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -252,6 +259,17 @@ int ensure_big(jv_index* ix, Ctx* c, int rk) {
         c->big_cand_cap = cap;
     }
     c->big_blocks = blocks;
+    const int st = (int)opt_spill_tables.load(), ss = next_pow2((int)opt_spill_slots.load());
+    if (c->spill_tables != st || c->spill_slots != ss) {
+        if (c->spill) HIPCHK(hipFree(c->spill));
+        c->spill = nullptr;
+        c->spill_tables = c->spill_slots = 0;
+        if (st > 0 && ss > 0) {
+            HIPCHK(hipMalloc((void**)&c->spill, (size_t)st * ss * sizeof(uint32_t)));
+            c->spill_tables = st;
+            c->spill_slots = ss;
+        }
+    }
     return JV_OK;
 }
 
@@ -291,10 +309,37 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
     a.big_cand_cap = c->big_cand_cap;
     a.work_counter = c->work_counter;
     a.retry_only = 0;
+    a.spill = c->spill;
+    a.spill_slots = c->spill_slots;
+    a.spill_tables = c->spill_tables;
+    a.spill_counter = c->work_counter + 1;
     a.dbg = (int64_t*)(uintptr_t)opt_dbg_ptr.load();  // always 0 unless a diagnostic run set it
     const bool force_big = opt_force_big.load() != 0 || !g.fast_ok;
-    HIPCHK(hipMemsetAsync(c->work_counter, 0, sizeof(int32_t), stream));
+    HIPCHK(hipMemsetAsync(c->work_counter, 0, 2 * sizeof(int32_t), stream));
+    // headline path: PQ + fused layout + single pool + flat graph -> specialised kernel without an in-loop
+    // visited set (jv_kernels.hip "PQF"); anything it cannot hold is flagged and falls through to the ladder
+    bool pqf = false;
+    if (!force_big && pq && g.pool && ix->dev.pq_fused && ix->dev.num_upper == 0 && ix->dev.R * ix->dev.pq_lanes <= JV_WAVE &&
+        rk + 128 <= 512 && opt_no_pqf.load() == 0) {
+        JvSearchArgs ap = a;
+        ap.cand_cap = (rk + 128 + 1) & ~1;          // pool entries
+        ap.res_cap = (3 * rk + 64 + 3) & ~3;        // expansion log entries
+        const int lut_b = ix->dev.pq_M * 256 * 4;
+        int loop_b = lut_b + ap.cand_cap * 8 + ap.res_cap * 4;
+        const int qc_b = ix->dev.nch * 64 * 4;
+        if (ap.cand_cap * 8 + ap.res_cap * 4 < qc_b) loop_b = lut_b + qc_b;             // LUT build aliases pool + log
+        const int rerank_b = qc_b + JV_TODO * 8 + ((rk + 1) & ~1) * 8;                  // after the search, inside the LUT area
+        if (rerank_b <= lut_b && loop_b <= kMaxLds) {
+            HIPCHK(jvk_launch_search_pqf(&ix->dev, &ap, (loop_b + 15) & ~15, stream));
+            pqf = true;
+        }
+    }
     if (!force_big) {
+        if (pqf) {
+            JvSearchArgs ar = a;
+            ar.retry_only = 1;
+            HIPCHK(jvk_launch_search_lds(&ix->dev, &ar, 1, g.pool ? 1 : 0, 1, g.lds_fast, stream));
+        } else
         HIPCHK(jvk_launch_search_lds(&ix->dev, &a, pq ? 1 : 0, g.pool ? 1 : 0, ix->build_client ? 2 : 0, g.lds_fast, stream));
         // escalation: queries that overflowed the on-chip visited set are retried with a 4x larger table
         // (fewer resident queries, but only the flagged few run) before the HBM-scratch path
@@ -341,6 +386,9 @@ int jv_set_option(const char* name, int64_t value) {
     else if (n == "force_general_path") opt_force_general = value;
     else if (n == "no_escalation") opt_no_escalation = value;
     else if (n == "dbg_ptr") opt_dbg_ptr = value;
+    else if (n == "no_pqf") opt_no_pqf = value;
+    else if (n == "spill_tables") opt_spill_tables = value;
+    else if (n == "spill_slots") opt_spill_slots = value;
     else if (n == "big_blocks") opt_big_blocks = value;
     else if (n == "big_cand_cap") opt_big_cand_cap = value;
     else return fail(JV_EINVAL, "unknown option '%s'", name);

@@ -64,6 +64,11 @@ struct JvSearchArgs {
     int32_t big_cand_cap;
     int32_t* work_counter;   // big path: dynamic query dequeue
     int32_t retry_only;      // LDS kernel: process only queries whose flag has JV_FLAG_OVERFLOW
+    // two-level visited set: pool of per-query spill tables in HBM (taken with spill_counter)
+    uint32_t* spill;
+    int32_t spill_slots;     // entries per table (power of two)
+    int32_t spill_tables;
+    int32_t* spill_counter;  // zeroed per call
     int64_t* dbg;            // diagnostic build (-DJV_STAMPS) only: 8 cycle accumulators; nullptr in the product
 };
 

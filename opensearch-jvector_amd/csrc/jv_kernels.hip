@@ -359,16 +359,21 @@ __device__ __forceinline__ float lanes_tree_sum(float v, int lpn) {
 }
 
 // 16 consecutive subspaces per lane, summed left to right; chunk sums combined by the lane tree.
+// All 16 table reads are issued before the first add (independent ds_read_b32, one LDS round trip);
+// slots beyond M contribute +0.0f, which leaves the sum bit-identical.
 __device__ __forceinline__ float adc_chunk(const float* lut, const u32x4 cw, int m0, int M) {
-    float s = 0.0f;
+    float v[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) {
         const int mi = m0 + i;
-        if (mi < M) {
-            const uint32_t code = (cw[i >> 2] >> ((i & 3) * 8)) & 0xFFu;
-            s = s + lut[mi * 256 + code];
-        }
+        const uint32_t code = (cw[i >> 2] >> ((i & 3) * 8)) & 0xFFu;
+        const int mc = mi < M ? mi : m0;  // clamp the address, mask the value
+        const float t = lut[mc * 256 + code];
+        v[i] = mi < M ? t : 0.0f;
     }
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; i++) s = s + v[i];
     return s;
 }
 
@@ -411,6 +416,36 @@ __device__ __forceinline__ bool visited_insert_lds(uint32_t* tab, uint32_t mask,
         h = (h + 1) & mask;
     }
 }
+// Two-level visited set: when the LDS table reaches its fill limit it is frozen (lookups only) and further
+// nodes go to a per-query spill table in HBM (L2-resident), taken from a per-launch pool.  Exact in all
+// cases; a query that also exhausts its spill table (or finds the pool empty) is flagged for the retry path.
+struct Visited {
+    uint32_t* lds;
+    uint32_t lmask;
+    int lshift;
+    uint32_t* spill;   // nullptr until the LDS table is frozen
+    uint32_t smask;
+    int sshift;
+    int nspill;
+};
+__device__ __forceinline__ bool visited_insert2(Visited& vs, uint32_t node) {
+    if (vs.spill == nullptr) return visited_insert_lds(vs.lds, vs.lmask, vs.lshift, node);
+    uint32_t h = (node * 0x9E3779B1u) >> vs.lshift;
+    for (;;) {
+        const uint32_t v = vs.lds[h];
+        if (v == node) return false;
+        if (v == HASH_EMPTY) break;
+        h = (h + 1) & vs.lmask;
+    }
+    uint32_t g = (node * 0x85EBCA6Bu) >> vs.sshift;
+    for (;;) {
+        const uint32_t old = atomicCAS(&vs.spill[g], HASH_EMPTY, node);
+        if (old == HASH_EMPTY) return true;
+        if (old == node) return false;
+        g = (g + 1) & vs.smask;
+    }
+}
+
 __device__ __forceinline__ bool visited_insert_bits(uint32_t* bits, uint32_t node) {
     const uint32_t bit = 1u << (node & 31);
     uint32_t old = atomicOr(&bits[node >> 5], bit);
@@ -495,7 +530,6 @@ struct QState {
     int nres;        // results: res[0..nres)
     int64_t worst;   // min key of res (valid when nres == rk_cur)
     int worst_idx;
-    int nvisited_set;  // entries in the visited set (incl. entry point)
     int visited, expanded, expanded_base, reranked;
     bool overflow;
 };
@@ -582,9 +616,19 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
         hash = (uint32_t*)(smem + off);
         cand_cap = a.cand_cap;
     }
+    // (vs.lds is set after `hash` is known; see below)
     const uint32_t hmask = (uint32_t)a.hash_slots - 1u;
     const int hshift = 32 - (31 - __clz(a.hash_slots));
     const int hash_limit = (a.hash_slots / 4) * 3;
+    Visited vs;
+    vs.lds = nullptr;
+    vs.lmask = hmask;
+    vs.lshift = hshift;
+    vs.spill = nullptr;
+    vs.smask = a.spill_slots > 0 ? (uint32_t)a.spill_slots - 1u : 0u;
+    vs.sshift = a.spill_slots > 0 ? 32 - (31 - __clz(a.spill_slots)) : 0;
+    vs.nspill = 0;
+    const int spill_limit = (a.spill_slots / 4) * 3;
 
     // ---- stage the query; clear the visited set ----
     const float* qg = a.queries + (size_t)qi * ix.d;
@@ -612,11 +656,30 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
     // the PQ provider's reranker is not wrapped (:353-356)
     const float search_scale = PQ ? 1.0f : ix.score_scale;
 
+    int st_nvisited_lds = 0;  // nodes in the LDS table
+    vs.lds = hash;
+    // room for 64 more nodes?  LDS table -> freeze it and take a spill table -> give up (retry path)
+    auto visited_room = [&]() -> bool {
+        if (vs.spill == nullptr) {
+            if (st_nvisited_lds + JV_WAVE <= hash_limit) return true;
+            if (a.spill == nullptr || a.spill_slots <= 0) return false;
+            int t = 0;
+            if (lane == 0) t = atomicAdd(a.spill_counter, 1);
+            t = __shfl(t, 0, JV_WAVE);
+            if (t >= a.spill_tables) return false;
+            uint32_t* tab = a.spill + (size_t)t * a.spill_slots;
+            for (int i = lane; i < a.spill_slots; i += JV_WAVE) tab[i] = HASH_EMPTY;
+            __syncthreads();
+            vs.spill = tab;
+            return true;
+        }
+        return vs.nspill + JV_WAVE <= spill_limit;
+    };
+
     QState st;
     st.ncand = st.nhand = st.nres = 0;
     st.worst = KEY_MAX;
     st.worst_idx = -1;
-    st.nvisited_set = 0;
     st.visited = st.expanded = st.expanded_base = st.reranked = 0;
     st.overflow = false;
 
@@ -634,7 +697,7 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
             if (BIG) visited_insert_bits(big_bits, (uint32_t)ep);
             else visited_insert_lds(hash, hmask, hshift, (uint32_t)ep);
         }
-        st.nvisited_set = 1;
+        st_nvisited_lds = 1;
         __syncthreads();
         score_todo(1);
         if (lane == 0) cand[0] = make_key(todo_score[0], ep);
@@ -711,21 +774,22 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
             // neighbours, 64 at a time, in stored order
             for (int cb = 0; cb < deg; cb += JV_WAVE) {
                 const int nn = cb == 0 ? nb0 : ((cb + lane < deg) ? row[cb + lane] : -1);
-                if (!BIG && st.nvisited_set + JV_WAVE > hash_limit) {
+                if (!BIG && !visited_room()) {
                     st.overflow = true;
                     break;
                 }
                 bool is_new = false;
                 if (nn >= 0) {
                     is_new = BIG ? visited_insert_bits(big_bits, (uint32_t)nn)
-                                 : visited_insert_lds(hash, hmask, hshift, (uint32_t)nn);
+                                 : visited_insert2(vs, (uint32_t)nn);
                 }
                 const unsigned long long mask = __ballot(is_new);
                 const int m = __popcll(mask);
                 if (is_new) todo[__popcll(mask & ((1ull << lane) - 1ull))] = nn;
                 __syncthreads();
                 if (m == 0) continue;
-                st.nvisited_set += m;
+                if (vs.spill == nullptr) st_nvisited_lds += m;
+                else vs.nspill += m;
                 st.visited += m;
                 score_todo(m);
                 if (thr > 0.0f) tracker_track(trk, todo_score, m, lane);
@@ -805,7 +869,11 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
             __syncthreads();
             np = pool_trim(cur, np, rk, lane);
         }
-        // rank-merge `keep` lanes' (score, node) into the sorted pool; returns false on tie overflow
+        // Rank-merge the `keep` lanes' (score, node) into the sorted pool, in place: new keys find their rank
+        // with an 8-ary search, old entries at or below the first insertion point shift right chunk by chunk
+        // from the top.  `lo_un` = index before which every entry is known to be expanded.
+        int lo_un = 0;
+        int64_t* newk_s = (int64_t*)todo_score;  // 64 keys: todo_score + todo are dead during a merge
         auto merge_keys = [&](bool keep, float s, int node) -> bool {
             if (keep && np >= rk && s < key_score(cur[rk - 1])) keep = false;  // below the boundary for good
             const unsigned long long km = __ballot(keep);
@@ -813,29 +881,42 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
             if (nk == 0) return true;
             if (keep) newk[__popcll(km & ((1ull << lane) - 1ull))] = make_pool_key(s, node);
             __syncthreads();
+            int64_t v = 0;
+            int rnew = 0, rold = 0;
             if (lane < nk) {
-                const int64_t v = newk[lane];
-                int lo = 0, hi = np;
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (cur[mid] > v) lo = mid + 1;
-                    else hi = mid;
+                v = newk[lane];
+                for (int j = 0; j < nk; j++) rnew += newk[j] > v ? 1 : 0;
+                int lo = 0, hi = np;  // rold = #{pool entries > v}
+                while (hi - lo > 8) {
+                    const int step = (hi - lo + 7) >> 3;
+                    int cgt = 0;
+#pragma unroll
+                    for (int k2 = 1; k2 < 8; k2++) {
+                        const int pp = lo + k2 * step;
+                        cgt += (pp < hi && cur[pp] > v) ? 1 : 0;
+                    }
+                    lo += cgt * step;
+                    hi = lo + step < hi ? lo + step : hi;
                 }
-                int r = lo;
-                for (int j = 0; j < nk; j++) r += newk[j] > v ? 1 : 0;
-                nxt[r] = v;
+                rold = lo;
+                for (int pp = lo; pp < hi; pp++) rold += cur[pp] > v ? 1 : 0;
+                newk_s[rnew] = v;  // new keys in descending order
             }
-            for (int i = lane; i < np; i += JV_WAVE) {
-                const int64_t v = cur[i];
-                int cnt = 0;
-                for (int j = 0; j < nk; j++) cnt += newk[j] > v ? 1 : 0;
-                nxt[i + cnt] = v;
-            }
+            const unsigned long long firstm = __ballot(lane < nk && rnew == 0);
+            const int r_min = __shfl(rold, __ffsll((long long)firstm) - 1, JV_WAVE);  // first insertion point
             __syncthreads();
-            int64_t* t = cur;
-            cur = nxt;
-            nxt = t;
+            for (int t = (np - 1) >> 6; t >= (r_min >> 6); t--) {
+                const int i = (t << 6) + lane;
+                const bool mv = i < np && i >= r_min;
+                const int64_t ov = mv ? cur[i] : 0;
+                int cnt = 0;
+                for (int j = 0; j < nk; j++) cnt += (mv && newk_s[j] > ov) ? 1 : 0;
+                if (mv && cnt > 0) cur[i + cnt] = ov;  // every lane has read its entry of this chunk already
+            }
+            if (lane < nk) cur[rold + rnew] = v;
+            __syncthreads();
             np = pool_trim(cur, np + nk, rk, lane);
+            lo_un = lo_un < r_min ? lo_un : r_min;
             return np <= pool_limit;  // false: more boundary ties than the pool has room for
         };
 
@@ -847,25 +928,27 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
         const int my_c = fused ? lane & (lpn - 1) : 0;     // 16-subspace chunk this lane sums
         const bool my_chunk = PQ && my_c * 16 < ix.pq_M;
         // speculative prefetch of the runner-up's block: it is the next expansion unless a neighbour scored
-        // in this one beats it; a wrong guess only costs the (tiny) load
+        // in this one beats it; a wrong guess only costs the (tiny) load.  The prefetch is issued AFTER this
+        // expansion's block has been consumed, so the wait for the current block never covers it.
         int pf_node = -1, pf_nn = -1;
         u32x4 pf_cw = (u32x4){0, 0, 0, 0};
         STAMP_DECL
         STAMP(7)  // everything before the loop: staging, LUT build, entry point
         while (!st.overflow) {
             int idx = -1, idx2 = -1;
-            for (int b0 = 0; b0 < np && idx2 < 0; b0 += JV_WAVE) {
+            for (int b0 = lo_un; b0 < np && idx2 < 0; b0 += JV_WAVE) {
                 const int i = b0 + lane;
                 const bool un = i < np && (cur[i] & 1ll);
                 unsigned long long um = __ballot(un);
                 while (um && idx2 < 0) {
-                    const int p = b0 + __ffsll((long long)um) - 1;
+                    const int pp = b0 + __ffsll((long long)um) - 1;
                     um &= um - 1ull;
-                    if (idx < 0) idx = p;
-                    else idx2 = p;
+                    if (idx < 0) idx = pp;
+                    else idx2 = pp;
                 }
             }
             if (idx < 0) break;
+            lo_un = idx + 1;
             STAMP(0)  // find the best / runner-up unexpanded entries
             const int64_t pk = cur[idx];
             const float sc = key_score(pk);
@@ -887,39 +970,45 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
                 if (fused && my_j < deg && my_chunk)
                     cw = *(const u32x4*)(ix.pq_fused + ((size_t)c * ix.R + my_j) * ix.pq_code_stride + my_c * 16);
             }
-            pf_node = idx2 >= 0 ? pool_node(cur[idx2]) : -1;
-            if (pf_node >= 0) {
-                pf_nn = my_j < deg ? ix.adj[(size_t)pf_node * ix.R + my_j] : -1;
-                if (fused && my_j < deg && my_chunk)
-                    pf_cw = *(const u32x4*)(ix.pq_fused + ((size_t)pf_node * ix.R + my_j) * ix.pq_code_stride + my_c * 16);
-            }
+            const int c2 = idx2 >= 0 ? pool_node(cur[idx2]) : -1;
             if (lane == 0) cur[idx] = pk & ~1ll;
 #ifdef JV_STAMPS
             asm volatile("" ::"v"(nn), "v"(cw[0]), "v"(cw[3]));  // force the block to have arrived
 #endif
-            STAMP(1)  // issue + wait for this expansion's block
+            STAMP(1)  // wait for this expansion's block
             if (fused) {
-                if (st.nvisited_set + JV_WAVE > hash_limit) {
+                if (!visited_room()) {
                     st.overflow = true;
                     break;
                 }
                 // ADC for every stored neighbour at once (lanes of a visited neighbour just idle later)
                 const bool have = nn >= 0 && my_chunk;
-                float s = have ? adc_chunk(lut, cw, my_c * 16, ix.pq_M) : 0.0f;
-                s = lanes_tree_sum(s, lpn);
+                float s = adc_chunk(lut, cw, my_c * 16, ix.pq_M);
+                float na = 0.0f;
+                if (ix.sim == 2) na = adc_chunk(ix.pq_norm_lut, cw, my_c * 16, ix.pq_M);
+                // the current block is in registers: now start the runner-up's fetch
+                __builtin_amdgcn_sched_barrier(0);
+                pf_node = c2;
+                if (c2 >= 0) {
+                    pf_nn = my_j < deg ? ix.adj[(size_t)c2 * ix.R + my_j] : -1;
+                    if (my_j < deg && my_chunk)
+                        pf_cw = *(const u32x4*)(ix.pq_fused + ((size_t)c2 * ix.R + my_j) * ix.pq_code_stride + my_c * 16);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                s = lanes_tree_sum(have ? s : 0.0f, lpn);
                 float score;
                 if (ix.sim == 2) {
-                    float na = have ? adc_chunk(ix.pq_norm_lut, cw, my_c * 16, ix.pq_M) : 0.0f;
-                    na = lanes_tree_sum(na, lpn);
+                    na = lanes_tree_sum(have ? na : 0.0f, lpn);
                     score = map_score(2, s / sqrtf(qnorm2 * na));
                 } else {
                     score = map_score(ix.sim, s);
                 }
                 STAMP(2)  // ADC: LUT gathers + lane tree + score map
                 bool is_new = false;
-                if (nn >= 0 && my_c == 0) is_new = visited_insert_lds(hash, hmask, hshift, (uint32_t)nn);
+                if (nn >= 0 && my_c == 0) is_new = visited_insert2(vs, (uint32_t)nn);
                 const int m = __popcll(__ballot(is_new));
-                st.nvisited_set += m;
+                if (vs.spill == nullptr) st_nvisited_lds += m;
+                else vs.nspill += m;
                 st.visited += m;
                 __syncthreads();
                 STAMP(3)  // visited-set inserts
@@ -931,22 +1020,32 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
             } else {
                 for (int cb = 0; cb < deg; cb += JV_WAVE) {
                     const int nv = cb == 0 ? nn : ((cb + lane < deg) ? row[cb + lane] : -1);
-                    if (st.nvisited_set + JV_WAVE > hash_limit) {
+                    if (!visited_room()) {
                         st.overflow = true;
                         break;
                     }
                     bool is_new = false;
-                    if (nv >= 0) is_new = visited_insert_lds(hash, hmask, hshift, (uint32_t)nv);
+                    if (nv >= 0) is_new = visited_insert2(vs, (uint32_t)nv);
                     const unsigned long long mask = __ballot(is_new);
                     const int m = __popcll(mask);
                     if (is_new) todo[__popcll(mask & ((1ull << lane) - 1ull))] = nv;
+                    if (cb == 0) {  // adjacency consumed: start the runner-up's fetch under the scoring below
+                        __builtin_amdgcn_sched_barrier(0);
+                        pf_node = c2;
+                        if (c2 >= 0) pf_nn = my_j < deg ? ix.adj[(size_t)c2 * ix.R + my_j] : -1;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                     __syncthreads();
                     if (m == 0) continue;
-                    st.nvisited_set += m;
+                    if (vs.spill == nullptr) st_nvisited_lds += m;
+                else vs.nspill += m;
                     st.visited += m;
                     score_todo(m);
                     const bool keep = lane < m;
-                    if (!merge_keys(keep, keep ? todo_score[lane] : 0.0f, keep ? todo[lane] : 0)) {
+                    const float ks = keep ? todo_score[lane] : 0.0f;
+                    const int kn = keep ? todo[lane] : 0;
+                    __syncthreads();
+                    if (!merge_keys(keep, ks, kn)) {
                         st.overflow = true;
                         break;
                     }
@@ -1051,6 +1150,354 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
         s[3] = st.expanded_base;
         a.out_flags[qi] = BIG ? (int32_t)JV_FLAG_BIG : 0;
     }
+}
+
+
+// =============================================================================================
+// PQF: the headline path — PQ approximate search on the FUSED layout, single pool, level 0 only.
+//
+// Differences to the generic pool loop (results identical; tests/test_gpu_parity.py):
+//  * no visited set inside the loop.  A re-encountered node has the same ADC score as before, so it is
+//    either still in the pool (the rank-merge finds the identical key and drops the duplicate) or it was
+//    dropped below the pool boundary, which only rises, so it is dropped again.  jvector's visitedCount
+//    (= distinct nodes over all expanded rows, entry point excluded) is computed AFTER the search from the
+//    log of expanded nodes, with a hash set that reuses the LUT's LDS.  That frees the 16-32 KB visited
+//    table during the search: 38 KB per query instead of 73 KB -> 4 resident queries per CU instead of 2.
+//  * merge bookkeeping lives in registers (v_readlane broadcasts), the unexpanded entries are tracked by
+//    ballot bit masks, and the pool is merged in place.
+// Bails out (JV_FLAG_OVERFLOW -> generic retry kernel) on: negative score vs threshold, > 64 boundary
+// ties, expansion log overflow, visited-count table overflow.
+// =============================================================================================
+#define PQF_MAX_CHUNKS 8  // pool capacity <= 512 entries
+
+template <int NCHT>
+__device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int qi, unsigned char* smem) {
+    const int lane = threadIdx.x;
+    const int rk = a.rk, topK = a.topK;
+    const int M = ix.pq_M, R = ix.R, lpn = ix.pq_lanes, cs = ix.pq_code_stride;
+    // ---- LDS carve ----
+    float* lut = (float*)smem;                                   // [M][256]; later: visited-count hash, then rerank scratch
+    size_t off = (size_t)M * 256 * sizeof(float);
+    int64_t* pool = (int64_t*)(smem + off);                      // [cap]
+    const int cap = a.cand_cap;                                  // rk + 128
+    off += (size_t)cap * sizeof(int64_t);
+    int32_t* explog = (int32_t*)(smem + off);                    // [a.res_cap] expanded nodes, in order
+    const int log_cap = a.res_cap;
+    float* qc_lds = (float*)pool;                                // LUT build only: aliases pool + log (host guarantees room)
+    const int pool_limit = cap - JV_WAVE;
+
+    // ---- centred query -> LUT ----
+    const float* qg = a.queries + (size_t)qi * ix.d;
+    for (int i = lane; i < ix.nch * 64; i += JV_WAVE) {
+        float v = i < ix.d ? qg[i] : 0.0f;
+        if (ix.pq_centroid && i < ix.d) v = v - ix.pq_centroid[i];
+        qc_lds[i] = v;
+    }
+    float qnorm2 = 0.0f;
+    if (ix.sim == 2) {  // |q|^2 of the UNcentred query (cosine never centres: no centroid)
+        __syncthreads();
+        qnorm2 = query_norm2(ix, qc_lds, lane);
+        qnorm2 = __shfl(qnorm2, 0, JV_WAVE);
+    }
+    __syncthreads();
+    build_lut(ix, qc_lds, lut, lane);
+    __syncthreads();
+
+    const int my_j = lane / lpn, my_c = lane & (lpn - 1);
+    const bool my_chunk = my_c * 16 < M;
+    auto adc_score = [&](const u32x4 cw, bool have) -> float {
+        float s = adc_chunk(lut, cw, my_c * 16, M);
+        float na = 0.0f;
+        if (ix.sim == 2) na = adc_chunk(ix.pq_norm_lut, cw, my_c * 16, M);
+        s = lanes_tree_sum(have ? s : 0.0f, lpn);
+        if (ix.sim == 2) {
+            na = lanes_tree_sum(have ? na : 0.0f, lpn);
+            return map_score(2, s / sqrtf(qnorm2 * na));
+        }
+        return map_score(ix.sim, s);
+    };
+
+    // ---- entry point ----
+    int np = 0, nexp = 0, expanded = 0;
+    bool overflow = false;
+    unsigned long long um[PQF_MAX_CHUNKS];
+#pragma unroll
+    for (int t = 0; t < PQF_MAX_CHUNKS; t++) um[t] = 0ull;
+    {
+        const int ep = ix.entry;
+        u32x4 cw = (u32x4){0, 0, 0, 0};
+        if (lane < lpn && my_chunk) cw = *(const u32x4*)(ix.pq_codes + (size_t)ep * cs + my_c * 16);
+        const float s = adc_score(cw, lane < lpn && my_chunk);
+        if (lane == 0) pool[0] = make_pool_key(s, ep);
+        np = 1;
+        um[0] = 1ull;
+        __syncthreads();
+    }
+
+    int pf_node = -1, pf_nn = -1;
+    u32x4 pf_cw = (u32x4){0, 0, 0, 0};
+    while (true) {
+        // best and runner-up unexpanded entries from the masks
+        int idx = -1, idx2 = -1;
+#pragma unroll
+        for (int t = 0; t < PQF_MAX_CHUNKS; t++) {
+            unsigned long long m = um[t];
+            if (m && idx2 < 0) {
+                const int p0 = (t << 6) + __ffsll((long long)m) - 1;
+                if (idx < 0) {
+                    idx = p0;
+                    m &= m - 1ull;
+                    if (m) idx2 = (t << 6) + __ffsll((long long)m) - 1;
+                } else {
+                    idx2 = p0;
+                }
+            }
+        }
+        if (idx < 0) break;
+        const int64_t pk = pool[idx];
+        const float sc = key_score(pk);
+        if (sc < a.threshold) {
+            overflow = true;
+            break;
+        }
+        const int c = pool_node(pk);
+        int nn;
+        u32x4 cw = (u32x4){0, 0, 0, 0};
+        if (c == pf_node) {
+            nn = pf_nn;
+            cw = pf_cw;
+        } else {
+            nn = my_j < R ? ix.adj[(size_t)c * R + my_j] : -1;
+            if (my_j < R && my_chunk) cw = *(const u32x4*)(ix.pq_fused + ((size_t)c * R + my_j) * cs + my_c * 16);
+        }
+        const int c2 = idx2 >= 0 ? pool_node(pool[idx2]) : -1;
+        if (nexp >= log_cap) {
+            overflow = true;
+            break;
+        }
+        if (lane == 0) {
+            pool[idx] = pk & ~1ll;
+            explog[nexp] = c;
+        }
+        nexp++;
+#pragma unroll
+        for (int t = 0; t < PQF_MAX_CHUNKS; t++)
+            if (t == (idx >> 6)) um[t] &= ~(1ull << (idx & 63));
+        // ADC of all R stored neighbours
+        const bool have = nn >= 0 && my_chunk;
+        const float score = adc_score(cw, have);
+        // the block is consumed: start the runner-up's fetch
+        __builtin_amdgcn_sched_barrier(0);
+        pf_node = c2;
+        if (c2 >= 0) {
+            pf_nn = my_j < R ? ix.adj[(size_t)c2 * R + my_j] : -1;
+            if (my_j < R && my_chunk) pf_cw = *(const u32x4*)(ix.pq_fused + ((size_t)c2 * R + my_j) * cs + my_c * 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        expanded++;
+        // ---- merge the new keys (one per neighbour, on the lanes with my_c == 0) ----
+        bool keep = nn >= 0 && my_c == 0;
+        if (keep && np >= rk && score < key_score(pool[rk - 1])) keep = false;  // below the boundary for good
+        const int64_t v = make_pool_key(score, nn);
+        int rold = 0;
+        if (keep) {  // rold = #{pool entries > v}: 8-ary search
+            int lo = 0, hi = np;
+            while (hi - lo > 8) {
+                const int step = (hi - lo + 7) >> 3;
+                int cgt = 0;
+#pragma unroll
+                for (int k2 = 1; k2 < 8; k2++) {
+                    const int pp = lo + k2 * step;
+                    cgt += (pp < hi && pool[pp] > v) ? 1 : 0;
+                }
+                lo += cgt * step;
+                hi = lo + step < hi ? lo + step : hi;
+            }
+            rold = lo;
+            for (int pp = lo; pp < hi; pp++) rold += pool[pp] > v ? 1 : 0;
+            // already in the pool (same node => same score => same key up to the expanded bit)?
+            if (rold < np && (pool[rold] | 1ll) == v) keep = false;
+        }
+        unsigned long long km = __ballot(keep);
+        const int nk = __popcll(km);
+        if (nk > 0) {
+            // rank among the kept new keys, and the first insertion point
+            int rnew = 0;
+            const int vlo = (int)(uint32_t)(v & 0xFFFFFFFFll), vhi = (int)(v >> 32);
+            for (unsigned long long m = km; m;) {
+                const int j = __ffsll((long long)m) - 1;
+                m &= m - 1ull;
+                const int64_t kj = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(vhi, j) << 32) |
+                                             (uint64_t)(uint32_t)__builtin_amdgcn_readlane(vlo, j));
+                rnew += kj > v ? 1 : 0;
+            }
+            const unsigned long long firstm = __ballot(keep && rnew == 0);
+            const int r_min = __builtin_amdgcn_readlane(rold, __ffsll((long long)firstm) - 1);
+            // shift old entries at or after the first insertion point, top chunk first, in place
+            for (int t = (np - 1) >> 6; t >= (r_min >> 6); t--) {
+                const int i = (t << 6) + lane;
+                const bool mv = i < np && i >= r_min;
+                const int64_t ov = mv ? pool[i] : 0;
+                int cnt = 0;
+                for (unsigned long long m = km; m;) {
+                    const int j = __ffsll((long long)m) - 1;
+                    m &= m - 1ull;
+                    cnt += i >= __builtin_amdgcn_readlane(rold, j) ? 1 : 0;  // new key j precedes entry i
+                }
+                if (mv && cnt > 0) pool[i + cnt] = ov;
+            }
+            if (keep) pool[rold + rnew] = v;
+            __syncthreads();
+            np = pool_trim(pool, np + nk, rk, lane);
+            if (np > pool_limit) {
+                overflow = true;
+                break;
+            }
+            // rebuild the unexpanded masks of the chunks that changed
+#pragma unroll
+            for (int t = 0; t < PQF_MAX_CHUNKS; t++) {
+                if ((t << 6) < np) {
+                    if (t >= (r_min >> 6)) {
+                        const int i = (t << 6) + lane;
+                        const bool un = i < np && (pool[i] & 1ll);
+                        um[t] = __ballot(un);
+                    }
+                } else {
+                    um[t] = 0ull;
+                }
+            }
+        }
+    }
+
+    int32_t* o_nodes = a.out_nodes + (size_t)qi * topK;
+    int32_t* o_docs = a.out_docs ? a.out_docs + (size_t)qi * topK : nullptr;
+    float* o_scores = a.out_scores + (size_t)qi * topK;
+    int visited = 0;
+    if (!overflow) {
+        // ---- jvector's visitedCount: distinct neighbours of the expanded nodes, entry point excluded ----
+        uint32_t* vh = (uint32_t*)lut;
+        int vslots = 1;
+        while (vslots * 2 <= M * 256) vslots <<= 1;
+        const uint32_t vmask = (uint32_t)vslots - 1u;
+        const int vshift = 32 - (31 - __clz(vslots));
+        const int vlimit = (vslots / 8) * 7;
+        __syncthreads();
+        for (int i = lane; i < vslots; i += JV_WAVE) vh[i] = HASH_EMPTY;
+        __syncthreads();
+        if (lane == 0) visited_insert_lds(vh, vmask, vshift, (uint32_t)ix.entry);
+        __syncthreads();
+        const int rows_per = JV_WAVE / R > 0 ? JV_WAVE / R : 1;  // adjacency rows per wave-instruction
+        for (int e0 = 0; e0 < nexp && !overflow; e0 += rows_per) {
+            if (visited + JV_WAVE > vlimit) {
+                overflow = true;
+                break;
+            }
+            const int e = e0 + lane / R;
+            int nb = -1;
+            if (R <= JV_WAVE) {
+                if (e < nexp && lane < rows_per * R) nb = ix.adj[(size_t)explog[e] * R + (lane % R)];
+                bool is_new = false;
+                if (nb >= 0) is_new = visited_insert_lds(vh, vmask, vshift, (uint32_t)nb);
+                visited += __popcll(__ballot(is_new));
+            } else {
+                for (int cb = 0; cb < R; cb += JV_WAVE) {
+                    nb = (cb + lane < R) ? ix.adj[(size_t)explog[e0] * R + cb + lane] : -1;
+                    bool is_new = false;
+                    if (nb >= 0) is_new = visited_insert_lds(vh, vmask, vshift, (uint32_t)nb);
+                    visited += __popcll(__ballot(is_new));
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (overflow) {
+        if (lane == 0) {
+            a.out_flags[qi] = (int32_t)JV_FLAG_OVERFLOW;
+            a.out_count[qi] = 0;
+        }
+        for (int i = lane; i < topK; i += JV_WAVE) {
+            o_nodes[i] = -1;
+            if (o_docs) o_docs[i] = -1;
+            o_scores[i] = 0.0f;
+        }
+        return;
+    }
+    // ---- rerank (NodeQueue.rerank) with the exact scorer; scratch lives where the LUT was ----
+    float* q_lds = (float*)smem;
+    size_t roff = (size_t)ix.nch * 64 * sizeof(float);
+    float* todo_score = (float*)(smem + roff);
+    roff += JV_TODO * sizeof(float);
+    int32_t* todo = (int32_t*)(smem + roff);
+    roff += JV_TODO * sizeof(int32_t);
+    int64_t* fin = (int64_t*)(smem + roff);  // [rk]
+    for (int i = lane; i < ix.nch * 64; i += JV_WAVE) q_lds[i] = i < ix.d ? qg[i] : 0.0f;
+    __syncthreads();
+    if (ix.sim == 2) qnorm2 = query_norm2(ix, q_lds, lane), qnorm2 = __shfl(qnorm2, 0, JV_WAVE);
+    const int nres = np < rk ? np : rk;
+    int nfin = 0, reranked = 0;
+    int above = 0;
+    for (int i = lane; i < nres; i += JV_WAVE) above += key_score(pool[i]) >= a.rerank_floor ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) above += __shfl_xor(above, o, JV_WAVE);
+    for (int b0 = 0; b0 < nres; b0 += JV_WAVE) {
+        const int i = b0 + lane;
+        bool take = false;
+        int node = 0;
+        if (i < nres) {
+            const int64_t k = pool[i];
+            node = pool_node(k);
+            take = above > 0 ? key_score(k) >= a.rerank_floor : i == 0;  // pool[0] is the best approximate entry
+        }
+        const unsigned long long tm = __ballot(take);
+        const int m = __popcll(tm);
+        if (take) todo[__popcll(tm & ((1ull << lane) - 1ull))] = node;
+        __syncthreads();
+        if (m > 0) {
+            score_rows<NCHT>(ix, q_lds, todo, m, todo_score, qnorm2, 1.0f, lane);
+            __syncthreads();
+            if (lane < m) fin[nfin + lane] = make_key(todo_score[lane], todo[lane]);
+            nfin += m;
+            reranked += m;
+        }
+        __syncthreads();
+    }
+    int cnt = 0;
+    for (; cnt < topK && nfin > 0; cnt++) {
+        int64_t bk;
+        int bidx;
+        scan_max(fin, nfin, lane, bk, bidx);
+        if (lane == 0) {
+            const int node = key_node(bk);
+            o_nodes[cnt] = node;
+            if (o_docs) o_docs[cnt] = ix.ord2doc ? ix.ord2doc[node] : node;
+            o_scores[cnt] = key_score(bk);
+            fin[bidx] = fin[nfin - 1];
+        }
+        nfin--;
+        __syncthreads();
+    }
+    for (int i = cnt + lane; i < topK; i += JV_WAVE) {
+        o_nodes[i] = -1;
+        if (o_docs) o_docs[i] = -1;
+        o_scores[i] = 0.0f;
+    }
+    if (lane == 0) {
+        a.out_count[qi] = cnt;
+        int32_t* st = a.out_stats + (size_t)qi * 4;
+        st[0] = visited;
+        st[1] = reranked;
+        st[2] = expanded;
+        st[3] = expanded;
+        a.out_flags[qi] = 0;
+    }
+}
+
+template <int NCHT>
+__global__ __launch_bounds__(JV_WAVE) void jv_search_pqf_kernel(const JvIndexDev ix, const JvSearchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int qi = blockIdx.x;
+    if (qi >= a.nq) return;
+    search_one_pqf<NCHT>(ix, a, qi, smem);
 }
 
 // Fast path: one query per workgroup, all scratch in LDS.
@@ -1211,6 +1658,8 @@ static const lds_kernel_t g_retry_kernels[2][2][4] = {
     {JV_ROW(jv_search_retry_kernel, true, false), JV_ROW(jv_search_retry_kernel, true, true)}};
 static const lds_kernel_t g_build_kernels[2][4] = {JV_ROW(jv_build_search_kernel, false),
                                                    JV_ROW(jv_build_search_kernel, true)};
+static const lds_kernel_t g_pqf_kernels[4] = {jv_search_pqf_kernel<0>, jv_search_pqf_kernel<2>, jv_search_pqf_kernel<12>,
+                                              jv_search_pqf_kernel<24>};
 static const big_kernel_t g_big_kernels[2][4] = {JV_ROW(jv_search_big_kernel, false), JV_ROW(jv_search_big_kernel, true)};
 
 static int nch_slot(const JvIndexDev* ix) {
@@ -1230,12 +1679,20 @@ extern "C" hipError_t jvk_set_max_lds(int bytes) {
                 if (e != hipSuccess) return e;
             }
             hipError_t e = hipFuncSetAttribute((const void*)g_build_kernels[a][s], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            if (e == hipSuccess && a == 0)
+                e = hipFuncSetAttribute((const void*)g_pqf_kernels[s], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             if (e == hipSuccess)
                 e = hipFuncSetAttribute((const void*)g_big_kernels[a][s], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             if (e != hipSuccess) return e;
         }
     }
     return hipSuccess;
+}
+
+extern "C" hipError_t jvk_launch_search_pqf(const JvIndexDev* ix, const JvSearchArgs* a, int lds_bytes, hipStream_t stream) {
+    if (a->nq <= 0) return hipSuccess;
+    g_pqf_kernels[nch_slot(ix)]<<<a->nq, JV_WAVE, lds_bytes, stream>>>(*ix, *a);
+    return hipGetLastError();
 }
 
 // tag: 0 = query launch, 1 = escalation launch, 2 = graph-builder client

@@ -14,6 +14,16 @@ import __graft_entry__ as graft  # noqa: E402
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # On a GPU box some tests use torch as the device allocator next to the engine.  torch bundles its own
+    # HIP runtime: it must be the first one loaded in the process, so that libjvgpu.so binds to the same
+    # runtime instead of opening the device through a second copy ("No HIP GPUs are available").
+    if os.path.exists("/dev/kfd"):
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except Exception:  # pragma: no cover
+            pass
 
 
 @pytest.fixture(scope="session")

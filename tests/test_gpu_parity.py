@@ -123,8 +123,17 @@ def test_big_path_parity_forced_and_on_overflow(pkg, pyoracle, small_sets):
         b.set_option("force_general_path", 1)    # literal two-queue form in LDS instead of the single pool
         _assert_same(gpu.search_batch(q, 10, 100), want, "general (two-queue) LDS path")
         b.set_option("force_general_path", 0)
-        b.set_option("lds_visited_slots", 512)   # far too small: every query overflows and is retried
-        _assert_same(gpu.search_batch(q, 10, 100), want, "visited overflow -> big path")
+        b.set_option("lds_visited_slots", 512)   # far too small: every query freezes its LDS table and spills to HBM
+        _assert_same(gpu.search_batch(q, 10, 100), want, "two-level visited set (LDS + HBM spill)")
+        b.set_option("spill_slots", 512)         # spill tables too small as well -> flagged -> HBM-scratch path
+        _assert_same(gpu.search_batch(q, 10, 100), want, "spill overflow -> big path")
+        b.set_option("spill_slots", 8192)
+        b.set_option("spill_tables", 0)          # no spill pool at all -> escalation / big path
+        _assert_same(gpu.search_batch(q, 10, 100), want, "visited overflow without spill -> big path")
+        b.set_option("spill_tables", 2048)
+        b.set_option("force_general_path", 1)
+        _assert_same(gpu.search_batch(q, 10, 100), want, "two-queue form with spill")
+        b.set_option("force_general_path", 0)
         b.set_option("lds_visited_slots", 0)
         b.set_option("lds_candidates", 100)      # candidate array too small
         _assert_same(gpu.search_batch(q, 10, 100), want, "candidate overflow -> big path")
@@ -133,6 +142,8 @@ def test_big_path_parity_forced_and_on_overflow(pkg, pyoracle, small_sets):
         b.set_option("force_general_path", 0)
         b.set_option("lds_visited_slots", 0)
         b.set_option("lds_candidates", 0)
+        b.set_option("spill_slots", 8192)
+        b.set_option("spill_tables", 2048)
     gpu.close()
 
 
@@ -216,8 +227,30 @@ def test_fused_adc_layout_parity(pkg, pyoracle, small_sets, sim, M, R):
     gpu = b.GpuIndex(ix, flags=b.DESC_FUSED_ADC)
     assert gpu.info().fused_adc == 1
     orc = pyoracle.Oracle(b, ix)
-    for (k, rk) in [(10, 50), (10, 10), (5, 120)]:
-        _assert_same(gpu.search_batch(q, k, rk), orc.search_batch(q, k, rk), f"fused sim={sim} M={M} R={R} k={k} rk={rk}")
+    for (k, rk) in [(10, 50), (10, 10), (5, 120), (1, 1), (100, 384)]:
+        want = orc.search_batch(q, k, rk)
+        _assert_same(gpu.search_batch(q, k, rk), want, f"fused sim={sim} M={M} R={R} k={k} rk={rk}")
+        try:
+            b.set_option("no_pqf", 1)   # generic pool kernel on the fused layout (in-loop visited set)
+            _assert_same(gpu.search_batch(q, k, rk), want, f"fused/no_pqf sim={sim} M={M} R={R} k={k} rk={rk}")
+        finally:
+            b.set_option("no_pqf", 0)
+    gpu.close()
+
+
+def test_pqf_kernel_with_duplicate_vectors(pkg, pyoracle):
+    """The specialised PQ kernel has no in-loop visited set: re-encountered nodes must be recognised in the
+    pool even when many nodes share one ADC score (duplicated vectors => identical codes)."""
+    b, bl = pkg.binding, pkg.builder
+    rng = np.random.default_rng(3)
+    uniq = rng.random((400, 32)).astype(np.float32)
+    base = np.repeat(uniq, 6, axis=0)[rng.permutation(2400)]
+    q = rng.random((32, 32)).astype(np.float32)
+    ix = bl.build_index_cpu(base, 0, R=32, L=60, pq_M=16)
+    gpu = b.GpuIndex(ix, flags=b.DESC_FUSED_ADC)
+    orc = pyoracle.Oracle(b, ix)
+    for k, rk in [(10, 30), (10, 100), (20, 20)]:
+        _assert_same(gpu.search_batch(q, k, rk), orc.search_batch(q, k, rk), f"pqf ties k={k} rk={rk}")
     gpu.close()
 
 
@@ -249,7 +282,7 @@ def test_device_pointer_api_and_merge_kernel(pkg, pyoracle, small_sets):
     assert np.array_equal(o_nodes.cpu().numpy(), want.nodes)
     assert np.array_equal(o_scores.cpu().numpy().view(np.uint32), want.scores.view(np.uint32))
     assert np.array_equal(o_stats.cpu().numpy(), want.stats)
-    assert (o_flags.cpu().numpy() & 0xC0000000 == 0).all()
+    assert ((o_flags.cpu().numpy().astype(np.uint32) & np.uint32(0xC0000000)) == 0).all()
     # merge kernel: 3 lists of k per query, with empty slots and score ties
     rng = np.random.default_rng(2)
     lists = 3
