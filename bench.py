@@ -264,7 +264,7 @@ def main():
             return sharding.sharded_search(dist, torch, local_search, gpu_merge, qbatch, k, world)
 
     # ---- ground truth + rerankK selection (recall@10 >= 0.95) ----
-    n_gt = 256
+    n_gt = 1024  # queries with exact ground truth (recall is quoted on these)
     gt_local = brute_force_topk(torch, base, queries[:n_gt], k, sim, row_offset)
     if world > 1:
         # global ground truth = merge of per-shard exact top-k
@@ -287,7 +287,7 @@ def main():
         gt = torch.gather(ci, 1, top)
     else:
         gt = gt_local
-    sweep = [args.rerankk] if args.rerankk > 0 else [20, 30, 50, 70, 100, 150, 200, 300, 400]
+    sweep = [args.rerankk] if args.rerankk > 0 else (list(range(20, 200, 10)) + [200, 225, 250, 300, 350, 400])
     chosen, chosen_recall, sweep_log = None, 0.0, []
     if args.profile_mode:
         if args.rerankk <= 0:

@@ -278,7 +278,7 @@ __device__ __forceinline__ void score_rows_fixed(const JvIndexDev& ix, const flo
 template <int NCHT>
 struct RowsInFlight { static constexpr int U = NCHT <= 6 ? 4 : (NCHT <= 12 ? 2 : 1); };
 
-template <int NCHT>
+template <int NCHT, int UMUL = 1>
 __device__ __forceinline__ void score_rows(const JvIndexDev& ix, const float* q_lds, const int32_t* todo, int m,
                                            float* todo_score, float qnorm2, float scale, int lane) {
     if (NCHT == 0) {
@@ -287,7 +287,7 @@ __device__ __forceinline__ void score_rows(const JvIndexDev& ix, const float* q_
         else score_rows_t<2>(ix, q_lds, todo, m, todo_score, qnorm2, scale, lane);
     } else {
         constexpr int N = NCHT == 0 ? 1 : NCHT;
-        constexpr int U = RowsInFlight<N>::U;
+        constexpr int U = RowsInFlight<N>::U * UMUL;
         if (ix.sim == 0) score_rows_fixed<0, N, U, true>(ix, q_lds, todo, m, todo_score, qnorm2, scale, lane);
         else if (ix.sim == 1) score_rows_fixed<1, N, U, true>(ix, q_lds, todo, m, todo_score, qnorm2, scale, lane);
         else score_rows_fixed<2, N, U, true>(ix, q_lds, todo, m, todo_score, qnorm2, scale, lane);
@@ -313,10 +313,10 @@ __device__ __forceinline__ float query_norm2(const JvIndexDev& ix, const float* 
 // PQ: per-query look-up table in LDS, ADC scoring (jvector PQVectors.precomputedScoreFunctionFor /
 // PQDecoder).  lut[m][c] is a sequential fmaf chain over the subspace.
 // ---------------------------------------------------------------------------------------------
+template <int PF>  // PF = codebook rows in flight per lane (each a 1 KiB wave-wide read of the transposed codebook)
 __device__ __forceinline__ void build_lut(const JvIndexDev& ix, const float* qc_lds, float* lut, int lane) {
     const int M = ix.pq_M;
     const bool l2 = ix.sim == 0;
-    constexpr int PF = 16;  // codebook rows in flight per lane (each a 1 KiB wave-wide read of the transposed codebook)
     for (int m = 0; m < M; m++) {
         const int d0 = ix.pq_sub_off[m], d1 = ix.pq_sub_off[m + 1];
         float a[4] = {0.f, 0.f, 0.f, 0.f};
@@ -649,7 +649,7 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
             qc_lds[i] = v;
         }
         __syncthreads();
-        build_lut(ix, qc_lds, lut, lane);
+        build_lut<16>(ix, qc_lds, lut, lane);
         __syncthreads();
     }
     // exact-provider path carries the Lucene MIP x2 wrap (J/JVectorReader.java:220-239,359-364);
@@ -1200,7 +1200,7 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
         qnorm2 = __shfl(qnorm2, 0, JV_WAVE);
     }
     __syncthreads();
-    build_lut(ix, qc_lds, lut, lane);
+    build_lut<24>(ix, qc_lds, lut, lane);
     __syncthreads();
 
     const int my_j = lane / lpn, my_c = lane & (lpn - 1);
@@ -1220,6 +1220,7 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
     // ---- entry point ----
     int np = 0, nexp = 0, expanded = 0;
     bool overflow = false;
+    float bscore = 0.0f;  // score of pool[rk-1] once the pool holds rk entries (the boundary)
     unsigned long long um[PQF_MAX_CHUNKS];
 #pragma unroll
     for (int t = 0; t < PQF_MAX_CHUNKS; t++) um[t] = 0ull;
@@ -1236,6 +1237,8 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
 
     int pf_node = -1, pf_nn = -1;
     u32x4 pf_cw = (u32x4){0, 0, 0, 0};
+    STAMP_DECL
+    STAMP(7)  // staging + LUT build + entry point
     while (true) {
         // best and runner-up unexpanded entries from the masks
         int idx = -1, idx2 = -1;
@@ -1271,6 +1274,14 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
             if (my_j < R && my_chunk) cw = *(const u32x4*)(ix.pq_fused + ((size_t)c * R + my_j) * cs + my_c * 16);
         }
         const int c2 = idx2 >= 0 ? pool_node(pool[idx2]) : -1;
+#ifdef JV_STAMPS
+        asm volatile("" ::"v"(c2), "v"(c));
+#endif
+        STAMP(0)  // masks -> idx, pool reads
+#ifdef JV_STAMPS
+        asm volatile("" ::"v"(nn), "v"(cw[0]), "v"(cw[3]));
+#endif
+        STAMP(1)  // wait for the block
         if (nexp >= log_cap) {
             overflow = true;
             break;
@@ -1295,79 +1306,113 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
         }
         __builtin_amdgcn_sched_barrier(0);
         expanded++;
+#ifdef JV_STAMPS
+        asm volatile("" ::"v"(score));
+#endif
+        STAMP(2)  // ADC + prefetch issue
         // ---- merge the new keys (one per neighbour, on the lanes with my_c == 0) ----
+        // All LDS reads below are unconditional (clamped index) and batched into registers first: a
+        // conditional load would compile into an exec-masked branch with its own LDS round trip.
         bool keep = nn >= 0 && my_c == 0;
-        if (keep && np >= rk && score < key_score(pool[rk - 1])) keep = false;  // below the boundary for good
+        if (np >= rk && score < bscore) keep = false;  // below the boundary for good
         const int64_t v = make_pool_key(score, nn);
-        int rold = 0;
-        if (keep) {  // rold = #{pool entries > v}: 8-ary search
-            int lo = 0, hi = np;
-            while (hi - lo > 8) {
-                const int step = (hi - lo + 7) >> 3;
-                int cgt = 0;
+        int rold;
+        {   // rold = #{pool entries > v} = first index whose entry is <= v.  Uniform 3-level 8-ary search over
+            // the (<= 512-entry) pool: block sizes 64, 8, 1.
+            const int last = cap - 1;
+            int64_t p1[7], p2[7], p3[9];
 #pragma unroll
-                for (int k2 = 1; k2 < 8; k2++) {
-                    const int pp = lo + k2 * step;
-                    cgt += (pp < hi && pool[pp] > v) ? 1 : 0;
-                }
-                lo += cgt * step;
-                hi = lo + step < hi ? lo + step : hi;
+            for (int k2 = 0; k2 < 7; k2++) p1[k2] = pool[min(k2 * 64 + 63, last)];
+            int c1 = 0;
+#pragma unroll
+            for (int k2 = 0; k2 < 7; k2++) c1 += ((k2 * 64 + 63 < np) & (p1[k2] > v)) ? 1 : 0;
+            int lo = c1 * 64;
+#pragma unroll
+            for (int k2 = 0; k2 < 7; k2++) p2[k2] = pool[min(lo + k2 * 8 + 7, last)];
+            int c2 = 0;
+#pragma unroll
+            for (int k2 = 0; k2 < 7; k2++) c2 += ((lo + k2 * 8 + 7 < np) & (p2[k2] > v)) ? 1 : 0;
+            lo += c2 * 8;
+#pragma unroll
+            for (int k2 = 0; k2 < 9; k2++) p3[k2] = pool[min(lo + k2, last)];
+            int c3 = 0;
+            bool dup = false;  // same node => same score => same key up to the expanded bit
+#pragma unroll
+            for (int k2 = 0; k2 < 9; k2++) {
+                const bool in = lo + k2 < np;
+                if (k2 < 8) c3 += (in & (p3[k2] > v)) ? 1 : 0;
+                dup |= in & ((p3[k2] | 1ll) == v);
             }
-            rold = lo;
-            for (int pp = lo; pp < hi; pp++) rold += pool[pp] > v ? 1 : 0;
-            // already in the pool (same node => same score => same key up to the expanded bit)?
-            if (rold < np && (pool[rold] | 1ll) == v) keep = false;
+            rold = lo + c3;
+            if (dup) keep = false;
         }
-        unsigned long long km = __ballot(keep);
+        const unsigned long long km = __ballot(keep);
         const int nk = __popcll(km);
+        STAMP(3)  // boundary check + 3-level rank search + duplicate check
         if (nk > 0) {
-            // rank among the kept new keys, and the first insertion point
+            // rank among the kept new keys, the first insertion point, and per-chunk shift counts
             int rnew = 0;
+            int cnt[PQF_MAX_CHUNKS];
+#pragma unroll
+            for (int t = 0; t < PQF_MAX_CHUNKS; t++) cnt[t] = 0;
             const int vlo = (int)(uint32_t)(v & 0xFFFFFFFFll), vhi = (int)(v >> 32);
             for (unsigned long long m = km; m;) {
                 const int j = __ffsll((long long)m) - 1;
                 m &= m - 1ull;
                 const int64_t kj = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(vhi, j) << 32) |
                                              (uint64_t)(uint32_t)__builtin_amdgcn_readlane(vlo, j));
+                const int rj = __builtin_amdgcn_readlane(rold, j);
                 rnew += kj > v ? 1 : 0;
+#pragma unroll
+                for (int t = 0; t < PQF_MAX_CHUNKS; t++) cnt[t] += ((t << 6) + lane >= rj) ? 1 : 0;  // key j precedes entry
             }
             const unsigned long long firstm = __ballot(keep && rnew == 0);
             const int r_min = __builtin_amdgcn_readlane(rold, __ffsll((long long)firstm) - 1);
-            // shift old entries at or after the first insertion point, top chunk first, in place
-            for (int t = (np - 1) >> 6; t >= (r_min >> 6); t--) {
+            // read every old entry first, then write the shifted ones: in place, no ordering hazard
+            int64_t ov[PQF_MAX_CHUNKS];
+#pragma unroll
+            for (int t = 0; t < PQF_MAX_CHUNKS; t++) ov[t] = pool[min((t << 6) + lane, cap - 1)];
+#pragma unroll
+            for (int t = 0; t < PQF_MAX_CHUNKS; t++) {
                 const int i = (t << 6) + lane;
-                const bool mv = i < np && i >= r_min;
-                const int64_t ov = mv ? pool[i] : 0;
-                int cnt = 0;
-                for (unsigned long long m = km; m;) {
-                    const int j = __ffsll((long long)m) - 1;
-                    m &= m - 1ull;
-                    cnt += i >= __builtin_amdgcn_readlane(rold, j) ? 1 : 0;  // new key j precedes entry i
-                }
-                if (mv && cnt > 0) pool[i + cnt] = ov;
+                if (i < np && cnt[t] > 0) pool[i + cnt[t]] = ov[t];
             }
             if (keep) pool[rold + rnew] = v;
             __syncthreads();
-            np = pool_trim(pool, np + nk, rk, lane);
+            STAMP(4)  // ranks among new keys + in-place shift + insert
+            // trim to the boundary (+ ties) and rebuild the unexpanded masks, one batched read of the pool
+            const int ntot = np + nk;
+#pragma unroll
+            for (int t = 0; t < PQF_MAX_CHUNKS; t++) ov[t] = pool[min((t << 6) + lane, cap - 1)];
+            int nnew = ntot;
+            if (ntot > rk) {
+                const int64_t bk = pool[rk - 1];
+                bscore = key_score(bk);
+                int ties = 0;  // entries beyond rk-1 that tie with the boundary score stay (they are contiguous)
+#pragma unroll
+                for (int t = 0; t < PQF_MAX_CHUNKS; t++) {
+                    const int i = (t << 6) + lane;
+                    ties += __popcll(__ballot(i >= rk && i < ntot && key_score(ov[t]) == bscore));
+                }
+                nnew = rk + ties;
+            } else if (ntot == rk) {
+                bscore = key_score(pool[rk - 1]);
+            }
+            np = nnew;
             if (np > pool_limit) {
                 overflow = true;
                 break;
             }
-            // rebuild the unexpanded masks of the chunks that changed
 #pragma unroll
             for (int t = 0; t < PQF_MAX_CHUNKS; t++) {
-                if ((t << 6) < np) {
-                    if (t >= (r_min >> 6)) {
-                        const int i = (t << 6) + lane;
-                        const bool un = i < np && (pool[i] & 1ll);
-                        um[t] = __ballot(un);
-                    }
-                } else {
-                    um[t] = 0ull;
-                }
+                const int i = (t << 6) + lane;
+                um[t] = __ballot(i < np && (ov[t] & 1ll));
             }
+            (void)r_min;
+            STAMP(5)  // trim + mask rebuild
         }
     }
+    STAMP(5)
 
     int32_t* o_nodes = a.out_nodes + (size_t)qi * topK;
     int32_t* o_docs = a.out_docs ? a.out_docs + (size_t)qi * topK : nullptr;
@@ -1387,21 +1432,31 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
         if (lane == 0) visited_insert_lds(vh, vmask, vshift, (uint32_t)ix.entry);
         __syncthreads();
         const int rows_per = JV_WAVE / R > 0 ? JV_WAVE / R : 1;  // adjacency rows per wave-instruction
-        for (int e0 = 0; e0 < nexp && !overflow; e0 += rows_per) {
-            if (visited + JV_WAVE > vlimit) {
-                overflow = true;
-                break;
+        if (R <= JV_WAVE) {
+            constexpr int VB = 8;  // adjacency batches in flight
+            for (int e0 = 0; e0 < nexp && !overflow; e0 += rows_per * VB) {
+                int nb[VB];
+#pragma unroll
+                for (int u = 0; u < VB; u++) {
+                    const int e = e0 + u * rows_per + lane / R;
+                    nb[u] = (e < nexp && lane < rows_per * R) ? ix.adj[(size_t)explog[e] * R + (lane % R)] : -1;
+                }
+#pragma unroll
+                for (int u = 0; u < VB; u++) {
+                    if (visited + JV_WAVE > vlimit) overflow = true;
+                    bool is_new = false;
+                    if (!overflow && nb[u] >= 0) is_new = visited_insert_lds(vh, vmask, vshift, (uint32_t)nb[u]);
+                    visited += __popcll(__ballot(is_new));
+                }
             }
-            const int e = e0 + lane / R;
-            int nb = -1;
-            if (R <= JV_WAVE) {
-                if (e < nexp && lane < rows_per * R) nb = ix.adj[(size_t)explog[e] * R + (lane % R)];
-                bool is_new = false;
-                if (nb >= 0) is_new = visited_insert_lds(vh, vmask, vshift, (uint32_t)nb);
-                visited += __popcll(__ballot(is_new));
-            } else {
+        } else {
+            for (int e0 = 0; e0 < nexp && !overflow; e0++) {
                 for (int cb = 0; cb < R; cb += JV_WAVE) {
-                    nb = (cb + lane < R) ? ix.adj[(size_t)explog[e0] * R + cb + lane] : -1;
+                    if (visited + JV_WAVE > vlimit) {
+                        overflow = true;
+                        break;
+                    }
+                    const int nb = (cb + lane < R) ? ix.adj[(size_t)explog[e0] * R + cb + lane] : -1;
                     bool is_new = false;
                     if (nb >= 0) is_new = visited_insert_lds(vh, vmask, vshift, (uint32_t)nb);
                     visited += __popcll(__ballot(is_new));
@@ -1410,6 +1465,8 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
         }
         __syncthreads();
     }
+    STAMP(6)  // visited-count pass
+    STAMP_FLUSH
     if (overflow) {
         if (lane == 0) {
             a.out_flags[qi] = (int32_t)JV_FLAG_OVERFLOW;
@@ -1453,7 +1510,7 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
         if (take) todo[__popcll(tm & ((1ull << lane) - 1ull))] = node;
         __syncthreads();
         if (m > 0) {
-            score_rows<NCHT>(ix, q_lds, todo, m, todo_score, qnorm2, 1.0f, lane);
+            score_rows<NCHT, 2>(ix, q_lds, todo, m, todo_score, qnorm2, 1.0f, lane);
             __syncthreads();
             if (lane < m) fin[nfin + lane] = make_key(todo_score[lane], todo[lane]);
             nfin += m;

@@ -20,7 +20,7 @@ base = bench.gen_rows_block(torch, n, d, 42, 0, zc, Bl, Bg, 0.35, 0.1, 0.005, Fa
 q = bench.gen_rows_block(torch, B, d, 43, 0, zc, Bl, Bg, 0.35, 0.1, 0.005, False, dev)
 adj, entry = gb.build_graph_gpu(torch, base, 0, R=32, L=100, verbose=False)
 pq = gb.pq_train_encode_gpu(torch, base, M, 0)
-for fused in (1, 0):
+for fused in (1,):
     desc, keep = b.make_desc_device(n, d, 32, base.data_ptr(), adj.data_ptr(), entry, 0, pq_M=M, pq_K=pq["K"],
                                     pq_codebooks=pq["codebooks"], pq_centroid=pq["centroid"], pq_codes_ptr=pq["codes"].data_ptr(),
                                     borrow=True, extra_flags=(b.DESC_FUSED_ADC if fused else 0))
@@ -39,10 +39,10 @@ for fused in (1, 0):
     b.set_option("dbg_ptr", 0)
     v = dbg.cpu().numpy().astype(np.float64)
     st = o[4].cpu().numpy().astype(np.float64).mean(0)
-    names = ["find-unexpanded", "block issue+wait", "ADC", "visited insert", "pool merge", "non-fused/exit", "prefetch hits", "pre-loop (LUT etc.)"]
-    cyc = v.copy(); hits = cyc[6]; cyc[6] = 0
+    names = ["find (masks, pool reads)", "block wait", "ADC + prefetch issue", "rank search + dedupe", "new-key ranks + shift + insert", "trim + mask rebuild", "visited-count pass", "pre-loop (LUT, entry)"]
+    cyc = v.copy(); hits = 0
     print(f"fused={fused}: {B / dt:.0f} QPS (stamped build), expansions/query {st[2]:.1f}, prefetch hit rate {hits / (st[2] * B):.2f}")
     for i, nme in enumerate(names):
-        if i != 6:
+        if True:
             print(f"   {nme:24s} {100 * cyc[i] / cyc.sum():5.1f} %   {cyc[i] / B / max(st[2], 1):8.0f} cycles/expansion")
     ix.close()
