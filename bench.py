@@ -373,6 +373,8 @@ def main():
         lat.append((time.perf_counter() - t1) * 1e3)
     p50 = float(np.median(lat[20:]))
 
+    fused_on = bool(pq_M) and os.environ.get("JV_BENCH_FUSED", "1") == "1"
+    main_kernel = "jv_search_pqf_kernel" if fused_on else "jv_search_lds_kernel"
     result = {
         "metric": "queries/sec at recall@10>=0.95",
         "value": round(qps, 1),
@@ -403,7 +405,7 @@ def main():
         "build_seconds": round(build_s, 1),
         "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "kernel": "jv_search_lds_kernel", "kernel_avg_ms": round(kernel_avg_ms, 4),
+                     "kernel": main_kernel, "kernel_avg_ms": round(kernel_avg_ms, 4),
                      "algorithmic_bytes_per_launch": round(bytes_per_launch, 1)},
     }
 

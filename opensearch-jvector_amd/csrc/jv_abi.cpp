@@ -146,7 +146,7 @@ int ctx_create(jv_index* ix, Ctx** out) {
     Ctx* c = new Ctx();
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->last_use, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipMalloc((void**)&c->work_counter, 2 * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&c->work_counter, 8 * sizeof(int32_t));
     if (e != hipSuccess) {
         delete c;
         return fail(JV_EDEVICE, "context creation failed: %s", hipGetErrorString(e));
@@ -313,9 +313,10 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
     a.spill_slots = c->spill_slots;
     a.spill_tables = c->spill_tables;
     a.spill_counter = c->work_counter + 1;
+    a.retry_counter = c->work_counter + 2;
     a.dbg = (int64_t*)(uintptr_t)opt_dbg_ptr.load();  // always 0 unless a diagnostic run set it
     const bool force_big = opt_force_big.load() != 0 || !g.fast_ok;
-    HIPCHK(hipMemsetAsync(c->work_counter, 0, 2 * sizeof(int32_t), stream));
+    HIPCHK(hipMemsetAsync(c->work_counter, 0, 8 * sizeof(int32_t), stream));
     // headline path: PQ + fused layout + single pool + flat graph -> specialised kernel without an in-loop
     // visited set (jv_kernels.hip "PQF"); anything it cannot hold is flagged and falls through to the ladder
     bool pqf = false;
@@ -338,6 +339,7 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
         if (pqf) {
             JvSearchArgs ar = a;
             ar.retry_only = 1;
+            ar.retry_counter = c->work_counter + 3;
             HIPCHK(jvk_launch_search_lds(&ix->dev, &ar, 1, g.pool ? 1 : 0, 1, g.lds_fast, stream));
         } else
         HIPCHK(jvk_launch_search_lds(&ix->dev, &a, pq ? 1 : 0, g.pool ? 1 : 0, ix->build_client ? 2 : 0, g.lds_fast, stream));
@@ -351,6 +353,7 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
                 a2.cand_cap = g2.cand_cap;
                 a2.res_cap = g2.res_cap;
                 a2.retry_only = 1;
+                a2.retry_counter = c->work_counter + 4;
                 HIPCHK(jvk_launch_search_lds(&ix->dev, &a2, pq ? 1 : 0, g2.pool ? 1 : 0, 1, g2.lds_fast, stream));
             }
         }

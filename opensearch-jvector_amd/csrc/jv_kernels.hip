@@ -1571,10 +1571,24 @@ __global__ __launch_bounds__(JV_WAVE) void jv_search_lds_kernel(const JvIndexDev
 template <bool PQ, bool POOL, int NCHT>
 __global__ __launch_bounds__(JV_WAVE) void jv_search_retry_kernel(const JvIndexDev ix, const JvSearchArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int qi = blockIdx.x;
-    if (qi >= a.nq) return;
-    if (!((uint32_t)a.out_flags[qi] & JV_FLAG_OVERFLOW)) return;
-    search_one<PQ, false, POOL, NCHT>(ix, a, qi, smem, nullptr, nullptr);
+    // A small resident grid walks the flag array 64 queries at a time (one flag per lane) and runs only the
+    // flagged ones: a launch with nothing to redo costs microseconds instead of dispatching nq large-LDS blocks.
+    const int lane = threadIdx.x;
+    for (;;) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(a.retry_counter, JV_WAVE);
+        base = __shfl(base, 0, JV_WAVE);
+        if (base >= a.nq) break;
+        const int qi = base + lane;
+        const bool flagged = qi < a.nq && ((uint32_t)a.out_flags[qi] & JV_FLAG_OVERFLOW);
+        unsigned long long m = __ballot(flagged);
+        while (m) {
+            const int j = __ffsll((long long)m) - 1;
+            m &= m - 1ull;
+            search_one<PQ, false, POOL, NCHT>(ix, a, base + j, smem, nullptr, nullptr);
+            __syncthreads();
+        }
+    }
 }
 
 // The same search launched on behalf of the graph builder (index created with JV_DESC_BUILD_CLIENT): a
@@ -1757,10 +1771,14 @@ extern "C" hipError_t jvk_launch_search_lds(const JvIndexDev* ix, const JvSearch
                                             int lds_bytes, hipStream_t stream) {
     if (a->nq <= 0) return hipSuccess;
     lds_kernel_t k;
-    if (tag == 1) k = g_retry_kernels[pq ? 1 : 0][pool ? 1 : 0][nch_slot(ix)];
-    else if (tag == 2 && !pq) k = g_build_kernels[pool ? 1 : 0][nch_slot(ix)];
+    int grid = a->nq;
+    if (tag == 1) {
+        k = g_retry_kernels[pq ? 1 : 0][pool ? 1 : 0][nch_slot(ix)];
+        grid = (a->nq + JV_WAVE - 1) / JV_WAVE;  // at most one block per 64 queries; blocks dequeue flag chunks
+        if (grid > 2048) grid = 2048;
+    } else if (tag == 2 && !pq) k = g_build_kernels[pool ? 1 : 0][nch_slot(ix)];
     else k = g_lds_kernels[pq ? 1 : 0][pool ? 1 : 0][nch_slot(ix)];
-    k<<<a->nq, JV_WAVE, lds_bytes, stream>>>(*ix, *a);
+    k<<<grid, JV_WAVE, lds_bytes, stream>>>(*ix, *a);
     return hipGetLastError();
 }
 

@@ -29,13 +29,14 @@ def main(src, name):
              "", f"bench line under the tracer: value = {bench['value']} {bench['unit']}, roofline = {json.dumps(bench['roofline'])}", "",
              "## kernel_stats.csv rows of this repo's kernels", "", "| kernel | calls | avg ms | total ms |", "|---|---|---|---|"]
     main_avg = None
+    main_kernel = bench["roofline"].get("kernel", "jv_search_lds_kernel")
     for r in csv.DictReader(open(os.path.join(src, "kernel_stats.csv"))):
-        if "jv_" in r["Name"]:
+        if "jv_" in r["Name"] or "jvb_" in r["Name"]:
             avg = float(r["AverageNs"]) / 1e6
             lines.append(f"| `{r['Name'].split('(')[0]}` | {r['Calls']} | {avg:.4f} | {float(r['TotalDurationNs']) / 1e6:.2f} |")
-            if "jv_search_lds_kernel" in r["Name"] and main_avg is None:
+            if main_kernel in r["Name"] and main_avg is None:
                 main_avg = avg
-    lines += ["", f"`jv_search_lds_kernel` is launched only by the {warm} warm-up + {steps} timed steps in --profile-mode "
+    lines += ["", f"`{main_kernel}` is launched only by the {warm} warm-up + {steps} timed steps in --profile-mode "
                   "(index construction uses `jv_build_search_kernel`, escalation passes `jv_search_retry_kernel`), so its "
                   f"average ({main_avg:.4f} ms) is directly comparable with bench.py's `roofline.kernel_avg_ms` "
                   f"({bench['roofline']['kernel_avg_ms']} ms, HIP events around launch + escalation + big-path launches).", ""]
@@ -45,7 +46,7 @@ def main(src, name):
         if not os.path.exists(p):
             continue
         vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(p))
-                if "jv_search_lds_kernel" in r["Kernel_Name"] and r["Grid_Size"] == grid]
+                if main_kernel in r["Kernel_Name"] and r["Grid_Size"] == grid]
         vals = vals[-steps:]
         if vals:
             traffic[cname] = sum(vals) / len(vals)
