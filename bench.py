@@ -182,14 +182,22 @@ def main():
             log(f"option {key[len('JV_OPT_'):].lower()} = {val}")
 
     wl = dict(WORKLOADS[args.workload])
-    n = args.n if args.n > 0 else wl["n"]
+    n_cfg = args.n if args.n > 0 else wl["n"]
     d, sim, pq_M = wl["d"], wl["sim"], wl["pq_M"]
     R, L, k = 32, 100, 10
-    row_offset = rank * n
+    # N > 1: doc-ID-range shards.  Default = the north star's curve: the SAME corpus (10M docs) split over the
+    # ranks ("strong": total work fixed; every rank searches every query on its n/N docs, rerankK is re-swept
+    # so that the MERGED recall@10 stays >= 0.95).  JV_BENCH_SCALING=weak keeps n docs per GPU instead.
+    scaling = os.environ.get("JV_BENCH_SCALING", "strong" if world > 1 else "weak")
+    if world > 1 and scaling == "strong":
+        lo_doc, hi_doc = sharding.shard_range(n_cfg, world, rank)
+        n, row_offset, n_total = hi_doc - lo_doc, lo_doc, n_cfg
+    else:
+        n, row_offset, n_total = n_cfg, rank * n_cfg, n_cfg * world
 
     # ---- data in HBM ----
     t0 = time.time()
-    centres = max(64, min(4096, n // 256))
+    centres = max(64, min(4096, n_total // 256))
     nq_pool = args.batch * 2
     if pq_M:
         sigma = float(os.environ.get("JV_BENCH_SIGMA", "0.35"))
@@ -228,7 +236,7 @@ def main():
         n, d, R, base.data_ptr(), adj_t.data_ptr(), entry, sim, device=local_rank,
         pq_M=pq_M, pq_K=(pq["K"] if pq else 0), pq_codebooks=(pq["codebooks"] if pq else None),
         pq_centroid=(pq["centroid"] if pq else None), pq_codes_ptr=(pq["codes"].data_ptr() if pq else 0),
-        ord2doc_ptr=(ord2doc.data_ptr() if ord2doc is not None else 0), max_doc=n * world, borrow=True,
+        ord2doc_ptr=(ord2doc.data_ptr() if ord2doc is not None else 0), max_doc=n_total, borrow=True,
         extra_flags=(binding.DESC_FUSED_ADC if (pq and os.environ.get("JV_BENCH_FUSED", "1") == "1") else 0))
     index = binding.GpuIndex(desc=desc, keepalive=keep, flags=binding.DESC_BORROW)
 
@@ -359,7 +367,7 @@ def main():
         # tools/summarize_profile.py); used only when workload, n, batch and rerankK all match this run
         try:
             tj = json.load(open(tpath)).get("entries", {}).get(args.workload)
-            if tj and tj.get("n") == n and tj.get("batch") == B and tj.get("rerankK") == rk:
+            if world == 1 and tj and tj.get("n") == n and tj.get("batch") == B and tj.get("rerankK") == rk:
                 traffic = tj.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
@@ -384,13 +392,13 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": scaling,
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": f"{args.workload}: {wl['desc']}" + ("" if n == wl["n"] else f" [REDUCED n={n} per GPU]"),
-            "docs_per_gpu": n, "total_docs": n * world, "dim": d, "similarity": ["l2", "dot", "cosine"][sim],
+            "workload": f"{args.workload}: {wl['desc']}" + ("" if n_total == wl["n"] * (world if scaling == "weak" else 1) else f" [n_total={n_total}]"),
+            "docs_per_gpu": n, "total_docs": n_total, "dim": d, "similarity": ["l2", "dot", "cosine"][sim],
             "R": R, "ef_construction": L, "k": k, "rerankK": rk, "pq_M": pq_M, "queries_per_step": B,
             "sharding": "doc-id range, RCCL all-gather of per-shard top-k + GPU merge" if world > 1 else "single GPU",
             "graph_builder": args.builder, "pq_layout": ("fused" if (pq_M and os.environ.get("JV_BENCH_FUSED", "1") == "1") else ("plain" if pq_M else None)),
