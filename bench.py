@@ -164,11 +164,18 @@ def main():
         log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    # one rank per GPU; (debug only: JV_BENCH_BACKEND=gloo lets several ranks share one GPU to exercise the
+    # shard / all-gather / merge path on a single-GPU box — the collective then stages through the host)
+    backend = os.environ.get("JV_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=backend)
 
     graft.load_package()
     binding = importlib.import_module("opensearch_jvector_amd.binding")
@@ -286,10 +293,17 @@ def main():
                 v = base[(ids - row_offset).clamp(0, n - 1)]
                 return (qn[:, None, :] * v).sum(-1)
         ls = sc_of(gt_local)
-        all_i = [torch.empty_like(gt_local) for _ in range(world)]
-        all_s = [torch.empty_like(ls) for _ in range(world)]
-        dist.all_gather(all_i, gt_local)
-        dist.all_gather(all_s, ls)
+        if backend == "nccl":
+            all_i = [torch.empty_like(gt_local) for _ in range(world)]
+            all_s = [torch.empty_like(ls) for _ in range(world)]
+            dist.all_gather(all_i, gt_local)
+            dist.all_gather(all_s, ls)
+        else:
+            all_i = [torch.empty_like(gt_local, device="cpu") for _ in range(world)]
+            all_s = [torch.empty_like(ls, device="cpu") for _ in range(world)]
+            dist.all_gather(all_i, gt_local.cpu())
+            dist.all_gather(all_s, ls.cpu())
+            all_i, all_s = [t.to(device) for t in all_i], [t.to(device) for t in all_s]
         ci, cs = torch.cat(all_i, 1), torch.cat(all_s, 1)
         top = cs.topk(k, dim=1).indices
         gt = torch.gather(ci, 1, top)
@@ -341,7 +355,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t_start
     if world > 1:
-        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device=(device if backend == "nccl" else "cpu"), dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     total_queries = args.steps * B

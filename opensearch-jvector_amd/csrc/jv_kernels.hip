@@ -361,15 +361,20 @@ __device__ __forceinline__ float lanes_tree_sum(float v, int lpn) {
 // 16 consecutive subspaces per lane, summed left to right; chunk sums combined by the lane tree.
 // All 16 table reads are issued before the first add (independent ds_read_b32, one LDS round trip);
 // slots beyond M contribute +0.0f, which leaves the sum bit-identical.
+template <bool FULL = false>  // FULL: all 16 subspaces of the chunk exist (M % 16 == 0): no per-slot masking
 __device__ __forceinline__ float adc_chunk(const float* lut, const u32x4 cw, int m0, int M) {
     float v[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) {
         const int mi = m0 + i;
         const uint32_t code = (cw[i >> 2] >> ((i & 3) * 8)) & 0xFFu;
-        const int mc = mi < M ? mi : m0;  // clamp the address, mask the value
-        const float t = lut[mc * 256 + code];
-        v[i] = mi < M ? t : 0.0f;
+        if (FULL) {
+            v[i] = lut[mi * 256 + code];
+        } else {
+            const int mc = mi < M ? mi : m0;  // clamp the address, mask the value
+            const float t = lut[mc * 256 + code];
+            v[i] = mi < M ? t : 0.0f;
+        }
     }
     float s = 0.0f;
 #pragma unroll
@@ -1205,10 +1210,11 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
 
     const int my_j = lane / lpn, my_c = lane & (lpn - 1);
     const bool my_chunk = my_c * 16 < M;
+    const bool full16 = (M & 15) == 0;
     auto adc_score = [&](const u32x4 cw, bool have) -> float {
-        float s = adc_chunk(lut, cw, my_c * 16, M);
+        float s = full16 ? adc_chunk<true>(lut, cw, my_c * 16, M) : adc_chunk<false>(lut, cw, my_c * 16, M);
         float na = 0.0f;
-        if (ix.sim == 2) na = adc_chunk(ix.pq_norm_lut, cw, my_c * 16, M);
+        if (ix.sim == 2) na = adc_chunk<false>(ix.pq_norm_lut, cw, my_c * 16, M);
         s = lanes_tree_sum(have ? s : 0.0f, lpn);
         if (ix.sim == 2) {
             na = lanes_tree_sum(have ? na : 0.0f, lpn);

@@ -24,8 +24,16 @@ def gather_topk(dist, torch, docs, scores, world: int, out_docs=None, out_scores
     if out_docs is None:
         out_docs = torch.empty((world, nq, k), dtype=docs.dtype, device=docs.device)
         out_scores = torch.empty((world, nq, k), dtype=scores.dtype, device=scores.device)
-    dist.all_gather_into_tensor(out_docs.view(-1), docs.contiguous().view(-1))
-    dist.all_gather_into_tensor(out_scores.view(-1), scores.contiguous().view(-1))
+    if docs.is_cuda and dist.get_backend() == "gloo":  # debug path (several ranks on one GPU): stage through the host
+        torch.cuda.current_stream(docs.device).synchronize()
+        hd, hs = torch.empty(out_docs.shape, dtype=docs.dtype), torch.empty(out_scores.shape, dtype=scores.dtype)
+        dist.all_gather_into_tensor(hd.view(-1), docs.contiguous().view(-1).cpu())
+        dist.all_gather_into_tensor(hs.view(-1), scores.contiguous().view(-1).cpu())
+        out_docs.copy_(hd)
+        out_scores.copy_(hs)
+    else:
+        dist.all_gather_into_tensor(out_docs.view(-1), docs.contiguous().view(-1))
+        dist.all_gather_into_tensor(out_scores.view(-1), scores.contiguous().view(-1))
     gd = out_docs.permute(1, 0, 2).reshape(nq, world * k).contiguous()
     gs = out_scores.permute(1, 0, 2).reshape(nq, world * k).contiguous()
     return gd, gs
