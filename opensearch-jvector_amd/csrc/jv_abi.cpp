@@ -320,7 +320,8 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
     // headline path: PQ + fused layout + single pool + flat graph -> specialised kernel without an in-loop
     // visited set (jv_kernels.hip "PQF"); anything it cannot hold is flagged and falls through to the ladder
     bool pqf = false;
-    if (!force_big && pq && g.pool && ix->dev.pq_fused && ix->dev.num_upper == 0 && ix->dev.R * ix->dev.pq_lanes <= JV_WAVE &&
+    if (!force_big && pq && g.pool && ix->dev.pq_fused && ix->dev.num_upper == 0 && ix->dev.R <= JV_WAVE && ix->dev.R * ix->dev.pq_lanes <= 4 * JV_WAVE &&
+        (ix->dev.R * ix->dev.pq_lanes + JV_WAVE - 1) / JV_WAVE <= ix->dev.pq_lanes &&
         rk + 128 <= 512 && opt_no_pqf.load() == 0) {
         JvSearchArgs ap = a;
         ap.cand_cap = (rk + 128 + 1) & ~1;          // pool entries

@@ -1174,6 +1174,7 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
 // ties, expansion log overflow, visited-count table overflow.
 // =============================================================================================
 #define PQF_MAX_CHUNKS 8  // pool capacity <= 512 entries
+#define PQF_MAX_PASS 4    // fused block passes: R * lanes-per-node <= 256
 
 template <int NCHT>
 __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int qi, unsigned char* smem) {
@@ -1208,7 +1209,13 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
     build_lut<24>(ix, qc_lds, lut, lane);
     __syncthreads();
 
-    const int my_j = lane / lpn, my_c = lane & (lpn - 1);
+    // A node's fused block = R neighbours x lpn 16-B code chunks.  One pass covers 64/lpn neighbours
+    // (lane = slot * lpn + chunk); blocks with R*lpn > 64 take npass <= lpn passes, and pass p's scores are
+    // moved to the lanes with chunk index p so that all R new keys sit on distinct lanes for ONE merge.
+    const int my_c = lane & (lpn - 1);
+    const int jpp = JV_WAVE / lpn;                       // neighbours per pass
+    const int npass = (R * lpn + JV_WAVE - 1) / JV_WAVE; // <= PQF_MAX_PASS, <= lpn (host checks)
+    const int my_slot = lane / lpn;
     const bool my_chunk = my_c * 16 < M;
     const bool full16 = (M & 15) == 0;
     auto adc_score = [&](const u32x4 cw, bool have) -> float {
@@ -1241,8 +1248,11 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
         __syncthreads();
     }
 
-    int pf_node = -1, pf_nn = -1;
-    u32x4 pf_cw = (u32x4){0, 0, 0, 0};
+    int pf_node = -1;
+    int pf_nn[PQF_MAX_PASS];
+    u32x4 pf_cw[PQF_MAX_PASS];
+#pragma unroll
+    for (int ps = 0; ps < PQF_MAX_PASS; ps++) pf_nn[ps] = -1, pf_cw[ps] = (u32x4){0, 0, 0, 0};
     STAMP_DECL
     STAMP(7)  // staging + LUT build + entry point
     while (true) {
@@ -1270,14 +1280,22 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
             break;
         }
         const int c = pool_node(pk);
-        int nn;
-        u32x4 cw = (u32x4){0, 0, 0, 0};
-        if (c == pf_node) {
-            nn = pf_nn;
-            cw = pf_cw;
-        } else {
-            nn = my_j < R ? ix.adj[(size_t)c * R + my_j] : -1;
-            if (my_j < R && my_chunk) cw = *(const u32x4*)(ix.pq_fused + ((size_t)c * R + my_j) * cs + my_c * 16);
+        int nnp[PQF_MAX_PASS];
+        u32x4 cwp[PQF_MAX_PASS];
+#pragma unroll
+        for (int ps = 0; ps < PQF_MAX_PASS; ps++) {
+            nnp[ps] = -1;
+            cwp[ps] = (u32x4){0, 0, 0, 0};
+            if (ps < npass) {
+                if (c == pf_node) {
+                    nnp[ps] = pf_nn[ps];
+                    cwp[ps] = pf_cw[ps];
+                } else {
+                    const int j = ps * jpp + my_slot;
+                    nnp[ps] = j < R ? ix.adj[(size_t)c * R + j] : -1;
+                    if (j < R && my_chunk) cwp[ps] = *(const u32x4*)(ix.pq_fused + ((size_t)c * R + j) * cs + my_c * 16);
+                }
+            }
         }
         const int c2 = idx2 >= 0 ? pool_node(pool[idx2]) : -1;
 #ifdef JV_STAMPS
@@ -1285,7 +1303,7 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
 #endif
         STAMP(0)  // masks -> idx, pool reads
 #ifdef JV_STAMPS
-        asm volatile("" ::"v"(nn), "v"(cw[0]), "v"(cw[3]));
+        asm volatile("" ::"v"(nnp[0]), "v"(cwp[0][0]), "v"(cwp[0][3]));
 #endif
         STAMP(1)  // wait for the block
         if (nexp >= log_cap) {
@@ -1300,15 +1318,33 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
 #pragma unroll
         for (int t = 0; t < PQF_MAX_CHUNKS; t++)
             if (t == (idx >> 6)) um[t] &= ~(1ull << (idx & 63));
-        // ADC of all R stored neighbours
-        const bool have = nn >= 0 && my_chunk;
-        const float score = adc_score(cw, have);
+        // ADC of all R stored neighbours; pass ps delivers its scores to the lanes whose chunk index is ps
+        float score = 0.0f;
+        int nn = -1;
+#pragma unroll
+        for (int ps = 0; ps < PQF_MAX_PASS; ps++) {
+            if (ps < npass) {
+                const float sp = adc_score(cwp[ps], nnp[ps] >= 0 && my_chunk);
+                const float sp_m = ps == 0 ? sp : __shfl(sp, lane - ps, JV_WAVE);
+                const int nn_m = ps == 0 ? nnp[0] : __shfl(nnp[ps], lane - ps, JV_WAVE);
+                if (my_c == ps) {
+                    score = sp_m;
+                    nn = nn_m;
+                }
+            }
+        }
         // the block is consumed: start the runner-up's fetch
         __builtin_amdgcn_sched_barrier(0);
         pf_node = c2;
         if (c2 >= 0) {
-            pf_nn = my_j < R ? ix.adj[(size_t)c2 * R + my_j] : -1;
-            if (my_j < R && my_chunk) pf_cw = *(const u32x4*)(ix.pq_fused + ((size_t)c2 * R + my_j) * cs + my_c * 16);
+#pragma unroll
+            for (int ps = 0; ps < PQF_MAX_PASS; ps++) {
+                if (ps < npass) {
+                    const int j = ps * jpp + my_slot;
+                    pf_nn[ps] = j < R ? ix.adj[(size_t)c2 * R + j] : -1;
+                    if (j < R && my_chunk) pf_cw[ps] = *(const u32x4*)(ix.pq_fused + ((size_t)c2 * R + j) * cs + my_c * 16);
+                }
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         expanded++;
@@ -1319,7 +1355,7 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
         // ---- merge the new keys (one per neighbour, on the lanes with my_c == 0) ----
         // All LDS reads below are unconditional (clamped index) and batched into registers first: a
         // conditional load would compile into an exec-masked branch with its own LDS round trip.
-        bool keep = nn >= 0 && my_c == 0;
+        bool keep = nn >= 0 && my_c < npass;
         if (np >= rk && score < bscore) keep = false;  // below the boundary for good
         const int64_t v = make_pool_key(score, nn);
         int rold;

@@ -217,7 +217,7 @@ def test_threshold_queries_parity(pkg, pyoracle, small_sets):
 
 
 @pytest.mark.parametrize("sim", [0, 1, 2])
-@pytest.mark.parametrize("M,R", [(32, 32), (16, 16), (32, 16), (64, 16), (24, 12)])
+@pytest.mark.parametrize("M,R", [(32, 32), (16, 16), (32, 16), (64, 16), (24, 12), (64, 32), (48, 32), (32, 64)])
 def test_fused_adc_layout_parity(pkg, pyoracle, small_sets, sim, M, R):
     """JV_DESC_FUSED_ADC (neighbours' PQ codes stored next to the adjacency row, one fetch per expansion,
     plus the runner-up prefetch) must not change a single bit: ids, scores, counters == oracle."""
