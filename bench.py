@@ -34,6 +34,9 @@ WORKLOADS = {
     # BASELINE.json configs[2] — the configuration the metric is quoted on
     "c3": dict(desc="10Mx768 L2 PQ-32 ADC + full-precision rerank (DiskANN two-pass)", n=10_000_000, d=768, sim=0,
                pq_M=32, normalize=False),
+    # BASELINE.json configs[3]: 100Mx1536 PQ-64 over 8 GPUs = 12.5M docs per GPU (always "weak": n per GPU fixed)
+    "c4": dict(desc="100Mx1536 PQ-64 DiskANN, doc-ID-range shards of 12.5M per GPU", n=12_500_000, d=1536, sim=0,
+               pq_M=64, normalize=False, per_gpu=True),
 }
 
 
@@ -195,7 +198,7 @@ def main():
     # N > 1: doc-ID-range shards.  Default = the north star's curve: the SAME corpus (10M docs) split over the
     # ranks ("strong": total work fixed; every rank searches every query on its n/N docs, rerankK is re-swept
     # so that the MERGED recall@10 stays >= 0.95).  JV_BENCH_SCALING=weak keeps n docs per GPU instead.
-    scaling = os.environ.get("JV_BENCH_SCALING", "strong" if world > 1 else "weak")
+    scaling = os.environ.get("JV_BENCH_SCALING", "strong" if (world > 1 and not wl.get("per_gpu")) else "weak")
     if world > 1 and scaling == "strong":
         lo_doc, hi_doc = sharding.shard_range(n_cfg, world, rank)
         n, row_offset, n_total = hi_doc - lo_doc, lo_doc, n_cfg
@@ -208,7 +211,8 @@ def main():
     nq_pool = args.batch * 2
     if pq_M:
         sigma = float(os.environ.get("JV_BENCH_SIGMA", "0.35"))
-        zc, Bl, Bg = make_block_generators(torch, d, device, centres, M=pq_M, per=2)
+        # 64 latent factors in total (2 per subspace at M = 32, 1 at M = 64): the same intrinsic dimension for C3 and C4
+        zc, Bl, Bg = make_block_generators(torch, d, device, centres, M=pq_M, per=max(1, 64 // pq_M))
         base = gen_rows_block(torch, n, d, 42, row_offset, zc, Bl, Bg, sigma, 0.1, 0.005, wl["normalize"], device)
         queries = gen_rows_block(torch, nq_pool, d, 43, 0, zc, Bl, Bg, sigma, 0.1, 0.005, wl["normalize"], device)
     else:

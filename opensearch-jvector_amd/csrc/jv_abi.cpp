@@ -322,7 +322,7 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
     bool pqf = false;
     if (!force_big && pq && g.pool && ix->dev.pq_fused && ix->dev.num_upper == 0 && ix->dev.R <= JV_WAVE && ix->dev.R * ix->dev.pq_lanes <= 4 * JV_WAVE &&
         (ix->dev.R * ix->dev.pq_lanes + JV_WAVE - 1) / JV_WAVE <= ix->dev.pq_lanes &&
-        rk + 128 <= 512 && opt_no_pqf.load() == 0) {
+        rk + 128 <= 1024 && opt_no_pqf.load() == 0) {
         JvSearchArgs ap = a;
         ap.cand_cap = (rk + 128 + 1) & ~1;          // pool entries
         ap.res_cap = (3 * rk + 64 + 3) & ~3;        // expansion log entries

@@ -1173,10 +1173,10 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
 // Bails out (JV_FLAG_OVERFLOW -> generic retry kernel) on: negative score vs threshold, > 64 boundary
 // ties, expansion log overflow, visited-count table overflow.
 // =============================================================================================
-#define PQF_MAX_CHUNKS 8  // pool capacity <= 512 entries
+// CH = pool capacity in 64-entry chunks (template parameter): 8 (rerankK <= 384) or 16 (rerankK <= 896)
 #define PQF_MAX_PASS 4    // fused block passes: R * lanes-per-node <= 256
 
-template <int NCHT>
+template <int NCHT, int CH>
 __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int qi, unsigned char* smem) {
     const int lane = threadIdx.x;
     const int rk = a.rk, topK = a.topK;
@@ -1234,9 +1234,9 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
     int np = 0, nexp = 0, expanded = 0;
     bool overflow = false;
     float bscore = 0.0f;  // score of pool[rk-1] once the pool holds rk entries (the boundary)
-    unsigned long long um[PQF_MAX_CHUNKS];
+    unsigned long long um[CH];
 #pragma unroll
-    for (int t = 0; t < PQF_MAX_CHUNKS; t++) um[t] = 0ull;
+    for (int t = 0; t < CH; t++) um[t] = 0ull;
     {
         const int ep = ix.entry;
         u32x4 cw = (u32x4){0, 0, 0, 0};
@@ -1259,7 +1259,7 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
         // best and runner-up unexpanded entries from the masks
         int idx = -1, idx2 = -1;
 #pragma unroll
-        for (int t = 0; t < PQF_MAX_CHUNKS; t++) {
+        for (int t = 0; t < CH; t++) {
             unsigned long long m = um[t];
             if (m && idx2 < 0) {
                 const int p0 = (t << 6) + __ffsll((long long)m) - 1;
@@ -1316,7 +1316,7 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
         }
         nexp++;
 #pragma unroll
-        for (int t = 0; t < PQF_MAX_CHUNKS; t++)
+        for (int t = 0; t < CH; t++)
             if (t == (idx >> 6)) um[t] &= ~(1ull << (idx & 63));
         // ADC of all R stored neighbours; pass ps delivers its scores to the lanes whose chunk index is ps
         float score = 0.0f;
@@ -1362,12 +1362,12 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
         {   // rold = #{pool entries > v} = first index whose entry is <= v.  Uniform 3-level 8-ary search over
             // the (<= 512-entry) pool: block sizes 64, 8, 1.
             const int last = cap - 1;
-            int64_t p1[7], p2[7], p3[9];
+            int64_t p1[CH - 1], p2[7], p3[9];
 #pragma unroll
-            for (int k2 = 0; k2 < 7; k2++) p1[k2] = pool[min(k2 * 64 + 63, last)];
+            for (int k2 = 0; k2 < CH - 1; k2++) p1[k2] = pool[min(k2 * 64 + 63, last)];
             int c1 = 0;
 #pragma unroll
-            for (int k2 = 0; k2 < 7; k2++) c1 += ((k2 * 64 + 63 < np) & (p1[k2] > v)) ? 1 : 0;
+            for (int k2 = 0; k2 < CH - 1; k2++) c1 += ((k2 * 64 + 63 < np) & (p1[k2] > v)) ? 1 : 0;
             int lo = c1 * 64;
 #pragma unroll
             for (int k2 = 0; k2 < 7; k2++) p2[k2] = pool[min(lo + k2 * 8 + 7, last)];
@@ -1394,9 +1394,9 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
         if (nk > 0) {
             // rank among the kept new keys, the first insertion point, and per-chunk shift counts
             int rnew = 0;
-            int cnt[PQF_MAX_CHUNKS];
+            int cnt[CH];
 #pragma unroll
-            for (int t = 0; t < PQF_MAX_CHUNKS; t++) cnt[t] = 0;
+            for (int t = 0; t < CH; t++) cnt[t] = 0;
             const int vlo = (int)(uint32_t)(v & 0xFFFFFFFFll), vhi = (int)(v >> 32);
             for (unsigned long long m = km; m;) {
                 const int j = __ffsll((long long)m) - 1;
@@ -1406,16 +1406,16 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
                 const int rj = __builtin_amdgcn_readlane(rold, j);
                 rnew += kj > v ? 1 : 0;
 #pragma unroll
-                for (int t = 0; t < PQF_MAX_CHUNKS; t++) cnt[t] += ((t << 6) + lane >= rj) ? 1 : 0;  // key j precedes entry
+                for (int t = 0; t < CH; t++) cnt[t] += ((t << 6) + lane >= rj) ? 1 : 0;  // key j precedes entry
             }
             const unsigned long long firstm = __ballot(keep && rnew == 0);
             const int r_min = __builtin_amdgcn_readlane(rold, __ffsll((long long)firstm) - 1);
             // read every old entry first, then write the shifted ones: in place, no ordering hazard
-            int64_t ov[PQF_MAX_CHUNKS];
+            int64_t ov[CH];
 #pragma unroll
-            for (int t = 0; t < PQF_MAX_CHUNKS; t++) ov[t] = pool[min((t << 6) + lane, cap - 1)];
+            for (int t = 0; t < CH; t++) ov[t] = pool[min((t << 6) + lane, cap - 1)];
 #pragma unroll
-            for (int t = 0; t < PQF_MAX_CHUNKS; t++) {
+            for (int t = 0; t < CH; t++) {
                 const int i = (t << 6) + lane;
                 if (i < np && cnt[t] > 0) pool[i + cnt[t]] = ov[t];
             }
@@ -1425,14 +1425,14 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
             // trim to the boundary (+ ties) and rebuild the unexpanded masks, one batched read of the pool
             const int ntot = np + nk;
 #pragma unroll
-            for (int t = 0; t < PQF_MAX_CHUNKS; t++) ov[t] = pool[min((t << 6) + lane, cap - 1)];
+            for (int t = 0; t < CH; t++) ov[t] = pool[min((t << 6) + lane, cap - 1)];
             int nnew = ntot;
             if (ntot > rk) {
                 const int64_t bk = pool[rk - 1];
                 bscore = key_score(bk);
                 int ties = 0;  // entries beyond rk-1 that tie with the boundary score stay (they are contiguous)
 #pragma unroll
-                for (int t = 0; t < PQF_MAX_CHUNKS; t++) {
+                for (int t = 0; t < CH; t++) {
                     const int i = (t << 6) + lane;
                     ties += __popcll(__ballot(i >= rk && i < ntot && key_score(ov[t]) == bscore));
                 }
@@ -1446,7 +1446,7 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
                 break;
             }
 #pragma unroll
-            for (int t = 0; t < PQF_MAX_CHUNKS; t++) {
+            for (int t = 0; t < CH; t++) {
                 const int i = (t << 6) + lane;
                 um[t] = __ballot(i < np && (ov[t] & 1ll));
             }
@@ -1591,12 +1591,12 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
     }
 }
 
-template <int NCHT>
+template <int NCHT, int CH>
 __global__ __launch_bounds__(JV_WAVE) void jv_search_pqf_kernel(const JvIndexDev ix, const JvSearchArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int qi = blockIdx.x;
     if (qi >= a.nq) return;
-    search_one_pqf<NCHT>(ix, a, qi, smem);
+    search_one_pqf<NCHT, CH>(ix, a, qi, smem);
 }
 
 // Fast path: one query per workgroup, all scratch in LDS.
@@ -1771,8 +1771,9 @@ static const lds_kernel_t g_retry_kernels[2][2][4] = {
     {JV_ROW(jv_search_retry_kernel, true, false), JV_ROW(jv_search_retry_kernel, true, true)}};
 static const lds_kernel_t g_build_kernels[2][4] = {JV_ROW(jv_build_search_kernel, false),
                                                    JV_ROW(jv_build_search_kernel, true)};
-static const lds_kernel_t g_pqf_kernels[4] = {jv_search_pqf_kernel<0>, jv_search_pqf_kernel<2>, jv_search_pqf_kernel<12>,
-                                              jv_search_pqf_kernel<24>};
+static const lds_kernel_t g_pqf_kernels[2][4] = {
+    {jv_search_pqf_kernel<0, 8>, jv_search_pqf_kernel<2, 8>, jv_search_pqf_kernel<12, 8>, jv_search_pqf_kernel<24, 8>},
+    {jv_search_pqf_kernel<0, 16>, jv_search_pqf_kernel<2, 16>, jv_search_pqf_kernel<12, 16>, jv_search_pqf_kernel<24, 16>}};
 static const big_kernel_t g_big_kernels[2][4] = {JV_ROW(jv_search_big_kernel, false), JV_ROW(jv_search_big_kernel, true)};
 
 static int nch_slot(const JvIndexDev* ix) {
@@ -1793,7 +1794,9 @@ extern "C" hipError_t jvk_set_max_lds(int bytes) {
             }
             hipError_t e = hipFuncSetAttribute((const void*)g_build_kernels[a][s], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             if (e == hipSuccess && a == 0)
-                e = hipFuncSetAttribute((const void*)g_pqf_kernels[s], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+                e = hipFuncSetAttribute((const void*)g_pqf_kernels[0][s], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            if (e == hipSuccess && a == 0)
+                e = hipFuncSetAttribute((const void*)g_pqf_kernels[1][s], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             if (e == hipSuccess)
                 e = hipFuncSetAttribute((const void*)g_big_kernels[a][s], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             if (e != hipSuccess) return e;
@@ -1804,7 +1807,7 @@ extern "C" hipError_t jvk_set_max_lds(int bytes) {
 
 extern "C" hipError_t jvk_launch_search_pqf(const JvIndexDev* ix, const JvSearchArgs* a, int lds_bytes, hipStream_t stream) {
     if (a->nq <= 0) return hipSuccess;
-    g_pqf_kernels[nch_slot(ix)]<<<a->nq, JV_WAVE, lds_bytes, stream>>>(*ix, *a);
+    g_pqf_kernels[a->cand_cap > 512 ? 1 : 0][nch_slot(ix)]<<<a->nq, JV_WAVE, lds_bytes, stream>>>(*ix, *a);
     return hipGetLastError();
 }
 

@@ -124,3 +124,27 @@ def test_empty_index_and_k_zero(pkg, host):
     r = gpu.search_batch(np.ones((2, 8), np.float32), 0, 0)
     assert r.count.tolist() == [0, 0]
     gpu.close()
+
+
+def test_baseline_config_c1_10k_128_l2_k10(pkg, host, pyoracle):
+    """BASELINE.json configs[0]: 10k random float32 vectors, d=128, L2, k=10 through the query/reader surface
+    (JVectorKnnFloatVectorQuery defaults: over-query 5) — GPU engine vs oracle vs brute force."""
+    n, d, k = 10_000, 128, 10
+    base = pkg.datagen.java_random_vectors(42, n, d)          # the JMH generator (Random(42) uniform [0,1))
+    queries = pkg.datagen.java_random_vectors(43, 50, d)
+    ix = pkg.builder.build_index_cpu(base, 0, R=32, L=100)
+    reader = host.JVectorReader(ix, "EUCLIDEAN")
+    orc = pyoracle.Oracle(pkg.binding, ix)
+    want = orc.search_batch(queries, k, k * 5)
+    truth, _ = orc.brute_force(queries, k)
+    found = []
+    for i in range(len(queries)):
+        docs, scores, total, used_exact = reader.search_leaf(queries[i], k, 5)
+        assert total == k and not used_exact
+        assert docs == want.docs[i].tolist()
+        assert np.array_equal(np.asarray(scores, np.float32).view(np.uint32), want.scores[i].view(np.uint32))
+        found.append(docs)
+    # i.i.d. uniform 128-d is the reference's JMH input; it asserts no recall on it (graph quality is the
+    # builder's, not the search path's) — sanity floor only
+    assert recall_at_k(np.asarray(found), truth) >= 0.6
+    reader.close()

@@ -227,7 +227,7 @@ def test_fused_adc_layout_parity(pkg, pyoracle, small_sets, sim, M, R):
     gpu = b.GpuIndex(ix, flags=b.DESC_FUSED_ADC)
     assert gpu.info().fused_adc == 1
     orc = pyoracle.Oracle(b, ix)
-    for (k, rk) in [(10, 50), (10, 10), (5, 120), (1, 1), (100, 384)]:
+    for (k, rk) in [(10, 50), (10, 10), (5, 120), (1, 1), (100, 384), (100, 600)]:
         want = orc.search_batch(q, k, rk)
         _assert_same(gpu.search_batch(q, k, rk), want, f"fused sim={sim} M={M} R={R} k={k} rk={rk}")
         try:
