@@ -34,6 +34,12 @@ WORKLOADS = {
     # BASELINE.json configs[2] — the configuration the metric is quoted on
     "c3": dict(desc="10Mx768 L2 PQ-32 ADC + full-precision rerank (DiskANN two-pass)", n=10_000_000, d=768, sim=0,
                pq_M=32, normalize=False),
+    # BASELINE.json configs[4]: 256 concurrent queries on the C3 index.  Run on the fp32 parity path: at B = 256 the
+    # only dense contraction (the LUT build, 2*B*256*d = 0.1 GFLOP) is ~0.02 % of a step and the rerank has no
+    # candidates shared between queries, so a bf16 MFMA path would change scores without changing throughput
+    # (DESIGN.md section 8).
+    "c5": dict(desc="batch=256 concurrent queries on the C3 index (10Mx768 PQ-32 fused + rerank), fp32 parity path",
+               n=10_000_000, d=768, sim=0, pq_M=32, normalize=False, batch=256),
     # BASELINE.json configs[3]: 100Mx1536 PQ-64 over 8 GPUs = 12.5M docs per GPU (always "weak": n per GPU fixed)
     "c4": dict(desc="100Mx1536 PQ-64 DiskANN, doc-ID-range shards of 12.5M per GPU", n=12_500_000, d=1536, sim=0,
                pq_M=64, normalize=False, per_gpu=True),
@@ -192,6 +198,8 @@ def main():
             log(f"option {key[len('JV_OPT_'):].lower()} = {val}")
 
     wl = dict(WORKLOADS[args.workload])
+    if "batch" in wl and "JV_BENCH_BATCH" not in os.environ and "--batch" not in sys.argv:
+        args.batch = wl["batch"]
     n_cfg = args.n if args.n > 0 else wl["n"]
     d, sim, pq_M = wl["d"], wl["sim"], wl["pq_M"]
     R, L, k = 32, 100, 10
@@ -208,7 +216,7 @@ def main():
     # ---- data in HBM ----
     t0 = time.time()
     centres = max(64, min(4096, n_total // 256))
-    nq_pool = args.batch * 2
+    nq_pool = max(args.batch * 2, 4096)
     if pq_M:
         sigma = float(os.environ.get("JV_BENCH_SIGMA", "0.35"))
         # 64 latent factors in total (2 per subspace at M = 32, 1 at M = 64): the same intrinsic dimension for C3 and C4
@@ -254,17 +262,19 @@ def main():
     # ---- search plumbing: everything device-resident, own stream ----
     stream = torch.cuda.Stream(device=device)
     B = args.batch
-    out_nodes = torch.empty((B, k), dtype=torch.int32, device=device)
-    out_docs = torch.empty((B, k), dtype=torch.int32, device=device)
-    out_scores = torch.empty((B, k), dtype=torch.float32, device=device)
-    out_count = torch.empty((B,), dtype=torch.int32, device=device)
-    out_stats = torch.empty((B, 4), dtype=torch.int32, device=device)
-    out_flags = torch.empty((B,), dtype=torch.int32, device=device)
+    n_gt = 1024  # queries with exact ground truth (recall is quoted on these)
+    OB = max(B, n_gt)  # output rows: a timed step uses the first B, the recall sweep the first n_gt
+    out_nodes = torch.empty((OB, k), dtype=torch.int32, device=device)
+    out_docs = torch.empty((OB, k), dtype=torch.int32, device=device)
+    out_scores = torch.empty((OB, k), dtype=torch.float32, device=device)
+    out_count = torch.empty((OB,), dtype=torch.int32, device=device)
+    out_stats = torch.empty((OB, 4), dtype=torch.int32, device=device)
+    out_flags = torch.empty((OB,), dtype=torch.int32, device=device)
     if world > 1:
         gather_docs = torch.empty((world, B, k), dtype=torch.int32, device=device)
         gather_scores = torch.empty((world, B, k), dtype=torch.float32, device=device)
-        merged_docs = torch.empty((B, k), dtype=torch.int32, device=device)
-        merged_scores = torch.empty((B, k), dtype=torch.float32, device=device)
+        merged_docs = torch.empty((OB, k), dtype=torch.int32, device=device)
+        merged_scores = torch.empty((OB, k), dtype=torch.float32, device=device)
 
     def gpu_merge(gd, gs, kk):
         nqm = gd.shape[0]
@@ -283,7 +293,6 @@ def main():
             return sharding.sharded_search(dist, torch, local_search, gpu_merge, qbatch, k, world)
 
     # ---- ground truth + rerankK selection (recall@10 >= 0.95) ----
-    n_gt = 1024  # queries with exact ground truth (recall is quoted on these)
     gt_local = brute_force_topk(torch, base, queries[:n_gt], k, sim, row_offset)
     if world > 1:
         # global ground truth = merge of per-shard exact top-k
@@ -352,10 +361,10 @@ def main():
         evs[s][1].record(stream)
         if world > 1:
             with torch.cuda.stream(stream):
-                gd, gs = sharding.gather_topk(dist, torch, out_docs, out_scores, world, gather_docs, gather_scores)
+                gd, gs = sharding.gather_topk(dist, torch, out_docs[:B], out_scores[:B], world, gather_docs, gather_scores)
                 gpu_merge(gd, gs, k)
         with torch.cuda.stream(stream):
-            stat_sums += out_stats.to(torch.int64).sum(0)  # per-query counters -> algorithmic bytes
+            stat_sums += out_stats[:B].to(torch.int64).sum(0)  # per-query counters -> algorithmic bytes
     barrier()
     elapsed = time.perf_counter() - t_start
     if world > 1:
@@ -366,7 +375,7 @@ def main():
     qps = total_queries / elapsed
     kernel_ms = [a.elapsed_time(b) for a, b in evs]
     kernel_avg_ms = float(np.mean(kernel_ms))
-    overflowed = int((out_flags.cpu().numpy().astype(np.uint32) & np.uint32(1)).sum())
+    overflowed = int((out_flags[:B].cpu().numpy().astype(np.uint32) & np.uint32(1)).sum())
 
     # ---- algorithmic bytes; counters are the reference's own (J/JVectorReader.java:183-187) ----
     st = stat_sums.cpu().numpy().astype(np.float64)

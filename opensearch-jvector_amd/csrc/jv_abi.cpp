@@ -64,9 +64,9 @@ std::atomic<int64_t> opt_force_general{0};
 std::atomic<int64_t> opt_no_escalation{0};
 std::atomic<int64_t> opt_dbg_ptr{0};
 std::atomic<int64_t> opt_no_pqf{0};
-std::atomic<int64_t> opt_spill_tables{2048};  // per context: 2048 x 8192 x 4 B = 64 MB
+std::atomic<int64_t> opt_spill_tables{2048};  // per context: 2048 x 8192 x 4 B = 64 MB (a launch that needs more falls to the ladder)
 std::atomic<int64_t> opt_spill_slots{8192};
-std::atomic<int64_t> opt_big_blocks{256};
+std::atomic<int64_t> opt_big_blocks{64};
 std::atomic<int64_t> opt_big_cand_cap{65536};
 
 int next_pow2(int v) {
