@@ -92,6 +92,13 @@ struct Ctx {
     size_t nq_cap = 0;
     uint64_t* d_accept = nullptr;
     size_t accept_cap = 0;  // words
+    // host-pointer API: one device arena [nodes|docs|scores|count|stats|flags] + one pinned mirror, so a call
+    // is one H2D (query) and ONE D2H instead of six staged pageable copies
+    uint8_t* d_arena = nullptr;
+    uint8_t* h_arena = nullptr;  // hipHostMalloc
+    size_t arena_cap = 0;
+    float* h_query = nullptr;    // pinned staging for small query batches
+    size_t h_query_cap = 0;
     // big-path HBM scratch
     uint32_t* big_visited = nullptr;
     int64_t* big_cand = nullptr;
@@ -166,6 +173,9 @@ void ctx_destroy(Ctx* c) {
     hipFree(c->d_stats);
     hipFree(c->d_flags);
     hipFree(c->d_accept);
+    hipFree(c->d_arena);
+    if (c->h_arena) hipHostFree(c->h_arena);
+    if (c->h_query) hipHostFree(c->h_query);
     hipFree(c->big_visited);
     hipFree(c->big_cand);
     hipFree(c->work_counter);
@@ -698,27 +708,27 @@ int jv_search_batch(jv_index* index, const float* queries, int32_t nq, int32_t t
     } rel{index, c};
     const int d = index->dev.d;
     if ((rc = grow((void**)&c->d_queries, &c->queries_cap, (size_t)nq * d, sizeof(float))) != JV_OK) return rc;
-    if (outn > c->out_cap || !c->d_nodes) {
-        size_t cap = 0;
-        hipFree(c->d_nodes); c->d_nodes = nullptr;
-        hipFree(c->d_docs); c->d_docs = nullptr;
-        hipFree(c->d_scores); c->d_scores = nullptr;
-        size_t c1 = 0, c2 = 0;
-        if ((rc = grow((void**)&c->d_nodes, &cap, outn, 4)) != JV_OK) return rc;
-        if ((rc = grow((void**)&c->d_docs, &c1, cap, 4)) != JV_OK) return rc;
-        if ((rc = grow((void**)&c->d_scores, &c2, cap, 4)) != JV_OK) return rc;
-        c->out_cap = cap;
+    // arena layout (4-byte units)
+    const size_t o_nodes = 0, o_docs = outn, o_scores = 2 * outn, o_count = 3 * outn, o_stats = o_count + (size_t)nq,
+                 o_flags = o_stats + 4 * (size_t)nq, total4 = o_flags + (size_t)nq;
+    if (total4 * 4 > c->arena_cap) {
+        hipFree(c->d_arena);
+        c->d_arena = nullptr;
+        if (c->h_arena) hipHostFree(c->h_arena);
+        c->h_arena = nullptr;
+        c->arena_cap = 0;
+        const size_t cap = total4 * 4 + total4;  // 25 % head room
+        HIPCHK(hipMalloc((void**)&c->d_arena, cap));
+        HIPCHK(hipHostMalloc((void**)&c->h_arena, cap, hipHostMallocDefault));
+        c->arena_cap = cap;
     }
-    if ((size_t)nq > c->nq_cap || !c->d_count) {
-        hipFree(c->d_count); c->d_count = nullptr;
-        hipFree(c->d_stats); c->d_stats = nullptr;
-        hipFree(c->d_flags); c->d_flags = nullptr;
-        size_t cap = 0, c1 = 0, c2 = 0;
-        if ((rc = grow((void**)&c->d_count, &cap, (size_t)nq, 4)) != JV_OK) return rc;
-        if ((rc = grow((void**)&c->d_stats, &c1, cap * 4, 4)) != JV_OK) return rc;
-        if ((rc = grow((void**)&c->d_flags, &c2, cap, 4)) != JV_OK) return rc;
-        c->nq_cap = cap;
-    }
+    int32_t* const a32 = (int32_t*)c->d_arena;
+    int32_t* const dn = a32 + o_nodes;
+    int32_t* const dd = a32 + o_docs;
+    float* const dsc = (float*)(a32 + o_scores);
+    int32_t* const dc = a32 + o_count;
+    int32_t* const dst = a32 + o_stats;
+    int32_t* const dfl = a32 + o_flags;
     const uint64_t* d_accept = nullptr;
     if (accept_doc_words) {
         if (accept_num_docs < 0) return fail(JV_EINVAL, "accept_num_docs < 0");
@@ -727,18 +737,31 @@ int jv_search_batch(jv_index* index, const float* queries, int32_t nq, int32_t t
         HIPCHK(hipMemcpyAsync(c->d_accept, accept_doc_words, words * 8, hipMemcpyHostToDevice, c->stream));
         d_accept = c->d_accept;
     }
-    HIPCHK(hipMemcpyAsync(c->d_queries, queries, (size_t)nq * d * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    const size_t qbytes = (size_t)nq * d * sizeof(float);
+    if (qbytes <= (1u << 20)) {  // small batches: stage through pinned memory (a pageable H2D is a blocking staged copy)
+        if (qbytes > c->h_query_cap) {
+            if (c->h_query) hipHostFree(c->h_query);
+            c->h_query = nullptr;
+            HIPCHK(hipHostMalloc((void**)&c->h_query, qbytes < 65536 ? 65536 : qbytes, hipHostMallocDefault));
+            c->h_query_cap = qbytes < 65536 ? 65536 : qbytes;
+        }
+        memcpy(c->h_query, queries, qbytes);
+        HIPCHK(hipMemcpyAsync(c->d_queries, c->h_query, qbytes, hipMemcpyHostToDevice, c->stream));
+    } else {
+        HIPCHK(hipMemcpyAsync(c->d_queries, queries, qbytes, hipMemcpyHostToDevice, c->stream));
+    }
     rc = enqueue_batch(index, c, c->stream, c->d_queries, nq, topK, rerankK, threshold, rerankFloor, d_accept,
-                       accept_num_docs, c->d_nodes, c->d_docs, c->d_scores, c->d_count, c->d_stats, c->d_flags);
+                       accept_num_docs, dn, dd, dsc, dc, dst, dfl);
     if (rc != JV_OK) return rc;
-    std::vector<int32_t> flags((size_t)nq);
-    if (out_nodes) HIPCHK(hipMemcpyAsync(out_nodes, c->d_nodes, outn * 4, hipMemcpyDeviceToHost, c->stream));
-    if (out_docs) HIPCHK(hipMemcpyAsync(out_docs, c->d_docs, outn * 4, hipMemcpyDeviceToHost, c->stream));
-    if (out_scores) HIPCHK(hipMemcpyAsync(out_scores, c->d_scores, outn * 4, hipMemcpyDeviceToHost, c->stream));
-    if (out_count) HIPCHK(hipMemcpyAsync(out_count, c->d_count, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
-    if (out_stats) HIPCHK(hipMemcpyAsync(out_stats, c->d_stats, (size_t)nq * 16, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(flags.data(), c->d_flags, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_arena, c->d_arena, total4 * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    const int32_t* h32 = (const int32_t*)c->h_arena;
+    if (out_nodes) memcpy(out_nodes, h32 + o_nodes, outn * 4);
+    if (out_docs) memcpy(out_docs, h32 + o_docs, outn * 4);
+    if (out_scores) memcpy(out_scores, h32 + o_scores, outn * 4);
+    if (out_count) memcpy(out_count, h32 + o_count, (size_t)nq * 4);
+    if (out_stats) memcpy(out_stats, h32 + o_stats, (size_t)nq * 16);
+    const int32_t* flags = h32 + o_flags;
     for (int i = 0; i < nq; i++) {
         if ((uint32_t)flags[i] & (JV_FLAG_FAILED | JV_FLAG_OVERFLOW))
             return fail(JV_ENOMEM, "query %d overflowed the HBM scratch (big_cand_cap=%d); raise option big_cand_cap", i,

@@ -1174,9 +1174,9 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
 // ties, expansion log overflow, visited-count table overflow.
 // =============================================================================================
 // CH = pool capacity in 64-entry chunks (template parameter): 8 (rerankK <= 384) or 16 (rerankK <= 896)
-#define PQF_MAX_PASS 4    // fused block passes: R * lanes-per-node <= 256
+// NP = compile-time bound on fused-block passes: 1 (R * lanes-per-node <= 64, the common case) or 4
 
-template <int NCHT, int CH>
+template <int NCHT, int CH, int NP>
 __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int qi, unsigned char* smem) {
     const int lane = threadIdx.x;
     const int rk = a.rk, topK = a.topK;
@@ -1214,7 +1214,7 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
     // moved to the lanes with chunk index p so that all R new keys sit on distinct lanes for ONE merge.
     const int my_c = lane & (lpn - 1);
     const int jpp = JV_WAVE / lpn;                       // neighbours per pass
-    const int npass = (R * lpn + JV_WAVE - 1) / JV_WAVE; // <= PQF_MAX_PASS, <= lpn (host checks)
+    const int npass = NP == 1 ? 1 : (R * lpn + JV_WAVE - 1) / JV_WAVE; // <= NP, <= lpn (host checks)
     const int my_slot = lane / lpn;
     const bool my_chunk = my_c * 16 < M;
     const bool full16 = (M & 15) == 0;
@@ -1249,10 +1249,10 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
     }
 
     int pf_node = -1;
-    int pf_nn[PQF_MAX_PASS];
-    u32x4 pf_cw[PQF_MAX_PASS];
+    int pf_nn[NP];
+    u32x4 pf_cw[NP];
 #pragma unroll
-    for (int ps = 0; ps < PQF_MAX_PASS; ps++) pf_nn[ps] = -1, pf_cw[ps] = (u32x4){0, 0, 0, 0};
+    for (int ps = 0; ps < NP; ps++) pf_nn[ps] = -1, pf_cw[ps] = (u32x4){0, 0, 0, 0};
     STAMP_DECL
     STAMP(7)  // staging + LUT build + entry point
     while (true) {
@@ -1280,10 +1280,10 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
             break;
         }
         const int c = pool_node(pk);
-        int nnp[PQF_MAX_PASS];
-        u32x4 cwp[PQF_MAX_PASS];
+        int nnp[NP];
+        u32x4 cwp[NP];
 #pragma unroll
-        for (int ps = 0; ps < PQF_MAX_PASS; ps++) {
+        for (int ps = 0; ps < NP; ps++) {
             nnp[ps] = -1;
             cwp[ps] = (u32x4){0, 0, 0, 0};
             if (ps < npass) {
@@ -1322,7 +1322,7 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
         float score = 0.0f;
         int nn = -1;
 #pragma unroll
-        for (int ps = 0; ps < PQF_MAX_PASS; ps++) {
+        for (int ps = 0; ps < NP; ps++) {
             if (ps < npass) {
                 const float sp = adc_score(cwp[ps], nnp[ps] >= 0 && my_chunk);
                 const float sp_m = ps == 0 ? sp : __shfl(sp, lane - ps, JV_WAVE);
@@ -1338,7 +1338,7 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
         pf_node = c2;
         if (c2 >= 0) {
 #pragma unroll
-            for (int ps = 0; ps < PQF_MAX_PASS; ps++) {
+            for (int ps = 0; ps < NP; ps++) {
                 if (ps < npass) {
                     const int j = ps * jpp + my_slot;
                     pf_nn[ps] = j < R ? ix.adj[(size_t)c2 * R + j] : -1;
@@ -1591,12 +1591,12 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
     }
 }
 
-template <int NCHT, int CH>
+template <int NCHT, int CH, int NP>
 __global__ __launch_bounds__(JV_WAVE) void jv_search_pqf_kernel(const JvIndexDev ix, const JvSearchArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int qi = blockIdx.x;
     if (qi >= a.nq) return;
-    search_one_pqf<NCHT, CH>(ix, a, qi, smem);
+    search_one_pqf<NCHT, CH, NP>(ix, a, qi, smem);
 }
 
 // Fast path: one query per workgroup, all scratch in LDS.
@@ -1771,9 +1771,10 @@ static const lds_kernel_t g_retry_kernels[2][2][4] = {
     {JV_ROW(jv_search_retry_kernel, true, false), JV_ROW(jv_search_retry_kernel, true, true)}};
 static const lds_kernel_t g_build_kernels[2][4] = {JV_ROW(jv_build_search_kernel, false),
                                                    JV_ROW(jv_build_search_kernel, true)};
-static const lds_kernel_t g_pqf_kernels[2][4] = {
-    {jv_search_pqf_kernel<0, 8>, jv_search_pqf_kernel<2, 8>, jv_search_pqf_kernel<12, 8>, jv_search_pqf_kernel<24, 8>},
-    {jv_search_pqf_kernel<0, 16>, jv_search_pqf_kernel<2, 16>, jv_search_pqf_kernel<12, 16>, jv_search_pqf_kernel<24, 16>}};
+#define JV_PQF_ROW(CH, NP) \
+    { jv_search_pqf_kernel<0, CH, NP>, jv_search_pqf_kernel<2, CH, NP>, jv_search_pqf_kernel<12, CH, NP>, jv_search_pqf_kernel<24, CH, NP> }
+// [multi-pass][large pool][nch slot]
+static const lds_kernel_t g_pqf_kernels[2][2][4] = {{JV_PQF_ROW(8, 1), JV_PQF_ROW(16, 1)}, {JV_PQF_ROW(8, 4), JV_PQF_ROW(16, 4)}};
 static const big_kernel_t g_big_kernels[2][4] = {JV_ROW(jv_search_big_kernel, false), JV_ROW(jv_search_big_kernel, true)};
 
 static int nch_slot(const JvIndexDev* ix) {
@@ -1794,9 +1795,8 @@ extern "C" hipError_t jvk_set_max_lds(int bytes) {
             }
             hipError_t e = hipFuncSetAttribute((const void*)g_build_kernels[a][s], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             if (e == hipSuccess && a == 0)
-                e = hipFuncSetAttribute((const void*)g_pqf_kernels[0][s], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            if (e == hipSuccess && a == 0)
-                e = hipFuncSetAttribute((const void*)g_pqf_kernels[1][s], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+                for (int v = 0; v < 4 && e == hipSuccess; v++)
+                    e = hipFuncSetAttribute((const void*)g_pqf_kernels[v >> 1][v & 1][s], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             if (e == hipSuccess)
                 e = hipFuncSetAttribute((const void*)g_big_kernels[a][s], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             if (e != hipSuccess) return e;
@@ -1807,7 +1807,8 @@ extern "C" hipError_t jvk_set_max_lds(int bytes) {
 
 extern "C" hipError_t jvk_launch_search_pqf(const JvIndexDev* ix, const JvSearchArgs* a, int lds_bytes, hipStream_t stream) {
     if (a->nq <= 0) return hipSuccess;
-    g_pqf_kernels[a->cand_cap > 512 ? 1 : 0][nch_slot(ix)]<<<a->nq, JV_WAVE, lds_bytes, stream>>>(*ix, *a);
+    const int multi = ix->R * ix->pq_lanes > JV_WAVE ? 1 : 0;
+    g_pqf_kernels[multi][a->cand_cap > 512 ? 1 : 0][nch_slot(ix)]<<<a->nq, JV_WAVE, lds_bytes, stream>>>(*ix, *a);
     return hipGetLastError();
 }
 
