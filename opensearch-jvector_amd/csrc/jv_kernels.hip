@@ -1234,6 +1234,11 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
     int np = 0, nexp = 0, expanded = 0;
     bool overflow = false;
     float bscore = 0.0f;  // score of pool[rk-1] once the pool holds rk entries (the boundary)
+    // level-1 pivots of the rank search (pool[63], pool[127], ...): wave-uniform, refreshed from the registers
+    // of the batched pool read after every merge instead of being re-read from LDS in every expansion
+    int64_t piv[CH - 1];
+#pragma unroll
+    for (int t = 0; t < CH - 1; t++) piv[t] = KEY_MIN;
     unsigned long long um[CH];
 #pragma unroll
     for (int t = 0; t < CH; t++) um[t] = 0ull;
@@ -1362,12 +1367,10 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
         {   // rold = #{pool entries > v} = first index whose entry is <= v.  Uniform 3-level 8-ary search over
             // the (<= 512-entry) pool: block sizes 64, 8, 1.
             const int last = cap - 1;
-            int64_t p1[CH - 1], p2[7], p3[9];
-#pragma unroll
-            for (int k2 = 0; k2 < CH - 1; k2++) p1[k2] = pool[min(k2 * 64 + 63, last)];
+            int64_t p2[7], p3[9];
             int c1 = 0;
 #pragma unroll
-            for (int k2 = 0; k2 < CH - 1; k2++) c1 += ((k2 * 64 + 63 < np) & (p1[k2] > v)) ? 1 : 0;
+            for (int k2 = 0; k2 < CH - 1; k2++) c1 += ((k2 * 64 + 63 < np) & (piv[k2] > v)) ? 1 : 0;
             int lo = c1 * 64;
 #pragma unroll
             for (int k2 = 0; k2 < 7; k2++) p2[k2] = pool[min(lo + k2 * 8 + 7, last)];
@@ -1449,6 +1452,11 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
             for (int t = 0; t < CH; t++) {
                 const int i = (t << 6) + lane;
                 um[t] = __ballot(i < np && (ov[t] & 1ll));
+                if (t < CH - 1) {  // pool[64t + 63] sits in lane 63 of ov[t]
+                    const int plo = __builtin_amdgcn_readlane((int)(uint32_t)(ov[t] & 0xFFFFFFFFll), 63);
+                    const int phi = __builtin_amdgcn_readlane((int)(ov[t] >> 32), 63);
+                    piv[t] = (int64_t)(((uint64_t)(uint32_t)phi << 32) | (uint64_t)(uint32_t)plo);
+                }
             }
             (void)r_min;
             STAMP(5)  // trim + mask rebuild
