@@ -64,6 +64,7 @@ std::atomic<int64_t> opt_force_general{0};
 std::atomic<int64_t> opt_no_escalation{0};
 std::atomic<int64_t> opt_dbg_ptr{0};
 std::atomic<int64_t> opt_no_pqf{0};
+std::atomic<int64_t> opt_pqf_only{0};  // diagnostics: skip the ladder after the PQF launch (flags stay visible)
 std::atomic<int64_t> opt_spill_tables{2048};  // per context: 2048 x 8192 x 4 B = 64 MB (a launch that needs more falls to the ladder)
 std::atomic<int64_t> opt_spill_slots{8192};
 std::atomic<int64_t> opt_big_blocks{64};
@@ -82,13 +83,7 @@ struct Ctx {
     // device staging for the host-pointer API
     float* d_queries = nullptr;
     size_t queries_cap = 0;  // floats
-    int32_t* d_nodes = nullptr;
-    int32_t* d_docs = nullptr;
-    float* d_scores = nullptr;
-    size_t out_cap = 0;  // nq*topK entries
-    int32_t* d_count = nullptr;
-    int32_t* d_stats = nullptr;
-    int32_t* d_flags = nullptr;
+    int32_t* d_flags = nullptr;  // flag words for device-pointer calls that pass no out_flags
     size_t nq_cap = 0;
     uint64_t* d_accept = nullptr;
     size_t accept_cap = 0;  // words
@@ -166,11 +161,6 @@ int ctx_create(jv_index* ix, Ctx** out) {
 void ctx_destroy(Ctx* c) {
     if (!c) return;
     hipFree(c->d_queries);
-    hipFree(c->d_nodes);
-    hipFree(c->d_docs);
-    hipFree(c->d_scores);
-    hipFree(c->d_count);
-    hipFree(c->d_stats);
     hipFree(c->d_flags);
     hipFree(c->d_accept);
     hipFree(c->d_arena);
@@ -346,14 +336,11 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
             pqf = true;
         }
     }
+    if (pqf && opt_pqf_only.load() != 0) return JV_OK;
     if (!force_big) {
-        if (pqf) {
-            JvSearchArgs ar = a;
-            ar.retry_only = 1;
-            ar.retry_counter = c->work_counter + 3;
-            HIPCHK(jvk_launch_search_lds(&ix->dev, &ar, 1, g.pool ? 1 : 0, 1, g.lds_fast, stream));
-        } else
-        HIPCHK(jvk_launch_search_lds(&ix->dev, &a, pq ? 1 : 0, g.pool ? 1 : 0, ix->build_client ? 2 : 0, g.lds_fast, stream));
+        if (!pqf)
+            HIPCHK(jvk_launch_search_lds(&ix->dev, &a, pq ? 1 : 0, g.pool ? 1 : 0, ix->build_client ? 2 : 0, g.lds_fast, stream));
+        // (after a PQF launch the flagged queries go straight to the rung below: generic kernel, 4x visited table)
         // escalation: queries that overflowed the on-chip visited set are retried with a 4x larger table
         // (fewer resident queries, but only the flagged few run) before the HBM-scratch path
         if (opt_lds_visited_slots.load() <= 0 && opt_no_escalation.load() == 0) {
@@ -401,6 +388,7 @@ int jv_set_option(const char* name, int64_t value) {
     else if (n == "no_escalation") opt_no_escalation = value;
     else if (n == "dbg_ptr") opt_dbg_ptr = value;
     else if (n == "no_pqf") opt_no_pqf = value;
+    else if (n == "pqf_only") opt_pqf_only = value;
     else if (n == "spill_tables") opt_spill_tables = value;
     else if (n == "spill_slots") opt_spill_slots = value;
     else if (n == "big_blocks") opt_big_blocks = value;

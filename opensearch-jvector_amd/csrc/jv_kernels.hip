@@ -1233,6 +1233,7 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
     // ---- entry point ----
     int np = 0, nexp = 0, expanded = 0;
     bool overflow = false;
+    int why = 0;  // bail-out reason, reported in bits 8..11 of the flag word (diagnostics)
     float bscore = 0.0f;  // score of pool[rk-1] once the pool holds rk entries (the boundary)
     // level-1 pivots of the rank search (pool[63], pool[127], ...): wave-uniform, refreshed from the registers
     // of the batched pool read after every merge instead of being re-read from LDS in every expansion
@@ -1282,6 +1283,7 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
         const float sc = key_score(pk);
         if (sc < a.threshold) {
             overflow = true;
+            why = 1;
             break;
         }
         const int c = pool_node(pk);
@@ -1313,6 +1315,7 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
         STAMP(1)  // wait for the block
         if (nexp >= log_cap) {
             overflow = true;
+            why = 2;
             break;
         }
         if (lane == 0) {
@@ -1446,6 +1449,7 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
             np = nnew;
             if (np > pool_limit) {
                 overflow = true;
+                why = 3;
                 break;
             }
 #pragma unroll
@@ -1493,7 +1497,7 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
                 }
 #pragma unroll
                 for (int u = 0; u < VB; u++) {
-                    if (visited + JV_WAVE > vlimit) overflow = true;
+                    if (visited + JV_WAVE > vlimit) overflow = true, why = 4;
                     bool is_new = false;
                     if (!overflow && nb[u] >= 0) is_new = visited_insert_lds(vh, vmask, vshift, (uint32_t)nb[u]);
                     visited += __popcll(__ballot(is_new));
@@ -1519,7 +1523,7 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
     STAMP_FLUSH
     if (overflow) {
         if (lane == 0) {
-            a.out_flags[qi] = (int32_t)JV_FLAG_OVERFLOW;
+            a.out_flags[qi] = (int32_t)(JV_FLAG_OVERFLOW | ((uint32_t)why << 8));
             a.out_count[qi] = 0;
         }
         for (int i = lane; i < topK; i += JV_WAVE) {
@@ -1660,14 +1664,21 @@ __global__ __launch_bounds__(JV_WAVE) void jv_search_big_kernel(const JvIndexDev
     const int words = (ix.n + 31) >> 5;
     int64_t* my_cand = a.big_cand + (size_t)blockIdx.x * a.big_cand_cap;
     uint32_t* my_bits = a.big_visited + (size_t)blockIdx.x * words;
-    for (;;) {
-        int next = 0;
-        if (threadIdx.x == 0) next = atomicAdd(a.work_counter, 1);
-        const int qi = __shfl(next, 0, JV_WAVE);
-        if (qi >= a.nq) break;
-        if (!force_all && !((uint32_t)a.out_flags[qi] & JV_FLAG_OVERFLOW)) continue;
-        search_one<PQ, true, false, NCHT>(ix, a, qi, smem, my_cand, my_bits);
-        __syncthreads();
+    const int lane = threadIdx.x;
+    for (;;) {  // dequeue 64 queries at a time, one flag per lane
+        int base = 0;
+        if (lane == 0) base = atomicAdd(a.work_counter, JV_WAVE);
+        base = __shfl(base, 0, JV_WAVE);
+        if (base >= a.nq) break;
+        const int qi = base + lane;
+        const bool todo_q = qi < a.nq && (force_all || ((uint32_t)a.out_flags[qi] & JV_FLAG_OVERFLOW));
+        unsigned long long m = __ballot(todo_q);
+        while (m) {
+            const int j = __ffsll((long long)m) - 1;
+            m &= m - 1ull;
+            search_one<PQ, true, false, NCHT>(ix, a, base + j, smem, my_cand, my_bits);
+            __syncthreads();
+        }
     }
 }
 

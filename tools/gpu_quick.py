@@ -1,6 +1,6 @@
 """Ad-hoc GPU check + timing used during development (not a pytest file)."""
 import importlib, sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # repo root
 import numpy as np
 import __graft_entry__ as g
 g.load_package()

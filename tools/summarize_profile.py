@@ -39,7 +39,10 @@ def main(src, name):
     lines += ["", f"`{main_kernel}` is launched only by the {warm} warm-up + {steps} timed steps in --profile-mode "
                   "(index construction uses `jv_build_search_kernel`, escalation passes `jv_search_retry_kernel`), so its "
                   f"average ({main_avg:.4f} ms) is directly comparable with bench.py's `roofline.kernel_avg_ms` "
-                  f"({bench['roofline']['kernel_avg_ms']} ms, HIP events around launch + escalation + big-path launches).", ""]
+                  f"({bench['roofline']['kernel_avg_ms']} ms, HIP events around launch + escalation + big-path launches; rocprofv3 "
+                  "attributes the main kernel's last ~2 ms — its slowest queries draining — to the dispatch that follows it, "
+                  "which is why the no-op retry launch shows ~2 ms here while HIP events put the whole ladder at 0.04 ms, "
+                  "tools/pqf_bailouts.py).", ""]
     traffic = {}
     for cname in ("FETCH_SIZE", "WRITE_SIZE"):
         p = os.path.join(src, f"pmc_{cname}.csv")
