@@ -1262,20 +1262,26 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
     STAMP_DECL
     STAMP(7)  // staging + LUT build + entry point
     while (true) {
-        // best and runner-up unexpanded entries from the masks
+        // best and runner-up unexpanded entries from the masks (first two set bits over the CH words)
         int idx = -1, idx2 = -1;
+        {
+            unsigned int nz = 0;  // bit t set <=> um[t] != 0
 #pragma unroll
-        for (int t = 0; t < CH; t++) {
-            unsigned long long m = um[t];
-            if (m && idx2 < 0) {
-                const int p0 = (t << 6) + __ffsll((long long)m) - 1;
-                if (idx < 0) {
-                    idx = p0;
-                    m &= m - 1ull;
-                    if (m) idx2 = (t << 6) + __ffsll((long long)m) - 1;
-                } else {
-                    idx2 = p0;
+            for (int t = 0; t < CH; t++) nz |= um[t] ? (1u << t) : 0u;
+            if (nz) {
+                const int t1 = __ffs((int)nz) - 1;
+                unsigned long long m1 = 0ull, m2 = 0ull;
+                const unsigned int nz2 = nz & (nz - 1u);
+                const int t2 = nz2 ? __ffs((int)nz2) - 1 : -1;
+#pragma unroll
+                for (int t = 0; t < CH; t++) {
+                    if (t == t1) m1 = um[t];
+                    if (t == t2) m2 = um[t];
                 }
+                idx = (t1 << 6) + __ffsll((long long)m1) - 1;
+                const unsigned long long r1 = m1 & (m1 - 1ull);
+                if (r1) idx2 = (t1 << 6) + __ffsll((long long)r1) - 1;
+                else if (t2 >= 0) idx2 = (t2 << 6) + __ffsll((long long)m2) - 1;
             }
         }
         if (idx < 0) break;
