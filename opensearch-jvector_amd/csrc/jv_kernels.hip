@@ -961,6 +961,25 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
                 st.overflow = true;
                 break;
             }
+            // jvector admits a popped candidate into a FULL result queue only if it is strictly better than the
+            // worst result; the pool's key order would instead rank it ahead of an equal-score, higher-ordinal
+            // node that was expanded earlier.  That tie (an expanded entry with the same score behind the
+            // candidate, possible once rerankK nodes have been expanded) is left to the literal two-queue form.
+            if (st.expanded >= rk) {
+                bool tie_bail = false;
+                for (int j = idx + 1; j < np; j++) {
+                    const int64_t kj = cur[j];
+                    if (key_score(kj) != sc) break;
+                    if (!(kj & 1ll)) {
+                        tie_bail = true;
+                        break;
+                    }
+                }
+                if (tie_bail) {
+                    st.overflow = true;
+                    break;
+                }
+            }
             const int c = pool_node(pk);
             const int deg = ix.R;
             const int32_t* row = ix.adj + (size_t)c * ix.R;
@@ -1292,6 +1311,24 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
             why = 1;
             break;
         }
+        // strict-admission tie (see the generic pool loop): an expanded entry with the same score behind the
+        // candidate once the result queue can be full -> the literal two-queue form decides
+        if (expanded >= rk) {
+            bool tie_bail = false;
+            for (int j = idx + 1; j < np; j++) {
+                const int64_t kj = pool[j];
+                if (key_score(kj) != sc) break;
+                if (!(kj & 1ll)) {
+                    tie_bail = true;
+                    break;
+                }
+            }
+            if (tie_bail) {
+                overflow = true;
+                why = 5;
+                break;
+            }
+        }
         const int c = pool_node(pk);
         int nnp[NP];
         u32x4 cwp[NP];
@@ -1400,25 +1437,35 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
             rold = lo + c3;
             if (dup) keep = false;
         }
-        const unsigned long long km = __ballot(keep);
-        const int nk = __popcll(km);
+        unsigned long long km = __ballot(keep);
+        int nk = __popcll(km);
         STAMP(3)  // boundary check + 3-level rank search + duplicate check
         if (nk > 0) {
             // rank among the kept new keys, the first insertion point, and per-chunk shift counts
             int rnew = 0;
             int cnt[CH];
-#pragma unroll
-            for (int t = 0; t < CH; t++) cnt[t] = 0;
             const int vlo = (int)(uint32_t)(v & 0xFFFFFFFFll), vhi = (int)(v >> 32);
-            for (unsigned long long m = km; m;) {
-                const int j = __ffsll((long long)m) - 1;
-                m &= m - 1ull;
-                const int64_t kj = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(vhi, j) << 32) |
-                                             (uint64_t)(uint32_t)__builtin_amdgcn_readlane(vlo, j));
-                const int rj = __builtin_amdgcn_readlane(rold, j);
-                rnew += kj > v ? 1 : 0;
+            for (int attempt = 0; attempt < 2; attempt++) {
+                rnew = 0;
 #pragma unroll
-                for (int t = 0; t < CH; t++) cnt[t] += ((t << 6) + lane >= rj) ? 1 : 0;  // key j precedes entry
+                for (int t = 0; t < CH; t++) cnt[t] = 0;
+                bool twin = false;  // the same neighbour twice in one adjacency row (malformed graph): keep one
+                for (unsigned long long m = km; m;) {
+                    const int j = __ffsll((long long)m) - 1;
+                    m &= m - 1ull;
+                    const int64_t kj = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(vhi, j) << 32) |
+                                                 (uint64_t)(uint32_t)__builtin_amdgcn_readlane(vlo, j));
+                    const int rj = __builtin_amdgcn_readlane(rold, j);
+                    rnew += kj > v ? 1 : 0;
+                    twin |= kj == v && j < lane;
+#pragma unroll
+                    for (int t = 0; t < CH; t++) cnt[t] += ((t << 6) + lane >= rj) ? 1 : 0;  // key j precedes entry
+                }
+                const unsigned long long km2 = __ballot(keep && !twin);
+                if (km2 == km) break;
+                keep = keep && !twin;
+                km = km2;
+                nk = __popcll(km);
             }
             const unsigned long long firstm = __ballot(keep && rnew == 0);
             const int r_min = __builtin_amdgcn_readlane(rold, __ffsll((long long)firstm) - 1);

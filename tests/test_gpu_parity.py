@@ -305,3 +305,32 @@ def test_device_pointer_api_and_merge_kernel(pkg, pyoracle, small_sets):
     assert np.array_equal(od.cpu().numpy(), wd)
     assert np.array_equal(os_.cpu().numpy(), ws)
     gpu.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_malformed_random_graphs_parity(pkg, pyoracle, seed):
+    """Robustness: random adjacency with holes (-1 in the middle of a row), self loops, the same neighbour
+    twice in one row, unreachable nodes and duplicated vectors.  jvector never writes such rows, but the engine
+    must still do exactly what the oracle's visited-set semantics say (and never corrupt its queues)."""
+    b, bl = pkg.binding, pkg.builder
+    rng = np.random.default_rng(seed)
+    n, d, R = 600, 32, 16
+    uniq = rng.random((n // 2, d)).astype(np.float32)
+    base = np.concatenate([uniq, uniq[rng.integers(0, n // 2, n - n // 2)]])   # many exact duplicates
+    adj = rng.integers(0, n, size=(n, R)).astype(np.int32)                      # random, with repeats
+    adj[rng.random((n, R)) < 0.15] = -1                                         # holes anywhere
+    for i in range(0, n, 7):
+        adj[i, rng.integers(0, R)] = i                                          # self loops
+        adj[i, 1] = adj[i, 0]                                                   # duplicate neighbour in a row
+    q = rng.random((24, d)).astype(np.float32)
+    for sim in (0, 1):
+        ix = b.IndexData(vectors=base, adj=adj, entry_node=int(rng.integers(0, n)), similarity=sim)
+        cb, cen, codes, K = bl.pq_train_encode_cpu(base, 16, sim)
+        ixq = b.IndexData(vectors=base, adj=adj, entry_node=ix.entry_node, similarity=sim, pq_codebooks=cb, pq_centroid=cen,
+                          pq_codes=codes, pq_M=16, pq_K=K)
+        for data, flags, name in ((ix, 0, "exact"), (ixq, 0, "pq"), (ixq, b.DESC_FUSED_ADC, "pq-fused")):
+            gpu = b.GpuIndex(data, flags=flags)
+            orc = pyoracle.Oracle(b, data)
+            for k, rk in ((5, 20), (10, 64), (3, 3)):
+                _assert_same(gpu.search_batch(q, k, rk), orc.search_batch(q, k, rk), f"{name} sim={sim} seed={seed} k={k} rk={rk}")
+            gpu.close()

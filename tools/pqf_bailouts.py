@@ -28,7 +28,7 @@ b.set_option("pqf_only", 0)
 fl = o[5].cpu().numpy().astype(np.uint32)
 ov = (fl & 0x80000000) != 0
 why = (fl >> 8) & 0xF
-print("flagged", int(ov.sum()), "of", B, {int(w): int(((why == w) & ov).sum()) for w in range(1, 5)}, "(1 thr, 2 log, 3 ties, 4 visited-count)")
+print("flagged", int(ov.sum()), "of", B, {int(w): int(((why == w) & ov).sum()) for w in range(1, 6)}, "(1 thr, 2 log, 3 tie slack, 4 visited-count, 5 strict-admission tie)")
 st = o[4].cpu().numpy()
 print("expanded: mean %.1f p99 %.0f max %d; visited: mean %.1f p99 %.0f max %d" % (st[~ov, 2].mean(), np.percentile(st[~ov, 2], 99), st[~ov, 2].max(), st[~ov, 0].mean(), np.percentile(st[~ov, 0], 99), st[~ov, 0].max()))
 
