@@ -962,19 +962,19 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
                 break;
             }
             // jvector admits a popped candidate into a FULL result queue only if it is strictly better than the
-            // worst result; the pool's key order would instead rank it ahead of an equal-score, higher-ordinal
-            // node that was expanded earlier.  That tie (an expanded entry with the same score behind the
-            // candidate, possible once rerankK nodes have been expanded) is left to the literal two-queue form.
-            if (st.expanded >= rk) {
-                bool tie_bail = false;
-                for (int j = idx + 1; j < np; j++) {
+            // worst result; the pool's key order would instead rank it ahead of equal-score, higher-ordinal nodes
+            // that were expanded earlier.  The two disagree exactly when the candidate sits inside the top rerankK
+            // and the expanded entries scoring >= it (all idx entries ahead + the equal-score expanded ones behind)
+            // already fill the result queue, i.e. the worst result's score equals the candidate's.  That tie is
+            // left to the literal two-queue form.
+            if (st.expanded >= rk && idx < rk) {
+                int ge = idx;
+                for (int j = idx + 1; j < np && ge < rk; j++) {
                     const int64_t kj = cur[j];
                     if (key_score(kj) != sc) break;
-                    if (!(kj & 1ll)) {
-                        tie_bail = true;
-                        break;
-                    }
+                    ge += (kj & 1ll) ? 0 : 1;
                 }
+                const bool tie_bail = ge >= rk;
                 if (tie_bail) {
                     st.overflow = true;
                     break;
@@ -1311,18 +1311,16 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
             why = 1;
             break;
         }
-        // strict-admission tie (see the generic pool loop): an expanded entry with the same score behind the
-        // candidate once the result queue can be full -> the literal two-queue form decides
-        if (expanded >= rk) {
-            bool tie_bail = false;
-            for (int j = idx + 1; j < np; j++) {
+        // strict-admission tie (see the generic pool loop): the expanded entries scoring >= the candidate already
+        // fill the result queue and the candidate ranks inside the top rerankK -> the two-queue form decides
+        if (expanded >= rk && idx < rk) {
+            int ge = idx;
+            for (int j = idx + 1; j < np && ge < rk; j++) {
                 const int64_t kj = pool[j];
                 if (key_score(kj) != sc) break;
-                if (!(kj & 1ll)) {
-                    tie_bail = true;
-                    break;
-                }
+                ge += (kj & 1ll) ? 0 : 1;
             }
+            const bool tie_bail = ge >= rk;
             if (tie_bail) {
                 overflow = true;
                 why = 5;

@@ -334,3 +334,27 @@ def test_malformed_random_graphs_parity(pkg, pyoracle, seed):
             for k, rk in ((5, 20), (10, 64), (3, 3)):
                 _assert_same(gpu.search_batch(q, k, rk), orc.search_batch(q, k, rk), f"{name} sim={sim} seed={seed} k={k} rk={rk}")
             gpu.close()
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14])
+def test_score_tie_storm_parity(pkg, pyoracle, seed):
+    """Vectors on a tiny integer grid (3^4 distinct points for 500 nodes) over a dense random graph: almost every
+    comparison in the search is a score tie, at every rank including the rerankK boundary.  Exercises jvector's
+    strict admission into a full result queue (GraphSearcher.addTopCandidate) against the pool forms' key order."""
+    b, bl = pkg.binding, pkg.builder
+    rng = np.random.default_rng(seed)
+    n, d, R = 500, 4, 16
+    base = rng.integers(0, 3, size=(n, d)).astype(np.float32)
+    adj = np.stack([rng.permutation(n)[:R] for _ in range(n)]).astype(np.int32)
+    q = rng.integers(0, 3, size=(64, d)).astype(np.float32) + np.float32(0.5) * (rng.random((64, d)) < 0.3)
+    for sim in (0, 1):
+        ix = b.IndexData(vectors=base, adj=adj, entry_node=int(rng.integers(0, n)), similarity=sim)
+        cb, cen, codes, K = bl.pq_train_encode_cpu(base, 2, sim)
+        ixq = b.IndexData(vectors=base, adj=adj, entry_node=ix.entry_node, similarity=sim, pq_codebooks=cb, pq_centroid=cen,
+                          pq_codes=codes, pq_M=2, pq_K=K)
+        for data, flags, name in ((ix, 0, "exact"), (ixq, 0, "pq"), (ixq, b.DESC_FUSED_ADC, "pq-fused")):
+            gpu = b.GpuIndex(data, flags=flags)
+            orc = pyoracle.Oracle(b, data)
+            for k, rk in ((1, 1), (2, 2), (3, 4), (5, 8), (10, 16), (10, 40), (20, 100)):
+                _assert_same(gpu.search_batch(q, k, rk), orc.search_batch(q, k, rk), f"{name} sim={sim} seed={seed} k={k} rk={rk}")
+            gpu.close()
