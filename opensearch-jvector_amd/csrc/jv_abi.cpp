@@ -12,9 +12,12 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <mutex>
 #include <string>
 #include <vector>
+
+#include <semaphore.h>
 
 #include "../../include/jvgpu.h"
 #include "jv_device.h"
@@ -69,6 +72,10 @@ std::atomic<int64_t> opt_spill_tables{2048};  // per context: 2048 x 8192 x 4 B 
 std::atomic<int64_t> opt_spill_slots{8192};
 std::atomic<int64_t> opt_big_blocks{64};
 std::atomic<int64_t> opt_big_cand_cap{65536};
+// jv_search (one query per call, many caller threads): concurrent calls are combined into batch launches
+std::atomic<int64_t> opt_combine{1};
+std::atomic<int64_t> opt_combine_leaders{2};     // batches in flight at once
+std::atomic<int64_t> opt_combine_max_batch{2048};
 
 int next_pow2(int v) {
     int p = 1;
@@ -105,9 +112,36 @@ struct Ctx {
     size_t big_words = 0;
 };
 
+// One caller's jv_search waiting to be served.  Lives on the caller's stack.
+struct PendingSearch {
+    const float* query;
+    int32_t topK, rerankK;
+    float threshold, rerankFloor;
+    int32_t* out_nodes;
+    int32_t* out_docs;
+    float* out_scores;
+    int32_t* out_count;
+    int32_t* out_stats;
+    int rc = 0;
+    char err[256];
+    enum { QUEUED, TAKEN } state = QUEUED;
+    bool promoted = false;
+    sem_t sem;  // posted once per promotion and once when another thread has served the request
+};
+
+// Group commit for the one-query-per-call API: a caller that finds a free leader slot takes every queued
+// request with the same parameters (its own included), runs them as ONE batch launch and hands the answers
+// back; callers arriving meanwhile queue up and form the next batch.
+struct Combiner {
+    std::mutex mu;
+    std::deque<PendingSearch*> queue;
+    int active = 0;  // leaders running or promoted
+};
+
 }  // namespace
 
 struct jv_index {
+    Combiner combiner;
     int device = 0;
     bool build_client = false;  // JV_DESC_BUILD_CLIENT: searches are launched under the builder's kernel name
     JvIndexDev dev{};
@@ -322,9 +356,9 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
     bool pqf = false;
     if (!force_big && pq && g.pool && ix->dev.pq_fused && ix->dev.num_upper == 0 && ix->dev.R <= JV_WAVE && ix->dev.R * ix->dev.pq_lanes <= 4 * JV_WAVE &&
         (ix->dev.R * ix->dev.pq_lanes + JV_WAVE - 1) / JV_WAVE <= ix->dev.pq_lanes &&
-        rk + 128 <= 1024 && opt_no_pqf.load() == 0) {
+        rk + 64 + ix->dev.R <= 1024 && opt_no_pqf.load() == 0) {
         JvSearchArgs ap = a;
-        ap.cand_cap = (rk + 128 + 1) & ~1;          // pool entries
+        ap.cand_cap = (rk + 64 + ix->dev.R + 1) & ~1;  // pool entries: rk + 64 boundary ties + one merge of <= R new keys
         ap.res_cap = (3 * rk + 64 + 3) & ~3;        // expansion log entries
         const int lut_b = ix->dev.pq_M * 256 * 4;
         int loop_b = lut_b + ap.cand_cap * 8 + ap.res_cap * 4;
@@ -393,6 +427,9 @@ int jv_set_option(const char* name, int64_t value) {
     else if (n == "spill_slots") opt_spill_slots = value;
     else if (n == "big_blocks") opt_big_blocks = value;
     else if (n == "big_cand_cap") opt_big_cand_cap = value;
+    else if (n == "combine") opt_combine = value;
+    else if (n == "combine_leaders") opt_combine_leaders = value;
+    else if (n == "combine_max_batch") opt_combine_max_batch = value;
     else return fail(JV_EINVAL, "unknown option '%s'", name);
     return JV_OK;
 }
@@ -758,11 +795,125 @@ int jv_search_batch(jv_index* index, const float* queries, int32_t nq, int32_t t
     return JV_OK;
 }
 
+namespace {
+
+// hand the leader slot to a queued request that has no leader yet, or give it up (combiner.mu held)
+void pass_leadership(Combiner& cb) {
+    for (PendingSearch* r : cb.queue) {
+        if (!r->promoted) {
+            r->promoted = true;
+            sem_post(&r->sem);
+            return;
+        }
+    }
+    cb.active--;
+}
+
+}  // namespace
+
 int jv_search(jv_index* index, const float* query, int32_t topK, int32_t rerankK, float threshold,
               float rerankFloor, const uint64_t* accept_doc_words, int64_t accept_num_docs, int32_t* out_nodes,
               int32_t* out_docs, float* out_scores, int32_t* out_count, int32_t* out_stats) {
-    return jv_search_batch(index, query, 1, topK, rerankK, threshold, rerankFloor, accept_doc_words, accept_num_docs,
-                           out_nodes, out_docs, out_scores, out_count, out_stats);
+    int rc = check_common(index, query, 1, topK, rerankK, threshold);
+    if (rc != JV_OK) return rc;
+    // per-query filters and degenerate calls are not combined
+    if (accept_doc_words || opt_combine.load() == 0 || topK == 0 || index->dev.n == 0 || index->dev.entry < 0)
+        return jv_search_batch(index, query, 1, topK, rerankK, threshold, rerankFloor, accept_doc_words, accept_num_docs,
+                               out_nodes, out_docs, out_scores, out_count, out_stats);
+    Combiner& cb = index->combiner;
+    PendingSearch me;
+    me.query = query;
+    me.topK = topK;
+    me.rerankK = rerankK;
+    me.threshold = threshold;
+    me.rerankFloor = rerankFloor;
+    me.out_nodes = out_nodes;
+    me.out_docs = out_docs;
+    me.out_scores = out_scores;
+    me.out_count = out_count;
+    me.out_stats = out_stats;
+    me.err[0] = 0;
+    sem_init(&me.sem, 0, 0);
+    auto finish = [&](int code) {
+        sem_destroy(&me.sem);
+        if (code != JV_OK) g_last_error = me.err;
+        return code;
+    };
+    std::unique_lock<std::mutex> lk(cb.mu);
+    cb.queue.push_back(&me);
+    int leaders = (int)opt_combine_leaders.load();
+    if (leaders < 1) leaders = 1;
+    if (cb.active < leaders) {
+        cb.active++;
+        me.promoted = true;
+    } else {
+        lk.unlock();
+        sem_wait(&me.sem);  // promotion, or the answer
+        lk.lock();
+        if (!me.promoted) return finish(me.rc);
+    }
+    // ---- leader (lock held) ----
+    if (me.state != PendingSearch::QUEUED) {
+        // another leader took this request before the promotion was acted on: give the slot away and wait for it
+        pass_leadership(cb);
+        lk.unlock();
+        sem_wait(&me.sem);
+        return finish(me.rc);
+    }
+    static thread_local std::vector<PendingSearch*> batch;
+    static thread_local std::vector<float> qbuf, sbuf;
+    static thread_local std::vector<int32_t> nbuf, dbuf, cbuf, stbuf;
+    batch.clear();
+    size_t max_batch = (size_t)std::max<int64_t>(1, opt_combine_max_batch.load());
+    for (auto it = cb.queue.begin(); it != cb.queue.end();) {
+        PendingSearch* r = *it;
+        const bool same = r == &me || (batch.size() + 1 < max_batch && r->state == PendingSearch::QUEUED && r->topK == topK &&
+                                       r->rerankK == rerankK && r->threshold == threshold && r->rerankFloor == rerankFloor);
+        if (same) {
+            r->state = PendingSearch::TAKEN;
+            batch.push_back(r);
+            it = cb.queue.erase(it);
+        } else {
+            ++it;
+        }
+    }
+    lk.unlock();
+    const size_t nb = batch.size(), d = (size_t)index->dev.d;
+    if (nb == 1) {
+        rc = jv_search_batch(index, query, 1, topK, rerankK, threshold, rerankFloor, nullptr, 0, out_nodes, out_docs,
+                             out_scores, out_count, out_stats);
+        if (rc != JV_OK) snprintf(me.err, sizeof(me.err), "%s", g_last_error.c_str());
+    } else {
+        qbuf.resize(nb * d);
+        nbuf.resize(nb * topK);
+        dbuf.resize(nb * topK);
+        sbuf.resize(nb * topK);
+        cbuf.resize(nb);
+        stbuf.resize(nb * 4);
+        for (size_t i = 0; i < nb; i++) memcpy(qbuf.data() + i * d, batch[i]->query, d * sizeof(float));
+        rc = jv_search_batch(index, qbuf.data(), (int32_t)nb, topK, rerankK, threshold, rerankFloor, nullptr, 0, nbuf.data(),
+                             dbuf.data(), sbuf.data(), cbuf.data(), stbuf.data());
+        for (size_t i = 0; i < nb; i++) {
+            PendingSearch* r = batch[i];
+            if (rc == JV_OK) {
+                if (r->out_nodes) memcpy(r->out_nodes, nbuf.data() + i * topK, sizeof(int32_t) * topK);
+                if (r->out_docs) memcpy(r->out_docs, dbuf.data() + i * topK, sizeof(int32_t) * topK);
+                if (r->out_scores) memcpy(r->out_scores, sbuf.data() + i * topK, sizeof(float) * topK);
+                if (r->out_count) *r->out_count = cbuf[i];
+                if (r->out_stats) memcpy(r->out_stats, stbuf.data() + i * 4, sizeof(int32_t) * 4);
+            } else {
+                snprintf(r->err, sizeof(r->err), "%s", g_last_error.c_str());
+            }
+            if (r != &me) {
+                r->rc = rc;
+                sem_post(&r->sem);  // r's frame may be gone as soon as this returns: r is not touched afterwards
+            }
+        }
+    }
+    lk.lock();
+    pass_leadership(cb);
+    lk.unlock();
+    return finish(rc);
 }
 
 int jv_score_ordinals(jv_index* index, const float* query, const int32_t* ordinals, int32_t count, float* out_scores) {

@@ -1192,7 +1192,7 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
 // Bails out (JV_FLAG_OVERFLOW -> generic retry kernel) on: negative score vs threshold, > 64 boundary
 // ties, expansion log overflow, visited-count table overflow.
 // =============================================================================================
-// CH = pool capacity in 64-entry chunks (template parameter): 8 (rerankK <= 384) or 16 (rerankK <= 896)
+// CH = pool capacity in 64-entry chunks (template parameter): 4, 8 or 16 (rerankK + 64 + R <= 64 * CH)
 // NP = compile-time bound on fused-block passes: 1 (R * lanes-per-node <= 64, the common case) or 4
 
 template <int NCHT, int CH, int NP>
@@ -1204,12 +1204,12 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
     float* lut = (float*)smem;                                   // [M][256]; later: visited-count hash, then rerank scratch
     size_t off = (size_t)M * 256 * sizeof(float);
     int64_t* pool = (int64_t*)(smem + off);                      // [cap]
-    const int cap = a.cand_cap;                                  // rk + 128
+    const int cap = a.cand_cap;                                  // rk + 64 boundary ties + R new keys, <= 64 * CH
     off += (size_t)cap * sizeof(int64_t);
     int32_t* explog = (int32_t*)(smem + off);                    // [a.res_cap] expanded nodes, in order
     const int log_cap = a.res_cap;
     float* qc_lds = (float*)pool;                                // LUT build only: aliases pool + log (host guarantees room)
-    const int pool_limit = cap - JV_WAVE;
+    const int pool_limit = cap - ix.R;                           // one merge adds at most R keys
 
     // ---- centred query -> LUT ----
     const float* qg = a.queries + (size_t)qi * ix.d;
@@ -1844,7 +1844,8 @@ static const lds_kernel_t g_build_kernels[2][4] = {JV_ROW(jv_build_search_kernel
 #define JV_PQF_ROW(CH, NP) \
     { jv_search_pqf_kernel<0, CH, NP>, jv_search_pqf_kernel<2, CH, NP>, jv_search_pqf_kernel<12, CH, NP>, jv_search_pqf_kernel<24, CH, NP> }
 // [multi-pass][large pool][nch slot]
-static const lds_kernel_t g_pqf_kernels[2][2][4] = {{JV_PQF_ROW(8, 1), JV_PQF_ROW(16, 1)}, {JV_PQF_ROW(8, 4), JV_PQF_ROW(16, 4)}};
+static const lds_kernel_t g_pqf_kernels[2][3][4] = {{JV_PQF_ROW(4, 1), JV_PQF_ROW(8, 1), JV_PQF_ROW(16, 1)},
+                                                    {JV_PQF_ROW(4, 4), JV_PQF_ROW(8, 4), JV_PQF_ROW(16, 4)}};
 static const big_kernel_t g_big_kernels[2][4] = {JV_ROW(jv_search_big_kernel, false), JV_ROW(jv_search_big_kernel, true)};
 
 static int nch_slot(const JvIndexDev* ix) {
@@ -1865,8 +1866,8 @@ extern "C" hipError_t jvk_set_max_lds(int bytes) {
             }
             hipError_t e = hipFuncSetAttribute((const void*)g_build_kernels[a][s], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             if (e == hipSuccess && a == 0)
-                for (int v = 0; v < 4 && e == hipSuccess; v++)
-                    e = hipFuncSetAttribute((const void*)g_pqf_kernels[v >> 1][v & 1][s], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+                for (int v = 0; v < 6 && e == hipSuccess; v++)
+                    e = hipFuncSetAttribute((const void*)g_pqf_kernels[v / 3][v % 3][s], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             if (e == hipSuccess)
                 e = hipFuncSetAttribute((const void*)g_big_kernels[a][s], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             if (e != hipSuccess) return e;
@@ -1878,7 +1879,7 @@ extern "C" hipError_t jvk_set_max_lds(int bytes) {
 extern "C" hipError_t jvk_launch_search_pqf(const JvIndexDev* ix, const JvSearchArgs* a, int lds_bytes, hipStream_t stream) {
     if (a->nq <= 0) return hipSuccess;
     const int multi = ix->R * ix->pq_lanes > JV_WAVE ? 1 : 0;
-    g_pqf_kernels[multi][a->cand_cap > 512 ? 1 : 0][nch_slot(ix)]<<<a->nq, JV_WAVE, lds_bytes, stream>>>(*ix, *a);
+    g_pqf_kernels[multi][a->cand_cap > 512 ? 2 : a->cand_cap > 256 ? 1 : 0][nch_slot(ix)]<<<a->nq, JV_WAVE, lds_bytes, stream>>>(*ix, *a);
     return hipGetLastError();
 }
 

@@ -45,6 +45,7 @@ def load_library(path: str = LIB_PATH):
         lib.jvh_docmap_roundtrip.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp]
         lib.jvh_similarity_ord_to_dist_func.argtypes = [i32, vp]
         lib.jvh_similarity_dist_func_to_ord.argtypes = [i32]
+        lib.jvh_concurrent_search_bench.argtypes = [vp, vp, i32, i32, i32, i32, i32, C.c_double, vp, vp]
         _lib = lib
     return _lib
 
@@ -142,3 +143,17 @@ class JVectorReader:
 
     def search_bytes(self):
         _check(self.lib, self.lib.jvh_reader_search_bytes(self.handle))
+
+
+def concurrent_search_bench(index: "binding.GpuIndex", queries: np.ndarray, topK: int, rerankK: int, threads: int,
+                            seconds: float, check_nodes: np.ndarray | None = None) -> dict:
+    """`threads` native threads each issuing one jv_search at a time on the same handle — the reference's calling
+    pattern (T/index/engine/JVectorConcurrentQueryTests.java:78-138)."""
+    lib = load_library()
+    q = np.ascontiguousarray(queries, dtype=np.float32)
+    chk = None if check_nodes is None else np.ascontiguousarray(check_nodes, dtype=np.int32)
+    out = np.zeros(5, dtype=np.float64)
+    _check(lib, lib.jvh_concurrent_search_bench(index.handle, q.ctypes.data, q.shape[0], q.shape[1], topK, rerankK, threads,
+                                                float(seconds), None if chk is None else chk.ctypes.data, out.ctypes.data))
+    return {"threads": threads, "qps": float(out[0]), "p50_ms": float(out[1]), "p99_ms": float(out[2]),
+            "completed": int(out[3]), "mismatches": int(out[4])}

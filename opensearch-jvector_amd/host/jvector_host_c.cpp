@@ -1,8 +1,13 @@
 // jvector_host_c.cpp — flat C entry points over the C++ host mirror, so the Python parity tests can
 // drive JVectorReader / JVectorKnnFloatVectorQuery the way the reference's own tests do
 // (KNNJVectorTests.java).  Exceptions become negative codes: -1 IllegalArgument, -4 Unsupported, -3 IO.
+#include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstring>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "jvector_host.hpp"
 
@@ -141,6 +146,65 @@ int jvh_similarity_ord_to_dist_func(int ord, int* out) {
 }
 int jvh_similarity_dist_func_to_ord(int lucene_similarity) {
     return VectorSimilarityMapper::distFuncToOrd((LuceneSimilarity)lucene_similarity);
+}
+
+// The reference's calling pattern at the boundary: many searcher threads, each issuing ONE query at a time on the
+// same reader handle (T/index/engine/JVectorConcurrentQueryTests.java:78-138, TJ/KNNJVectorTests.java:982-1027).
+// Drives jv_search from `threads` native threads for `seconds`; thread t walks queries t, t+threads, ... round robin.
+// out[0] = completed queries/s, out[1] = p50 ms, out[2] = p99 ms, out[3] = completed queries.
+// When `check_nodes` is given ([nq][topK], e.g. from a batch call) every answer is compared with it and the
+// number of mismatching queries is returned in out[4].
+int jvh_concurrent_search_bench(jv_index* index, const float* queries, int nq, int dim, int topK, int rerankK,
+                                int threads, double seconds, const int32_t* check_nodes, double out[5]) {
+    if (!index || !queries || nq <= 0 || threads <= 0 || topK <= 0) {
+        g_err = "bad argument";
+        return -1;
+    }
+    std::atomic<bool> stop{false};
+    std::atomic<int> failed{0};
+    std::atomic<long long> mismatches{0};
+    std::vector<std::vector<float>> lat((size_t)threads);
+    std::vector<std::thread> pool;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int t = 0; t < threads; t++) {
+        pool.emplace_back([&, t]() {
+            std::vector<int32_t> nodes((size_t)topK), docs((size_t)topK);
+            std::vector<float> scores((size_t)topK);
+            int32_t count = 0, stats[4];
+            auto& l = lat[(size_t)t];
+            l.reserve(1 << 16);
+            for (int qi = t % nq; !stop.load(std::memory_order_relaxed); qi = (qi + threads) % nq) {
+                const auto a = std::chrono::steady_clock::now();
+                int rc = jv_search(index, queries + (size_t)qi * dim, topK, rerankK, 0.0f, 0.0f, nullptr, 0, nodes.data(),
+                                   docs.data(), scores.data(), &count, stats);
+                const auto b = std::chrono::steady_clock::now();
+                if (rc != 0) {
+                    failed.store(rc);
+                    break;
+                }
+                if (check_nodes && memcmp(check_nodes + (size_t)qi * topK, nodes.data(), sizeof(int32_t) * topK) != 0)
+                    mismatches.fetch_add(1);
+                l.push_back(std::chrono::duration<float, std::milli>(b - a).count());
+            }
+        });
+    }
+    std::this_thread::sleep_for(std::chrono::duration<double>(seconds));
+    stop.store(true);
+    for (auto& th : pool) th.join();
+    const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (failed.load() != 0) {
+        g_err = std::string("jv_search failed: ") + jv_last_error();
+        return -5;
+    }
+    std::vector<float> all;
+    for (auto& l : lat) all.insert(all.end(), l.begin(), l.end());
+    std::sort(all.begin(), all.end());
+    out[0] = all.size() / el;
+    out[1] = all.empty() ? 0.0 : all[all.size() / 2];
+    out[2] = all.empty() ? 0.0 : all[(size_t)(all.size() * 0.99)];
+    out[3] = (double)all.size();
+    out[4] = (double)mismatches.load();
+    return 0;
 }
 
 }  // extern "C"

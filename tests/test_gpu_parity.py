@@ -358,3 +358,67 @@ def test_score_tie_storm_parity(pkg, pyoracle, seed):
             for k, rk in ((1, 1), (2, 2), (3, 4), (5, 8), (10, 16), (10, 40), (20, 100)):
                 _assert_same(gpu.search_batch(q, k, rk), orc.search_batch(q, k, rk), f"{name} sim={sim} seed={seed} k={k} rk={rk}")
             gpu.close()
+
+
+def test_combined_single_query_calls_match_oracle(pkg, pyoracle):
+    """jv_search from many threads: concurrent one-query calls are combined into batch launches inside the library
+    (grouped by identical topK / rerankK / threshold / rerankFloor; filtered calls go alone).  Every caller must get
+    exactly its own query's answer — ids, score bits and counters of the oracle — whatever it was batched with."""
+    import threading
+    b, bl = pkg.binding, pkg.builder
+    base = pkg.datagen.splitmix_uniform(71, 4000, 48)
+    queries = pkg.datagen.splitmix_uniform(72, 96, 48)
+    ix = bl.build_index_cpu(base, 0, R=16, L=60, pq_M=16)
+    orc = pyoracle.Oracle(b, ix)
+    accept = np.zeros((4000 + 63) // 64, dtype=np.uint64)
+    accept[::2] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    params = [(5, 20, 0.0, 0.0, None), (10, 40, 0.0, 0.0, None), (5, 20, 0.0, 0.55, None), (3, 3, 0.0, 0.0, None),
+              (5, 25, 0.0, 0.0, accept)]
+    want = [orc.search_batch(queries, k, rk, threshold=th, rerank_floor=fl, accept=acc, accept_num_docs=(4000 if acc is not None else 0))
+            for k, rk, th, fl, acc in params]
+    for flags, combine in ((b.DESC_FUSED_ADC, 1), (0, 1), (b.DESC_FUSED_ADC, 0)):
+        gpu = b.GpuIndex(ix, flags=flags)
+        b.set_option("combine", combine)
+        errors = []
+
+        def worker(tid):
+            try:
+                rng = np.random.default_rng(tid)
+                for it in range(60):
+                    pi = int(rng.integers(0, len(params)))
+                    qi = int(rng.integers(0, len(queries)))
+                    k, rk, th, fl, acc = params[pi]
+                    got = gpu.search(queries[qi], k, rk, threshold=th, rerank_floor=fl, accept=acc,
+                                     accept_num_docs=(4000 if acc is not None else 0))
+                    w = want[pi]
+                    ok = (np.array_equal(got.nodes[0], w.nodes[qi]) and np.array_equal(got.docs[0], w.docs[qi]) and
+                          np.array_equal(got.scores[0].view(np.uint32), w.scores[qi].view(np.uint32)) and
+                          got.count[0] == w.count[qi] and np.array_equal(got.stats[0], w.stats[qi]))
+                    if not ok:
+                        errors.append((tid, pi, qi))
+            except Exception as e:  # pragma: no cover
+                errors.append((tid, repr(e)))
+
+        threads = [threading.Thread(target=worker, args=(t,)) for t in range(24)]
+        [t.start() for t in threads]
+        [t.join() for t in threads]
+        b.set_option("combine", 1)
+        gpu.close()
+        assert not errors, (flags, combine, errors[:5])
+
+
+def test_concurrent_native_callers_get_batch_answers(pkg):
+    import importlib
+    host = importlib.import_module("opensearch_jvector_amd.host")
+    """Native threads hammering jv_search on one handle (the reference's searcher-thread pattern,
+    JVectorConcurrentQueryTests.java:78-138): every answer equals the batch API's for the same query."""
+    b, bl = pkg.binding, pkg.builder
+    base = pkg.datagen.splitmix_uniform(73, 6000, 64)
+    queries = pkg.datagen.splitmix_uniform(74, 200, 64)
+    ix = bl.build_index_cpu(base, 1, R=32, L=80, pq_M=16)
+    gpu = b.GpuIndex(ix, flags=b.DESC_FUSED_ADC)
+    want = gpu.search_batch(queries, 10, 50).nodes
+    for threads in (3, 48):
+        r = host.concurrent_search_bench(gpu, queries, 10, 50, threads, 0.5, want)
+        assert r["completed"] > threads and r["mismatches"] == 0, r
+    gpu.close()

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""The reference's real calling pattern at the boundary: T searcher threads, one jv_search (one query) per call on
+a shared handle (C3-like index, n from $N).  Prints queries/s, p50/p99 per thread count, and checks every answer
+against the batch API's."""
+import importlib, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import __graft_entry__ as g
+g.load_package()
+b = importlib.import_module("opensearch_jvector_amd.binding")
+gb = importlib.import_module("opensearch_jvector_amd.builder_gpu")
+host = importlib.import_module("opensearch_jvector_amd.host")
+import bench
+n = int(os.environ.get("N", 2_000_000)); d = 768; M = 32; rk = int(os.environ.get("RK", 160)); NQ = 8192
+secs = float(os.environ.get("SECS", 3))
+dev = torch.device("cuda", 0)
+zc, Bl, Bg = bench.make_block_generators(torch, d, dev, max(64, min(4096, n // 256)), M=M, per=2)
+base = bench.gen_rows_block(torch, n, d, 42, 0, zc, Bl, Bg, 0.35, 0.1, 0.005, False, dev)
+q = bench.gen_rows_block(torch, NQ, d, 43, 0, zc, Bl, Bg, 0.35, 0.1, 0.005, False, dev)
+adj, entry = gb.build_graph_gpu(torch, base, 0, R=32, L=100, verbose=False)
+pq = gb.pq_train_encode_gpu(torch, base, M, 0)
+desc, keep = b.make_desc_device(n, d, 32, base.data_ptr(), adj.data_ptr(), entry, 0, pq_M=M, pq_K=pq["K"], pq_codebooks=pq["codebooks"],
+                                pq_centroid=pq["centroid"], pq_codes_ptr=pq["codes"].data_ptr(), borrow=True, extra_flags=b.DESC_FUSED_ADC)
+ix = b.GpuIndex(desc=desc, keepalive=keep, flags=b.DESC_BORROW)
+qh = q.cpu().numpy()
+want = ix.search_batch(qh, 10, rk).nodes
+for opt in os.environ.get("JV_OPTS", "").split(","):
+    if "=" in opt:
+        k_, v_ = opt.split("=")
+        b.set_option(k_, int(v_))
+rows = []
+for T in [int(x) for x in os.environ.get("THREADS", "1,8,32,64,128,256").split(",")]:
+    r = host.concurrent_search_bench(ix, qh, 10, rk, T, secs, want)
+    rows.append(r)
+    print(json.dumps(r), flush=True)
+    assert r["mismatches"] == 0, "single-query answers differ from the batch API's"
+print("done")
