@@ -123,7 +123,16 @@ void jv_index_destroy(jv_index* index);
  * Outputs: up to topK (ordinal, score) pairs in descending score order, ties by ascending
  * ordinal; out_docs (optional) = ord2doc[ordinal] as the reference's collect loop does (:175-177);
  * out_stats[JV_NUM_STATS] = visited, reranked, expanded, expandedBaseLayer (:183-187).
- * rerankK < topK -> JV_EINVAL (jvector throws IllegalArgumentException). */
+ * rerankK < topK -> JV_EINVAL (jvector throws IllegalArgumentException).
+ *
+ * Concurrency: the reference issues ONE query per call from many searcher threads
+ * (T/index/engine/JVectorConcurrentQueryTests.java:78-138).  Calls that are in flight at the same time on
+ * one handle are combined inside the library into batch launches (group commit: the caller that finds a
+ * free leader slot runs every queued call with the same topK / rerankK / threshold / rerankFloor — its own
+ * included — as one launch, each query with its OWN filter, and hands the answers back; later arrivals form
+ * the next batch).  Semantics per call are unchanged (same ids, scores and counters as a lone call); a lone
+ * caller pays no extra latency.  Options "combine" (1), "combine_leaders" (2 batches in flight),
+ * "combine_max_batch" (2048). */
 int jv_search(jv_index* index, const float* query, int32_t topK, int32_t rerankK, float threshold,
               float rerankFloor, const uint64_t* accept_doc_words, int64_t accept_num_docs,
               int32_t* out_nodes, int32_t* out_docs, float* out_scores, int32_t* out_count,
@@ -174,7 +183,9 @@ typedef struct jv_index_info {
 int jv_index_get_info(const jv_index* index, jv_index_info* out);
 
 /* Tunables (process-wide, read at call time): name = "lds_visited_slots", "lds_candidates",
- * "force_big_path", "force_general_path", "big_blocks", "big_cand_cap". Returns JV_EINVAL for unknown names. */
+ * "force_big_path", "force_general_path", "big_blocks", "big_cand_cap", "spill_tables", "spill_slots",
+ * "combine", "combine_leaders", "combine_max_batch" (+ diagnostics: "no_escalation", "no_pqf", "pqf_only",
+ * "dbg_ptr"). Returns JV_EINVAL for unknown names. */
 int jv_set_option(const char* name, int64_t value);
 
 /* Thread-local message of the calling thread's most recent failing call ("" if none). */

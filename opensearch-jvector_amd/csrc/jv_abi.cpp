@@ -122,6 +122,8 @@ struct PendingSearch {
     float* out_scores;
     int32_t* out_count;
     int32_t* out_stats;
+    const uint64_t* accept;  // this query's doc filter (host words) or nullptr
+    int64_t accept_docs;
     int rc = 0;
     char err[256];
     enum { QUEUED, TAKEN } state = QUEUED;
@@ -310,7 +312,8 @@ int ensure_big(jv_index* ix, Ctx* c, int rk) {
 // enqueue one batch on `stream`; all pointers are device pointers
 int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queries, int nq, int topK, int rk,
                   float thr, float floor_, const uint64_t* d_accept, int64_t accept_docs, int32_t* d_nodes,
-                  int32_t* d_docs, float* d_scores, int32_t* d_count, int32_t* d_stats, int32_t* d_flags) {
+                  int32_t* d_docs, float* d_scores, int32_t* d_count, int32_t* d_stats, int32_t* d_flags,
+                  int64_t accept_stride = 0) {
     const bool pq = ix->dev.pq_M > 0;
     // the single-pool form is exact only without a filter and with threshold <= 0 (kernel re-checks scores)
     Geometry g = plan_geometry(ix, rk, d_accept == nullptr && thr <= 0.0f, 0, thr > 0.0f);
@@ -329,6 +332,7 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
     a.rerank_floor = floor_;
     a.accept = d_accept;
     a.accept_docs = accept_docs;
+    a.accept_stride = d_accept ? accept_stride : 0;
     a.out_nodes = d_nodes;
     a.out_docs = d_docs;
     a.out_scores = d_scores;
@@ -705,9 +709,16 @@ int jv_search_batch_device(jv_index* index, const float* d_queries, int32_t nq, 
     return JV_OK;
 }
 
-int jv_search_batch(jv_index* index, const float* queries, int32_t nq, int32_t topK, int32_t rerankK,
-                    float threshold, float rerankFloor, const uint64_t* accept_doc_words, int64_t accept_num_docs,
-                    int32_t* out_nodes, int32_t* out_docs, float* out_scores, int32_t* out_count, int32_t* out_stats) {
+}  // extern "C"
+
+namespace {
+
+// host-pointer batch.  `accept_list` (optional, nq host pointers) gives every query its own doc filter of
+// accept_num_docs bits; `accept_doc_words` is one filter shared by the whole batch.
+int search_batch_host(jv_index* index, const float* queries, int32_t nq, int32_t topK, int32_t rerankK,
+                      float threshold, float rerankFloor, const uint64_t* accept_doc_words,
+                      const uint64_t* const* accept_list, int64_t accept_num_docs, int32_t* out_nodes, int32_t* out_docs,
+                      float* out_scores, int32_t* out_count, int32_t* out_stats) {
     int rc = check_common(index, queries, nq, topK, rerankK, threshold);
     if (rc != JV_OK) return rc;
     if (nq == 0) return JV_OK;
@@ -755,12 +766,19 @@ int jv_search_batch(jv_index* index, const float* queries, int32_t nq, int32_t t
     int32_t* const dst = a32 + o_stats;
     int32_t* const dfl = a32 + o_flags;
     const uint64_t* d_accept = nullptr;
-    if (accept_doc_words) {
+    int64_t accept_stride = 0;
+    if (accept_doc_words || accept_list) {
         if (accept_num_docs < 0) return fail(JV_EINVAL, "accept_num_docs < 0");
         size_t words = ((size_t)accept_num_docs + 63) / 64;
-        if ((rc = grow((void**)&c->d_accept, &c->accept_cap, words, 8)) != JV_OK) return rc;
-        HIPCHK(hipMemcpyAsync(c->d_accept, accept_doc_words, words * 8, hipMemcpyHostToDevice, c->stream));
+        if (words == 0) words = 1;
+        const size_t sets = accept_list ? (size_t)nq : 1;
+        if ((rc = grow((void**)&c->d_accept, &c->accept_cap, words * sets, 8)) != JV_OK) return rc;
+        const size_t copy_words = ((size_t)accept_num_docs + 63) / 64;
+        for (size_t i = 0; i < sets && copy_words; i++)
+            HIPCHK(hipMemcpyAsync(c->d_accept + i * words, accept_list ? accept_list[i] : accept_doc_words, copy_words * 8,
+                                  hipMemcpyHostToDevice, c->stream));
         d_accept = c->d_accept;
+        accept_stride = accept_list ? (int64_t)words : 0;
     }
     const size_t qbytes = (size_t)nq * d * sizeof(float);
     if (qbytes <= (1u << 20)) {  // small batches: stage through pinned memory (a pageable H2D is a blocking staged copy)
@@ -776,7 +794,7 @@ int jv_search_batch(jv_index* index, const float* queries, int32_t nq, int32_t t
         HIPCHK(hipMemcpyAsync(c->d_queries, queries, qbytes, hipMemcpyHostToDevice, c->stream));
     }
     rc = enqueue_batch(index, c, c->stream, c->d_queries, nq, topK, rerankK, threshold, rerankFloor, d_accept,
-                       accept_num_docs, dn, dd, dsc, dc, dst, dfl);
+                       accept_num_docs, dn, dd, dsc, dc, dst, dfl, accept_stride);
     if (rc != JV_OK) return rc;
     HIPCHK(hipMemcpyAsync(c->h_arena, c->d_arena, total4 * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -795,6 +813,19 @@ int jv_search_batch(jv_index* index, const float* queries, int32_t nq, int32_t t
     return JV_OK;
 }
 
+}  // namespace
+
+extern "C" {
+
+int jv_search_batch(jv_index* index, const float* queries, int32_t nq, int32_t topK, int32_t rerankK,
+                    float threshold, float rerankFloor, const uint64_t* accept_doc_words, int64_t accept_num_docs,
+                    int32_t* out_nodes, int32_t* out_docs, float* out_scores, int32_t* out_count, int32_t* out_stats) {
+    return search_batch_host(index, queries, nq, topK, rerankK, threshold, rerankFloor, accept_doc_words, nullptr,
+                             accept_num_docs, out_nodes, out_docs, out_scores, out_count, out_stats);
+}
+
+}  // extern "C"
+
 namespace {
 
 // hand the leader slot to a queued request that has no leader yet, or give it up (combiner.mu held)
@@ -811,13 +842,16 @@ void pass_leadership(Combiner& cb) {
 
 }  // namespace
 
+extern "C" {
+
 int jv_search(jv_index* index, const float* query, int32_t topK, int32_t rerankK, float threshold,
               float rerankFloor, const uint64_t* accept_doc_words, int64_t accept_num_docs, int32_t* out_nodes,
               int32_t* out_docs, float* out_scores, int32_t* out_count, int32_t* out_stats) {
     int rc = check_common(index, query, 1, topK, rerankK, threshold);
     if (rc != JV_OK) return rc;
-    // per-query filters and degenerate calls are not combined
-    if (accept_doc_words || opt_combine.load() == 0 || topK == 0 || index->dev.n == 0 || index->dev.entry < 0)
+    if (accept_doc_words && accept_num_docs < 0) return fail(JV_EINVAL, "accept_num_docs < 0");
+    // degenerate calls are not combined
+    if (opt_combine.load() == 0 || topK == 0 || index->dev.n == 0 || index->dev.entry < 0)
         return jv_search_batch(index, query, 1, topK, rerankK, threshold, rerankFloor, accept_doc_words, accept_num_docs,
                                out_nodes, out_docs, out_scores, out_count, out_stats);
     Combiner& cb = index->combiner;
@@ -832,6 +866,8 @@ int jv_search(jv_index* index, const float* query, int32_t topK, int32_t rerankK
     me.out_scores = out_scores;
     me.out_count = out_count;
     me.out_stats = out_stats;
+    me.accept = accept_doc_words;
+    me.accept_docs = accept_doc_words ? accept_num_docs : 0;
     me.err[0] = 0;
     sem_init(&me.sem, 0, 0);
     auto finish = [&](int code) {
@@ -863,12 +899,18 @@ int jv_search(jv_index* index, const float* query, int32_t topK, int32_t rerankK
     static thread_local std::vector<PendingSearch*> batch;
     static thread_local std::vector<float> qbuf, sbuf;
     static thread_local std::vector<int32_t> nbuf, dbuf, cbuf, stbuf;
+    static thread_local std::vector<const uint64_t*> abuf;
     batch.clear();
     size_t max_batch = (size_t)std::max<int64_t>(1, opt_combine_max_batch.load());
+    if (me.accept) {  // filtered calls batch with filtered calls over the same doc space; bound the staged filter bytes
+        const size_t fbytes = (((size_t)me.accept_docs + 63) / 64) * 8 + 8;
+        max_batch = std::min(max_batch, std::max<size_t>(1, ((size_t)64 << 20) / fbytes));
+    }
     for (auto it = cb.queue.begin(); it != cb.queue.end();) {
         PendingSearch* r = *it;
         const bool same = r == &me || (batch.size() + 1 < max_batch && r->state == PendingSearch::QUEUED && r->topK == topK &&
-                                       r->rerankK == rerankK && r->threshold == threshold && r->rerankFloor == rerankFloor);
+                                       r->rerankK == rerankK && r->threshold == threshold && r->rerankFloor == rerankFloor &&
+                                       (r->accept != nullptr) == (me.accept != nullptr) && r->accept_docs == me.accept_docs);
         if (same) {
             r->state = PendingSearch::TAKEN;
             batch.push_back(r);
@@ -880,8 +922,8 @@ int jv_search(jv_index* index, const float* query, int32_t topK, int32_t rerankK
     lk.unlock();
     const size_t nb = batch.size(), d = (size_t)index->dev.d;
     if (nb == 1) {
-        rc = jv_search_batch(index, query, 1, topK, rerankK, threshold, rerankFloor, nullptr, 0, out_nodes, out_docs,
-                             out_scores, out_count, out_stats);
+        rc = jv_search_batch(index, query, 1, topK, rerankK, threshold, rerankFloor, me.accept, me.accept_docs, out_nodes,
+                             out_docs, out_scores, out_count, out_stats);
         if (rc != JV_OK) snprintf(me.err, sizeof(me.err), "%s", g_last_error.c_str());
     } else {
         qbuf.resize(nb * d);
@@ -890,9 +932,14 @@ int jv_search(jv_index* index, const float* query, int32_t topK, int32_t rerankK
         sbuf.resize(nb * topK);
         cbuf.resize(nb);
         stbuf.resize(nb * 4);
-        for (size_t i = 0; i < nb; i++) memcpy(qbuf.data() + i * d, batch[i]->query, d * sizeof(float));
-        rc = jv_search_batch(index, qbuf.data(), (int32_t)nb, topK, rerankK, threshold, rerankFloor, nullptr, 0, nbuf.data(),
-                             dbuf.data(), sbuf.data(), cbuf.data(), stbuf.data());
+        abuf.resize(nb);
+        for (size_t i = 0; i < nb; i++) {
+            memcpy(qbuf.data() + i * d, batch[i]->query, d * sizeof(float));
+            abuf[i] = batch[i]->accept;
+        }
+        rc = search_batch_host(index, qbuf.data(), (int32_t)nb, topK, rerankK, threshold, rerankFloor, nullptr,
+                               me.accept ? abuf.data() : nullptr, me.accept_docs, nbuf.data(), dbuf.data(), sbuf.data(),
+                               cbuf.data(), stbuf.data());
         for (size_t i = 0; i < nb; i++) {
             PendingSearch* r = batch[i];
             if (rc == JV_OK) {

@@ -48,6 +48,7 @@ struct JvSearchArgs {
     float threshold, rerank_floor;
     const uint64_t* accept;  // doc-space bitset or nullptr
     int64_t accept_docs;
+    int64_t accept_stride;   // 64-bit words between consecutive queries' bitsets; 0 = one bitset for the whole batch
     int32_t* out_nodes;
     int32_t* out_docs;
     float* out_scores;

@@ -715,6 +715,7 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
         const int rk_cur = lvl > 0 ? 1 : rk;
         const float thr = lvl > 0 ? 0.0f : a.threshold;
         const bool accept_all = lvl > 0 || a.accept == nullptr;
+        const uint64_t* const accw = a.accept ? a.accept + (size_t)qi * (size_t)a.accept_stride : nullptr;
         while (st.ncand > 0) {
             int64_t best;
             int bi;
@@ -754,7 +755,7 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
             bool acc = true;
             if (!accept_all) {
                 int doc = ix.ord2doc ? ix.ord2doc[c] : c;
-                acc = doc >= 0 && (int64_t)doc < a.accept_docs && ((a.accept[doc >> 6] >> (doc & 63)) & 1ull);
+                acc = doc >= 0 && (int64_t)doc < a.accept_docs && ((accw[doc >> 6] >> (doc & 63)) & 1ull);
             }
             // addTopCandidate: a full queue only admits a STRICTLY better score
             if (acc && sc >= thr) {

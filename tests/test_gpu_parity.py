@@ -362,7 +362,8 @@ def test_score_tie_storm_parity(pkg, pyoracle, seed):
 
 def test_combined_single_query_calls_match_oracle(pkg, pyoracle):
     """jv_search from many threads: concurrent one-query calls are combined into batch launches inside the library
-    (grouped by identical topK / rerankK / threshold / rerankFloor; filtered calls go alone).  Every caller must get
+    (grouped by identical topK / rerankK / threshold / rerankFloor; filtered calls are batched with each query's own
+    filter).  Every caller must get
     exactly its own query's answer — ids, score bits and counters of the oracle — whatever it was batched with."""
     import threading
     b, bl = pkg.binding, pkg.builder
@@ -372,8 +373,9 @@ def test_combined_single_query_calls_match_oracle(pkg, pyoracle):
     orc = pyoracle.Oracle(b, ix)
     accept = np.zeros((4000 + 63) // 64, dtype=np.uint64)
     accept[::2] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    accept_b = np.full_like(accept, np.uint64(0x0F0F0F0F0F0F0F0F))   # a different filter, batched with the first one
     params = [(5, 20, 0.0, 0.0, None), (10, 40, 0.0, 0.0, None), (5, 20, 0.0, 0.55, None), (3, 3, 0.0, 0.0, None),
-              (5, 25, 0.0, 0.0, accept)]
+              (5, 25, 0.0, 0.0, accept), (5, 25, 0.0, 0.0, accept_b)]
     want = [orc.search_batch(queries, k, rk, threshold=th, rerank_floor=fl, accept=acc, accept_num_docs=(4000 if acc is not None else 0))
             for k, rk, th, fl, acc in params]
     for flags, combine in ((b.DESC_FUSED_ADC, 1), (0, 1), (b.DESC_FUSED_ADC, 0)):
