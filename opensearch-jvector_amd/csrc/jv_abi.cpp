@@ -70,7 +70,7 @@ std::atomic<int64_t> opt_no_pqf{0};
 std::atomic<int64_t> opt_pqf_only{0};  // diagnostics: skip the ladder after the PQF launch (flags stay visible)
 std::atomic<int64_t> opt_spill_tables{2048};  // per context: 2048 x 8192 x 4 B = 64 MB (a launch that needs more falls to the ladder)
 std::atomic<int64_t> opt_spill_slots{8192};
-std::atomic<int64_t> opt_big_blocks{64};
+std::atomic<int64_t> opt_big_blocks{0};  // 0 = auto: as many resident big-path blocks as fit a 768 MB scratch budget (64..1024)
 std::atomic<int64_t> opt_big_cand_cap{65536};
 // jv_search (one query per call, many caller threads): concurrent calls are combined into batch launches
 std::atomic<int64_t> opt_combine{1};
@@ -274,14 +274,24 @@ Geometry plan_geometry(const jv_index* ix, int rk, bool pool_ok, int force_slots
 }
 
 int ensure_big(jv_index* ix, Ctx* c, int rk) {
-    int blocks = (int)opt_big_blocks.load();
-    if (blocks < 1) blocks = 1;
     int cap = (int)opt_big_cand_cap.load();
     int res_cap = ((rk + 1) & ~1);
     if (cap < 4 * rk) cap = 4 * rk;
+    if (cap > ix->dev.n + 64) cap = ix->dev.n + 64;  // the candidate queue never holds more than every node once
     cap += res_cap;
     size_t words = ((size_t)ix->dev.n + 31) / 32;
     if (words == 0) words = 1;
+    int blocks = (int)opt_big_blocks.load();
+    if (blocks < 1) {
+        // queries that outgrow the on-chip scratch (selective filters, huge rerankK) run here: the more resident
+        // blocks, the more of them run side by side
+        if (c->big_blocks > 0 && c->big_words == words && c->big_cand_cap >= cap) {
+            blocks = c->big_blocks;
+        } else {
+            const size_t per = words * sizeof(uint32_t) + (size_t)cap * sizeof(int64_t);
+            blocks = (int)std::min<size_t>(1024, std::max<size_t>(64, ((size_t)768 << 20) / per));
+        }
+    }
     if (c->big_blocks != blocks || c->big_words != words) {
         if (c->big_visited) HIPCHK(hipFree(c->big_visited));
         c->big_visited = nullptr;
@@ -358,20 +368,48 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
     // headline path: PQ + fused layout + single pool + flat graph -> specialised kernel without an in-loop
     // visited set (jv_kernels.hip "PQF"); anything it cannot hold is flagged and falls through to the ladder
     bool pqf = false;
-    if (!force_big && pq && g.pool && ix->dev.pq_fused && ix->dev.num_upper == 0 && ix->dev.R <= JV_WAVE && ix->dev.R * ix->dev.pq_lanes <= 4 * JV_WAVE &&
+    const bool filtered = d_accept != nullptr;
+    // filtered variant: single-pass blocks, ordinals below 2^30 (one key bit carries "accepted")
+    const bool pqf_shape = filtered ? (thr <= 0.0f && ix->dev.R * ix->dev.pq_lanes <= JV_WAVE && ix->dev.n < (1 << 30)) : g.pool;
+    if (!force_big && pq && pqf_shape && ix->dev.pq_fused && ix->dev.num_upper == 0 && ix->dev.R <= JV_WAVE && ix->dev.R * ix->dev.pq_lanes <= 4 * JV_WAVE &&
         (ix->dev.R * ix->dev.pq_lanes + JV_WAVE - 1) / JV_WAVE <= ix->dev.pq_lanes &&
         rk + 64 + ix->dev.R <= 1024 && opt_no_pqf.load() == 0) {
         JvSearchArgs ap = a;
+        const int lut_b = ix->dev.pq_M * 256 * 4;
         ap.cand_cap = (rk + 64 + ix->dev.R + 1) & ~1;  // pool entries: rk + 64 boundary ties + one merge of <= R new keys
         ap.res_cap = (3 * rk + 64 + 3) & ~3;        // expansion log entries
-        const int lut_b = ix->dev.pq_M * 256 * 4;
-        int loop_b = lut_b + ap.cand_cap * 8 + ap.res_cap * 4;
+        bool shape_ok = true;
+        bool second_rung = false;
+        if (filtered) {
+            // the pool must hold every node scoring >= the rk-th best ACCEPTED one (~ rk / selectivity entries) and
+            // the search expands about as many.  First launch: 448 entries (4 resident queries per CU with a 32 KB
+            // LUT); queries that outgrow it are redone by a second launch with 960 entries before the generic ladder.
+            const int need = ap.cand_cap;
+            const bool big_lut = lut_b > 32768;
+            const int want = (need <= 448) ? 448 : 960;
+            shape_ok = need <= want && !(big_lut && want > 448);
+            second_rung = want == 448 && !big_lut;
+            ap.cand_cap = want;
+            ap.res_cap = want == 448 ? 1024 : 2048;
+        }
         const int qc_b = ix->dev.nch * 64 * 4;
-        if (ap.cand_cap * 8 + ap.res_cap * 4 < qc_b) loop_b = lut_b + qc_b;             // LUT build aliases pool + log
         const int rerank_b = qc_b + JV_TODO * 8 + ((rk + 1) & ~1) * 8;                  // after the search, inside the LUT area
-        if (rerank_b <= lut_b && loop_b <= kMaxLds) {
-            HIPCHK(jvk_launch_search_pqf(&ix->dev, &ap, (loop_b + 15) & ~15, stream));
+        auto loop_bytes = [&](const JvSearchArgs& x) {
+            int b_ = lut_b + x.cand_cap * 8 + x.res_cap * 4;
+            if (x.cand_cap * 8 + x.res_cap * 4 < qc_b) b_ = lut_b + qc_b;               // LUT build aliases pool + log
+            return b_;
+        };
+        if (shape_ok && rerank_b <= lut_b && loop_bytes(ap) <= kMaxLds) {
+            HIPCHK(jvk_launch_search_pqf(&ix->dev, &ap, (loop_bytes(ap) + 15) & ~15, stream));
             pqf = true;
+            if (second_rung && opt_pqf_only.load() == 0) {
+                JvSearchArgs ap2 = ap;
+                ap2.cand_cap = 960;
+                ap2.res_cap = 2048;
+                ap2.retry_only = 1;
+                ap2.retry_counter = c->work_counter + 5;
+                if (loop_bytes(ap2) <= kMaxLds) HIPCHK(jvk_launch_search_pqf(&ix->dev, &ap2, (loop_bytes(ap2) + 15) & ~15, stream));
+            }
         }
     }
     if (pqf && opt_pqf_only.load() != 0) return JV_OK;

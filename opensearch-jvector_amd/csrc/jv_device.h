@@ -64,7 +64,7 @@ struct JvSearchArgs {
     int64_t* big_cand;       // [blocks][big_cand_cap]
     int32_t big_cand_cap;
     int32_t* work_counter;   // big path: dynamic query dequeue
-    int32_t retry_only;      // (unused by kernels; kept for diagnostics)
+    int32_t retry_only;      // filtered PQF kernel: 1 = walk the flag array and redo pool/log overflows only
     int32_t* retry_counter;  // escalation launches: flag-chunk dequeue counter (zeroed per call, one per rung)
     // two-level visited set: pool of per-query spill tables in HBM (taken with spill_counter)
     uint32_t* spill;

@@ -553,6 +553,31 @@ __device__ __forceinline__ int64_t pool_to_key(int64_t pk) {
     return (int64_t)(((uint64_t)pk & 0xFFFFFFFF00000000ull) | 0x80000000ull | (((uint64_t)pk >> 1) & 0x7FFFFFFFull));
 }
 __device__ __forceinline__ int pool_node(int64_t pk) { return key_node(pool_to_key(pk)); }
+// filtered pool keys (n < 2^30): one more constant bit of ~node is dropped to make room for bit 1 = "accepted by
+// the query's doc filter" (a function of the node, so equal nodes still have equal keys up to bit 0)
+__device__ __forceinline__ int64_t make_pool_key_f(float score, int node, bool acc) {
+    int32_t b = __float_as_int(score);
+    int32_t s = b ^ ((b >> 31) & 0x7fffffff);
+    return (int64_t)(((uint64_t)(uint32_t)s << 32) | ((uint64_t)((uint32_t)(~node) & 0x3FFFFFFFu) << 2) | (acc ? 2ull : 0ull) | 1ull);
+}
+__device__ __forceinline__ int pool_node_f(int64_t pk) { return (int)((~(uint32_t)((uint64_t)pk >> 2)) & 0x3FFFFFFFu); }
+// position of the n-th (1-based) set bit of m; popcount(m) >= n
+__device__ __forceinline__ int select_nth_bit(unsigned long long m, int n) {
+    int pos = 0;
+#pragma unroll
+    for (int w = 32; w >= 1; w >>= 1) {
+        const unsigned long long low = m & ((1ull << w) - 1ull);
+        const int c = __popcll(low);
+        if (n > c) {
+            n -= c;
+            m >>= w;
+            pos += w;
+        } else {
+            m = low;
+        }
+    }
+    return pos;
+}
 
 // keep the best rk entries of a descending pool plus every entry tied (equal score) with the rk-th
 __device__ __forceinline__ int pool_trim(const int64_t* pool, int np, int rk, int lane) {
@@ -1196,9 +1221,46 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
 // CH = pool capacity in 64-entry chunks (template parameter): 4, 8 or 16 (rerankK + 64 + R <= 64 * CH)
 // NP = compile-time bound on fused-block passes: 1 (R * lanes-per-node <= 64, the common case) or 4
 
-template <int NCHT, int CH, int NP>
+// FILT = the query has a doc filter (J/JVectorReader.java:157-163): entries carry an "accepted" bit, the boundary is
+// the rerankK-th best ACCEPTED entry (jvector's result queue only holds accepted nodes, but every node scoring at
+// least as well as its worst entry stays a candidate), NP == 1 only.
+template <int NCHT, int CH, int NP, bool FILT>
 __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int qi, unsigned char* smem) {
     const int lane = threadIdx.x;
+    const uint64_t* const accw = FILT ? a.accept + (size_t)qi * (size_t)a.accept_stride : nullptr;
+    auto accepts = [&](int node) -> bool {  // the reference's acceptOrds lambda
+        const int doc = ix.ord2doc ? ix.ord2doc[node] : node;
+        return doc >= 0 && (int64_t)doc < a.accept_docs && ((accw[doc >> 6] >> (doc & 63)) & 1ull);
+    };
+    auto pnode = [&](int64_t pk) -> int { return FILT ? pool_node_f(pk) : pool_node(pk); };
+    if (FILT) {
+        // Rung choice only (never results): estimate the filter's selectivity from 64 sampled words; a pool of
+        // ~ rerankK / selectivity entries that cannot fit this launch's capacity is handed on right away instead
+        // of after a wasted search.
+        const int64_t nwords = (a.accept_docs + 63) >> 6;
+        int bits = 0;
+        if (nwords > 0) {
+            const uint64_t h = ((uint64_t)(lane + 1) * 0x9E3779B97F4A7C15ull) >> 20;
+            bits = __popcll(accw[nwords <= JV_WAVE ? (int64_t)(lane % (int)nwords) : (int64_t)(h % (uint64_t)nwords)]);
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) bits += __shfl_xor(bits, o, JV_WAVE);
+        const float sel = fmaxf((float)bits, 1.0f) * (1.0f / 4096.0f);
+        const float need = (float)a.rk / sel * 1.05f + 64.0f + (float)ix.R;
+        if (need > (float)a.cand_cap && a.cand_cap < 8 * a.rk + 256) {
+            if (lane == 0) {
+                a.out_flags[qi] = (int32_t)(JV_FLAG_OVERFLOW | (3u << 8));
+                a.out_count[qi] = 0;
+            }
+            int32_t* o_n = a.out_nodes + (size_t)qi * a.topK;
+            for (int i = lane; i < a.topK; i += JV_WAVE) {
+                o_n[i] = -1;
+                if (a.out_docs) a.out_docs[(size_t)qi * a.topK + i] = -1;
+                a.out_scores[(size_t)qi * a.topK + i] = 0.0f;
+            }
+            return;
+        }
+    }
     const int rk = a.rk, topK = a.topK;
     const int M = ix.pq_M, R = ix.R, lpn = ix.pq_lanes, cs = ix.pq_code_stride;
     // ---- LDS carve ----
@@ -1261,17 +1323,28 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
 #pragma unroll
     for (int t = 0; t < CH - 1; t++) piv[t] = KEY_MIN;
     unsigned long long um[CH];
+    unsigned long long am[FILT ? CH : 1];  // FILT: accepted entries
+    bool have_b = false;                   // FILT: the pool holds >= rk accepted entries, bscore is their rk-th best
 #pragma unroll
     for (int t = 0; t < CH; t++) um[t] = 0ull;
+#pragma unroll
+    for (int t = 0; t < (FILT ? CH : 1); t++) am[t] = 0ull;
     {
         const int ep = ix.entry;
         u32x4 cw = (u32x4){0, 0, 0, 0};
         if (lane < lpn && my_chunk) cw = *(const u32x4*)(ix.pq_codes + (size_t)ep * cs + my_c * 16);
         const float s = adc_score(cw, lane < lpn && my_chunk);
-        if (lane == 0) pool[0] = make_pool_key(s, ep);
+        bool acc_ep = true;
+        if (FILT) acc_ep = accepts(ep);
+        if (lane == 0) pool[0] = FILT ? make_pool_key_f(s, ep, acc_ep) : make_pool_key(s, ep);
         np = 1;
         um[0] = 1ull;
         __syncthreads();
+        if (FILT) {
+            am[0] = acc_ep ? 1ull : 0ull;
+            have_b = acc_ep && rk <= 1;
+            bscore = key_score(pool[0]);  // (s is only valid on the entry point's lanes)
+        }
     }
 
     int pf_node = -1;
@@ -1314,7 +1387,7 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
         }
         // strict-admission tie (see the generic pool loop): the expanded entries scoring >= the candidate already
         // fill the result queue and the candidate ranks inside the top rerankK -> the two-queue form decides
-        if (expanded >= rk && idx < rk) {
+        if (!FILT && expanded >= rk && idx < rk) {
             int ge = idx;
             for (int j = idx + 1; j < np && ge < rk; j++) {
                 const int64_t kj = pool[j];
@@ -1328,7 +1401,31 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
                 break;
             }
         }
-        const int c = pool_node(pk);
+        if (FILT && expanded >= rk && (pk & 2ll)) {
+            // same rule over the ACCEPTED entries (only they enter jvector's result queue): all entries ahead of
+            // the candidate are expanded; the accepted ones among them + the accepted, expanded, equal-score
+            // entries behind it are the results scoring >= the candidate
+            int ge = 0;
+#pragma unroll
+            for (int t = 0; t < CH; t++) {
+                const int lo = t << 6;
+                const unsigned long long below = idx >= lo + 64 ? ~0ull : (idx > lo ? ((1ull << (idx - lo)) - 1ull) : 0ull);
+                ge += __popcll(am[t] & below);
+            }
+            if (ge < rk) {
+                for (int j = idx + 1; j < np && ge < rk; j++) {
+                    const int64_t kj = pool[j];
+                    if (key_score(kj) != sc) break;
+                    ge += ((kj & 3ll) == 2ll) ? 1 : 0;
+                }
+                if (ge >= rk) {
+                    overflow = true;
+                    why = 5;
+                    break;
+                }
+            }
+        }
+        const int c = pnode(pk);
         int nnp[NP];
         u32x4 cwp[NP];
 #pragma unroll
@@ -1346,7 +1443,13 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
                 }
             }
         }
-        const int c2 = idx2 >= 0 ? pool_node(pool[idx2]) : -1;
+        const int c2 = idx2 >= 0 ? pnode(pool[idx2]) : -1;
+        // FILT: the neighbours' accept bits (ord -> doc -> bitset word) are fetched while the ADC runs
+        bool accn = true;
+        if (FILT) {
+            accn = false;
+            if (nnp[0] >= 0 && my_c == 0) accn = accepts(nnp[0]);
+        }
 #ifdef JV_STAMPS
         asm volatile("" ::"v"(c2), "v"(c));
 #endif
@@ -1406,8 +1509,8 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
         // All LDS reads below are unconditional (clamped index) and batched into registers first: a
         // conditional load would compile into an exec-masked branch with its own LDS round trip.
         bool keep = nn >= 0 && my_c < npass;
-        if (np >= rk && score < bscore) keep = false;  // below the boundary for good
-        const int64_t v = make_pool_key(score, nn);
+        if ((FILT ? have_b : np >= rk) && score < bscore) keep = false;  // below the boundary for good
+        const int64_t v = FILT ? make_pool_key_f(score, nn, accn) : make_pool_key(score, nn);
         int rold;
         {   // rold = #{pool entries > v} = first index whose entry is <= v.  Uniform 3-level 8-ary search over
             // the (<= 512-entry) pool: block sizes 64, 8, 1.
@@ -1485,7 +1588,34 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
 #pragma unroll
             for (int t = 0; t < CH; t++) ov[t] = pool[min((t << 6) + lane, cap - 1)];
             int nnew = ntot;
-            if (ntot > rk) {
+            if (FILT) {
+                int nacc = 0;
+#pragma unroll
+                for (int t = 0; t < CH; t++) {
+                    am[t] = __ballot((t << 6) + lane < ntot && (ov[t] & 2ll));
+                    nacc += __popcll(am[t]);
+                }
+                have_b = nacc >= rk;
+                if (have_b) {
+                    int need = rk, bpos = -1;
+#pragma unroll
+                    for (int t = 0; t < CH; t++) {
+                        const int ct = __popcll(am[t]);
+                        if (bpos < 0) {
+                            if (need <= ct) bpos = (t << 6) + select_nth_bit(am[t], need);
+                            else need -= ct;
+                        }
+                    }
+                    bscore = key_score(pool[bpos]);
+                    int ties = 0;
+#pragma unroll
+                    for (int t = 0; t < CH; t++) {
+                        const int i = (t << 6) + lane;
+                        ties += __popcll(__ballot(i > bpos && i < ntot && key_score(ov[t]) == bscore));
+                    }
+                    nnew = bpos + 1 + ties;
+                }
+            } else if (ntot > rk) {
                 const int64_t bk = pool[rk - 1];
                 bscore = key_score(bk);
                 int ties = 0;  // entries beyond rk-1 that tie with the boundary score stay (they are contiguous)
@@ -1508,6 +1638,7 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
             for (int t = 0; t < CH; t++) {
                 const int i = (t << 6) + lane;
                 um[t] = __ballot(i < np && (ov[t] & 1ll));
+                if (FILT) am[t] &= __ballot(i < np);
                 if (t < CH - 1) {  // pool[64t + 63] sits in lane 63 of ov[t]
                     const int plo = __builtin_amdgcn_readlane((int)(uint32_t)(ov[t] & 0xFFFFFFFFll), 63);
                     const int phi = __builtin_amdgcn_readlane((int)(ov[t] >> 32), 63);
@@ -1596,6 +1727,22 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
     for (int i = lane; i < ix.nch * 64; i += JV_WAVE) q_lds[i] = i < ix.d ? qg[i] : 0.0f;
     __syncthreads();
     if (ix.sim == 2) qnorm2 = query_norm2(ix, q_lds, lane), qnorm2 = __shfl(qnorm2, 0, JV_WAVE);
+    if (FILT) {
+        // jvector's result queue = the accepted entries, best rerankK of them: compact them to the front, in order
+        // (a chunk is read into registers before anything is written, and writes never pass the read position)
+        int w = 0;
+        for (int b0 = 0; b0 < np; b0 += JV_WAVE) {
+            const int i = b0 + lane;
+            const int64_t k = i < np ? pool[i] : 0;
+            const bool t_ = i < np && (k & 2ll);
+            const unsigned long long tm = __ballot(t_);
+            __syncthreads();
+            if (t_) pool[w + __popcll(tm & ((1ull << lane) - 1ull))] = k;
+            w += __popcll(tm);
+            __syncthreads();
+        }
+        np = w;
+    }
     const int nres = np < rk ? np : rk;
     int nfin = 0, reranked = 0;
     int above = 0;
@@ -1608,7 +1755,7 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
         int node = 0;
         if (i < nres) {
             const int64_t k = pool[i];
-            node = pool_node(k);
+            node = pnode(k);
             take = above > 0 ? key_score(k) >= a.rerank_floor : i == 0;  // pool[0] is the best approximate entry
         }
         const unsigned long long tm = __ballot(take);
@@ -1660,7 +1807,41 @@ __global__ __launch_bounds__(JV_WAVE) void jv_search_pqf_kernel(const JvIndexDev
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int qi = blockIdx.x;
     if (qi >= a.nq) return;
-    search_one_pqf<NCHT, CH, NP>(ix, a, qi, smem);
+    search_one_pqf<NCHT, CH, NP, false>(ix, a, qi, smem);
+}
+
+// the same search with a per-query doc filter (own name: profiles keep filtered launches apart)
+template <int NCHT, int CH>
+__global__ __launch_bounds__(JV_WAVE) void jv_search_pqf_filtered_kernel(const JvIndexDev ix, const JvSearchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (!a.retry_only) {
+        const int qi = blockIdx.x;
+        if (qi >= a.nq) return;
+        search_one_pqf<NCHT, CH, 1, true>(ix, a, qi, smem);
+        return;
+    }
+    // second rung (larger pool + log): only the queries whose pool or expansion log overflowed in the first launch
+    const int lane = threadIdx.x;
+    for (;;) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(a.retry_counter, 8);  // small chunks: most queries may be flagged here
+        base = __shfl(base, 0, JV_WAVE);
+        if (base >= a.nq) break;
+        const int qi = base + lane;
+        bool flagged = false;
+        if (lane < 8 && qi < a.nq) {
+            const uint32_t f = (uint32_t)a.out_flags[qi];
+            const uint32_t why = (f >> 8) & 0xFu;
+            flagged = (f & JV_FLAG_OVERFLOW) && (why == 2u || why == 3u);
+        }
+        unsigned long long m = __ballot(flagged);
+        while (m) {
+            const int j = __ffsll((long long)m) - 1;
+            m &= m - 1ull;
+            search_one_pqf<NCHT, CH, 1, true>(ix, a, base + j, smem);
+            __syncthreads();
+        }
+    }
 }
 
 // Fast path: one query per workgroup, all scratch in LDS.
@@ -1847,6 +2028,9 @@ static const lds_kernel_t g_build_kernels[2][4] = {JV_ROW(jv_build_search_kernel
 // [multi-pass][large pool][nch slot]
 static const lds_kernel_t g_pqf_kernels[2][3][4] = {{JV_PQF_ROW(4, 1), JV_PQF_ROW(8, 1), JV_PQF_ROW(16, 1)},
                                                     {JV_PQF_ROW(4, 4), JV_PQF_ROW(8, 4), JV_PQF_ROW(16, 4)}};
+#define JV_PQFF_ROW(CH) \
+    { jv_search_pqf_filtered_kernel<0, CH>, jv_search_pqf_filtered_kernel<2, CH>, jv_search_pqf_filtered_kernel<12, CH>, jv_search_pqf_filtered_kernel<24, CH> }
+static const lds_kernel_t g_pqff_kernels[2][4] = {JV_PQFF_ROW(8), JV_PQFF_ROW(16)};
 static const big_kernel_t g_big_kernels[2][4] = {JV_ROW(jv_search_big_kernel, false), JV_ROW(jv_search_big_kernel, true)};
 
 static int nch_slot(const JvIndexDev* ix) {
@@ -1869,6 +2053,9 @@ extern "C" hipError_t jvk_set_max_lds(int bytes) {
             if (e == hipSuccess && a == 0)
                 for (int v = 0; v < 6 && e == hipSuccess; v++)
                     e = hipFuncSetAttribute((const void*)g_pqf_kernels[v / 3][v % 3][s], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            if (e == hipSuccess && a == 0)
+                for (int v = 0; v < 2 && e == hipSuccess; v++)
+                    e = hipFuncSetAttribute((const void*)g_pqff_kernels[v][s], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             if (e == hipSuccess)
                 e = hipFuncSetAttribute((const void*)g_big_kernels[a][s], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             if (e != hipSuccess) return e;
@@ -1880,6 +2067,16 @@ extern "C" hipError_t jvk_set_max_lds(int bytes) {
 extern "C" hipError_t jvk_launch_search_pqf(const JvIndexDev* ix, const JvSearchArgs* a, int lds_bytes, hipStream_t stream) {
     if (a->nq <= 0) return hipSuccess;
     const int multi = ix->R * ix->pq_lanes > JV_WAVE ? 1 : 0;
+    if (a->accept) {  // filtered variant (the host only selects it for single-pass blocks)
+        int grid = a->nq;
+        if (a->retry_only) {
+            grid = (a->nq + 7) / 8;
+            const int resident = 256 * (lds_bytes > 0 ? (163840 / lds_bytes > 0 ? 163840 / lds_bytes : 1) : 8);
+            if (grid > resident) grid = resident;
+        }
+        g_pqff_kernels[a->cand_cap > 512 ? 1 : 0][nch_slot(ix)]<<<grid, JV_WAVE, lds_bytes, stream>>>(*ix, *a);
+        return hipGetLastError();
+    }
     g_pqf_kernels[multi][a->cand_cap > 512 ? 2 : a->cand_cap > 256 ? 1 : 0][nch_slot(ix)]<<<a->nq, JV_WAVE, lds_bytes, stream>>>(*ix, *a);
     return hipGetLastError();
 }

@@ -424,3 +424,57 @@ def test_concurrent_native_callers_get_batch_answers(pkg):
         r = host.concurrent_search_bench(gpu, queries, 10, 50, threads, 0.5, want)
         assert r["completed"] > threads and r["mismatches"] == 0, r
     gpu.close()
+
+
+@pytest.mark.parametrize("sim", [0, 1, 2])
+def test_filtered_fused_pq_parity(pkg, pyoracle, small_sets, sim):
+    """Doc filters on the fused-PQ path (the filtered PQF kernel: accepted bit in the pool keys, boundary = rerankK-th
+    best ACCEPTED entry) against the oracle's literal two-queue search, from mild to selective filters (the latter
+    overflow the on-chip pool and take the ladder), with a permuted sparse doc-id space and deleted ordinals."""
+    b, bl = pkg.binding, pkg.builder
+    base, q = small_sets["base64"][:5000], small_sets["q64"][:48]
+    n = base.shape[0]
+    rng = np.random.default_rng(17 + sim)
+    max_doc = 2 * n
+    ord2doc = rng.permutation(max_doc)[:n].astype(np.int32)
+    ord2doc[rng.random(n) < 0.03] = -1
+    ix = bl.build_index_cpu(base, sim, R=32, L=80, pq_M=16, ord2doc=ord2doc, max_doc=max_doc)
+    gpu = b.GpuIndex(ix, flags=b.DESC_FUSED_ADC)
+    orc = pyoracle.Oracle(b, ix)
+    for frac in (0.95, 0.6, 0.3, 0.1, 0.02):
+        acc_docs = np.nonzero(rng.random(max_doc) < frac)[0]
+        words = b.accept_words(acc_docs, max_doc)
+        for k, rk in ((10, 50), (3, 3), (10, 160), (1, 1)):
+            want = orc.search_batch(q, k, rk, accept=words, accept_num_docs=max_doc)
+            got = gpu.search_batch(q, k, rk, accept=words, accept_num_docs=max_doc)
+            _assert_same(got, want, f"sim={sim} frac={frac} k={k} rk={rk}")
+    # rerankFloor with a filter
+    words = b.accept_words(np.nonzero(rng.random(max_doc) < 0.5)[0], max_doc)
+    want = orc.search_batch(q, 10, 40, rerank_floor=0.6, accept=words, accept_num_docs=max_doc)
+    got = gpu.search_batch(q, 10, 40, rerank_floor=0.6, accept=words, accept_num_docs=max_doc)
+    _assert_same(got, want, f"sim={sim} filter + rerankFloor")
+    gpu.close()
+
+
+@pytest.mark.parametrize("seed", [21, 22])
+def test_filtered_tie_storm_parity(pkg, pyoracle, seed):
+    """Grid-valued vectors (every comparison is a tie) + doc filters on the fused-PQ path: strict admission into a
+    full result queue is decided over the ACCEPTED entries only."""
+    b, bl = pkg.binding, pkg.builder
+    rng = np.random.default_rng(seed)
+    n, d, R = 500, 4, 16
+    base = rng.integers(0, 3, size=(n, d)).astype(np.float32)
+    adj = np.stack([rng.permutation(n)[:R] for _ in range(n)]).astype(np.int32)
+    q = rng.integers(0, 3, size=(64, d)).astype(np.float32) + np.float32(0.5) * (rng.random((64, d)) < 0.3)
+    for sim in (0, 1):
+        cb, cen, codes, K = bl.pq_train_encode_cpu(base, 2, sim)
+        ixq = b.IndexData(vectors=base, adj=adj, entry_node=int(rng.integers(0, n)), similarity=sim, pq_codebooks=cb,
+                          pq_centroid=cen, pq_codes=codes, pq_M=2, pq_K=K)
+        gpu = b.GpuIndex(ixq, flags=b.DESC_FUSED_ADC)
+        orc = pyoracle.Oracle(b, ixq)
+        for frac in (0.8, 0.4):
+            words = b.accept_words(np.nonzero(rng.random(n) < frac)[0], n)
+            for k, rk in ((1, 1), (2, 2), (3, 4), (5, 8), (10, 16), (10, 40)):
+                _assert_same(gpu.search_batch(q, k, rk, accept=words, accept_num_docs=n),
+                             orc.search_batch(q, k, rk, accept=words, accept_num_docs=n), f"sim={sim} seed={seed} frac={frac} k={k} rk={rk}")
+        gpu.close()

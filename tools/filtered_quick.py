@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Throughput of filtered searches (shared doc filter, batch device API) on a C3-like index, n from $N."""
+import importlib, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import __graft_entry__ as g
+g.load_package()
+b = importlib.import_module("opensearch_jvector_amd.binding")
+gb = importlib.import_module("opensearch_jvector_amd.builder_gpu")
+import bench
+n = int(os.environ.get("N", 2_000_000)); d = 768; M = 32; rk = int(os.environ.get("RK", 160)); B = int(os.environ.get("B", 16384))
+dev = torch.device("cuda", 0)
+zc, Bl, Bg = bench.make_block_generators(torch, d, dev, max(64, min(4096, n // 256)), M=M, per=2)
+base = bench.gen_rows_block(torch, n, d, 42, 0, zc, Bl, Bg, 0.35, 0.1, 0.005, False, dev)
+q = bench.gen_rows_block(torch, B, d, 43, 0, zc, Bl, Bg, 0.35, 0.1, 0.005, False, dev)
+adj, entry = gb.build_graph_gpu(torch, base, 0, R=32, L=100, verbose=False)
+pq = gb.pq_train_encode_gpu(torch, base, M, 0)
+desc, keep = b.make_desc_device(n, d, 32, base.data_ptr(), adj.data_ptr(), entry, 0, pq_M=M, pq_K=pq["K"], pq_codebooks=pq["codebooks"],
+                                pq_centroid=pq["centroid"], pq_codes_ptr=pq["codes"].data_ptr(), borrow=True, extra_flags=b.DESC_FUSED_ADC)
+ix = b.GpuIndex(desc=desc, keepalive=keep, flags=b.DESC_BORROW)
+o = [torch.empty((B, 10), dtype=torch.int32, device=dev), torch.empty((B, 10), dtype=torch.int32, device=dev),
+     torch.empty((B, 10), dtype=torch.float32, device=dev), torch.empty((B,), dtype=torch.int32, device=dev),
+     torch.zeros((B, 4), dtype=torch.int32, device=dev), torch.empty((B,), dtype=torch.int32, device=dev)]
+rng = np.random.default_rng(5)
+for sel in [None if x == "None" else float(x) for x in os.environ.get("SELS", "None,0.9,0.5,0.3,0.2").split(",")]:
+    if sel is None:
+        acc_ptr = 0
+    else:
+        bits = rng.random(n) < sel
+        words = np.packbits(bits, bitorder="little")
+        words = np.concatenate([words, np.zeros((-len(words)) % 8, np.uint8)]).view(np.uint64)
+        acc = torch.from_numpy(words.view(np.int64)).to(dev)
+        acc_ptr = acc.data_ptr()
+    for it in range(3):
+        torch.cuda.synchronize(); t = time.time()
+        ix.search_batch_device(q.data_ptr(), B, 10, rk, *[t_.data_ptr() for t_ in o], d_accept=acc_ptr, accept_num_docs=(n if acc_ptr else 0))
+        torch.cuda.synchronize(); dt = time.time() - t
+    st = o[4].cpu().numpy().astype(np.float64).mean(0)
+    fl = o[5].cpu().numpy().astype(np.uint32)
+    print(f"selectivity {sel}: {B / dt:9.0f} QPS  visited {st[0]:.0f} expanded {st[2]:.0f}  big-path {int((fl & 1).sum())}  count<10: {int((o[3].cpu().numpy() < 10).sum())}", flush=True)
+print("done")
