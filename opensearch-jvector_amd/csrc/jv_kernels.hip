@@ -1224,7 +1224,9 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
 // FILT = the query has a doc filter (J/JVectorReader.java:157-163): entries carry an "accepted" bit, the boundary is
 // the rerankK-th best ACCEPTED entry (jvector's result queue only holds accepted nodes, but every node scoring at
 // least as well as its worst entry stays a candidate), NP == 1 only.
-template <int NCHT, int CH, int NP, bool FILT>
+// FAST = pq_M is a multiple of 16 and the similarity is not cosine: only the unmasked LDS look-up is compiled
+// (the masked and norm-table variants cost ~70 scalar registers of hoisted lane predicates even when unused).
+template <int NCHT, int CH, int NP, bool FILT, bool FAST>
 __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int qi, unsigned char* smem) {
     const int lane = threadIdx.x;
     const uint64_t* const accw = FILT ? a.accept + (size_t)qi * (size_t)a.accept_stride : nullptr;
@@ -1301,6 +1303,10 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
     const bool my_chunk = my_c * 16 < M;
     const bool full16 = (M & 15) == 0;
     auto adc_score = [&](const u32x4 cw, bool have) -> float {
+        if (FAST) {
+            const float s_ = adc_chunk<true>(lut, cw, my_c * 16, M);
+            return map_score(ix.sim == 0 ? 0 : 1, lanes_tree_sum(have ? s_ : 0.0f, lpn));
+        }
         float s = full16 ? adc_chunk<true>(lut, cw, my_c * 16, M) : adc_chunk<false>(lut, cw, my_c * 16, M);
         float na = 0.0f;
         if (ix.sim == 2) na = adc_chunk<false>(ix.pq_norm_lut, cw, my_c * 16, M);
@@ -1802,22 +1808,22 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
     }
 }
 
-template <int NCHT, int CH, int NP>
+template <int NCHT, int CH, int NP, bool FAST>
 __global__ __launch_bounds__(JV_WAVE) void jv_search_pqf_kernel(const JvIndexDev ix, const JvSearchArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int qi = blockIdx.x;
     if (qi >= a.nq) return;
-    search_one_pqf<NCHT, CH, NP, false>(ix, a, qi, smem);
+    search_one_pqf<NCHT, CH, NP, false, FAST>(ix, a, qi, smem);
 }
 
 // the same search with a per-query doc filter (own name: profiles keep filtered launches apart)
-template <int NCHT, int CH>
+template <int NCHT, int CH, bool FAST>
 __global__ __launch_bounds__(JV_WAVE) void jv_search_pqf_filtered_kernel(const JvIndexDev ix, const JvSearchArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (!a.retry_only) {
         const int qi = blockIdx.x;
         if (qi >= a.nq) return;
-        search_one_pqf<NCHT, CH, 1, true>(ix, a, qi, smem);
+        search_one_pqf<NCHT, CH, 1, true, FAST>(ix, a, qi, smem);
         return;
     }
     // second rung (larger pool + log): only the queries whose pool or expansion log overflowed in the first launch
@@ -1838,7 +1844,7 @@ __global__ __launch_bounds__(JV_WAVE) void jv_search_pqf_filtered_kernel(const J
         while (m) {
             const int j = __ffsll((long long)m) - 1;
             m &= m - 1ull;
-            search_one_pqf<NCHT, CH, 1, true>(ix, a, base + j, smem);
+            search_one_pqf<NCHT, CH, 1, true, FAST>(ix, a, base + j, smem);
             __syncthreads();
         }
     }
@@ -2023,14 +2029,16 @@ static const lds_kernel_t g_retry_kernels[2][2][4] = {
     {JV_ROW(jv_search_retry_kernel, true, false), JV_ROW(jv_search_retry_kernel, true, true)}};
 static const lds_kernel_t g_build_kernels[2][4] = {JV_ROW(jv_build_search_kernel, false),
                                                    JV_ROW(jv_build_search_kernel, true)};
-#define JV_PQF_ROW(CH, NP) \
-    { jv_search_pqf_kernel<0, CH, NP>, jv_search_pqf_kernel<2, CH, NP>, jv_search_pqf_kernel<12, CH, NP>, jv_search_pqf_kernel<24, CH, NP> }
-// [multi-pass][large pool][nch slot]
-static const lds_kernel_t g_pqf_kernels[2][3][4] = {{JV_PQF_ROW(4, 1), JV_PQF_ROW(8, 1), JV_PQF_ROW(16, 1)},
-                                                    {JV_PQF_ROW(4, 4), JV_PQF_ROW(8, 4), JV_PQF_ROW(16, 4)}};
-#define JV_PQFF_ROW(CH) \
-    { jv_search_pqf_filtered_kernel<0, CH>, jv_search_pqf_filtered_kernel<2, CH>, jv_search_pqf_filtered_kernel<12, CH>, jv_search_pqf_filtered_kernel<24, CH> }
-static const lds_kernel_t g_pqff_kernels[2][4] = {JV_PQFF_ROW(8), JV_PQFF_ROW(16)};
+#define JV_PQF_ROW(CH, NP, FAST) \
+    { jv_search_pqf_kernel<0, CH, NP, FAST>, jv_search_pqf_kernel<2, CH, NP, FAST>, jv_search_pqf_kernel<12, CH, NP, FAST>, jv_search_pqf_kernel<24, CH, NP, FAST> }
+// [0 single-pass | 1 multi-pass | 2 single-pass FAST][pool size][nch slot]
+static const lds_kernel_t g_pqf_kernels[3][3][4] = {{JV_PQF_ROW(4, 1, false), JV_PQF_ROW(8, 1, false), JV_PQF_ROW(16, 1, false)},
+                                                    {JV_PQF_ROW(4, 4, false), JV_PQF_ROW(8, 4, false), JV_PQF_ROW(16, 4, false)},
+                                                    {JV_PQF_ROW(4, 1, true), JV_PQF_ROW(8, 1, true), JV_PQF_ROW(16, 1, true)}};
+#define JV_PQFF_ROW(CH, FAST) \
+    { jv_search_pqf_filtered_kernel<0, CH, FAST>, jv_search_pqf_filtered_kernel<2, CH, FAST>, jv_search_pqf_filtered_kernel<12, CH, FAST>, jv_search_pqf_filtered_kernel<24, CH, FAST> }
+// [FAST][pool size][nch slot]
+static const lds_kernel_t g_pqff_kernels[2][2][4] = {{JV_PQFF_ROW(8, false), JV_PQFF_ROW(16, false)}, {JV_PQFF_ROW(8, true), JV_PQFF_ROW(16, true)}};
 static const big_kernel_t g_big_kernels[2][4] = {JV_ROW(jv_search_big_kernel, false), JV_ROW(jv_search_big_kernel, true)};
 
 static int nch_slot(const JvIndexDev* ix) {
@@ -2051,11 +2059,11 @@ extern "C" hipError_t jvk_set_max_lds(int bytes) {
             }
             hipError_t e = hipFuncSetAttribute((const void*)g_build_kernels[a][s], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             if (e == hipSuccess && a == 0)
-                for (int v = 0; v < 6 && e == hipSuccess; v++)
+                for (int v = 0; v < 9 && e == hipSuccess; v++)
                     e = hipFuncSetAttribute((const void*)g_pqf_kernels[v / 3][v % 3][s], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             if (e == hipSuccess && a == 0)
-                for (int v = 0; v < 2 && e == hipSuccess; v++)
-                    e = hipFuncSetAttribute((const void*)g_pqff_kernels[v][s], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+                for (int v = 0; v < 4 && e == hipSuccess; v++)
+                    e = hipFuncSetAttribute((const void*)g_pqff_kernels[v >> 1][v & 1][s], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             if (e == hipSuccess)
                 e = hipFuncSetAttribute((const void*)g_big_kernels[a][s], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             if (e != hipSuccess) return e;
@@ -2067,6 +2075,7 @@ extern "C" hipError_t jvk_set_max_lds(int bytes) {
 extern "C" hipError_t jvk_launch_search_pqf(const JvIndexDev* ix, const JvSearchArgs* a, int lds_bytes, hipStream_t stream) {
     if (a->nq <= 0) return hipSuccess;
     const int multi = ix->R * ix->pq_lanes > JV_WAVE ? 1 : 0;
+    const int fast = (ix->pq_M % 16 == 0 && ix->sim != 2) ? 1 : 0;
     if (a->accept) {  // filtered variant (the host only selects it for single-pass blocks)
         int grid = a->nq;
         if (a->retry_only) {
@@ -2074,10 +2083,10 @@ extern "C" hipError_t jvk_launch_search_pqf(const JvIndexDev* ix, const JvSearch
             const int resident = 256 * (lds_bytes > 0 ? (163840 / lds_bytes > 0 ? 163840 / lds_bytes : 1) : 8);
             if (grid > resident) grid = resident;
         }
-        g_pqff_kernels[a->cand_cap > 512 ? 1 : 0][nch_slot(ix)]<<<grid, JV_WAVE, lds_bytes, stream>>>(*ix, *a);
+        g_pqff_kernels[fast][a->cand_cap > 512 ? 1 : 0][nch_slot(ix)]<<<grid, JV_WAVE, lds_bytes, stream>>>(*ix, *a);
         return hipGetLastError();
     }
-    g_pqf_kernels[multi][a->cand_cap > 512 ? 2 : a->cand_cap > 256 ? 1 : 0][nch_slot(ix)]<<<a->nq, JV_WAVE, lds_bytes, stream>>>(*ix, *a);
+    g_pqf_kernels[multi ? 1 : (fast ? 2 : 0)][a->cand_cap > 512 ? 2 : a->cand_cap > 256 ? 1 : 0][nch_slot(ix)]<<<a->nq, JV_WAVE, lds_bytes, stream>>>(*ix, *a);
     return hipGetLastError();
 }
 
