@@ -1439,11 +1439,11 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
             nnp[ps] = -1;
             cwp[ps] = (u32x4){0, 0, 0, 0};
             if (ps < npass) {
-                if (c == pf_node) {
-                    nnp[ps] = pf_nn[ps];
-                    cwp[ps] = pf_cw[ps];
+                const int j = ps * jpp + my_slot;
+                if (c == pf_node) {  // the prefetch loaded with clamped indices: mask here
+                    nnp[ps] = j < R ? pf_nn[ps] : -1;
+                    if (j < R && my_chunk) cwp[ps] = pf_cw[ps];
                 } else {
-                    const int j = ps * jpp + my_slot;
                     nnp[ps] = j < R ? ix.adj[(size_t)c * R + j] : -1;
                     if (j < R && my_chunk) cwp[ps] = *(const u32x4*)(ix.pq_fused + ((size_t)c * R + j) * cs + my_c * 16);
                 }
@@ -1463,6 +1463,23 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
 #ifdef JV_STAMPS
         asm volatile("" ::"v"(nnp[0]), "v"(cwp[0][0]), "v"(cwp[0][3]));
 #endif
+        // start the runner-up's fetch now (this expansion's block is older in the load queue, so waiting for it
+        // does not wait for the prefetch): ADC + merge (~3 500 cycles) cover its HBM latency
+        // The loads are UNCONDITIONAL (clamped indices, every lane, also when there is no runner-up): a fixed number
+        // of younger loads is what lets the wait for this expansion's block be vmcnt(2) instead of vmcnt(0).
+        pf_node = c2;
+        {
+            const int c2e = c2 >= 0 ? c2 : c;
+#pragma unroll
+            for (int ps = 0; ps < NP; ps++) {
+                if (NP == 1 || ps < npass) {
+                    const int j = min(ps * jpp + my_slot, R - 1);
+                    pf_nn[ps] = ix.adj[(size_t)c2e * R + j];
+                    pf_cw[ps] = *(const u32x4*)(ix.pq_fused + ((size_t)c2e * R + j) * cs + (my_chunk ? my_c * 16 : 0));
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
         STAMP(1)  // wait for the block
         if (nexp >= log_cap) {
             overflow = true;
@@ -1492,20 +1509,6 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
                 }
             }
         }
-        // the block is consumed: start the runner-up's fetch
-        __builtin_amdgcn_sched_barrier(0);
-        pf_node = c2;
-        if (c2 >= 0) {
-#pragma unroll
-            for (int ps = 0; ps < NP; ps++) {
-                if (ps < npass) {
-                    const int j = ps * jpp + my_slot;
-                    pf_nn[ps] = j < R ? ix.adj[(size_t)c2 * R + j] : -1;
-                    if (j < R && my_chunk) pf_cw[ps] = *(const u32x4*)(ix.pq_fused + ((size_t)c2 * R + j) * cs + my_c * 16);
-                }
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
         expanded++;
 #ifdef JV_STAMPS
         asm volatile("" ::"v"(score));
