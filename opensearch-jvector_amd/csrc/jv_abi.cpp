@@ -1018,20 +1018,28 @@ int jv_score_ordinals(jv_index* index, const float* query, const int32_t* ordina
         ~Releaser() { ctx_release(ix, c); }
     } rel{index, c};
     const int d = index->dev.d;
-    float* dq = nullptr;
-    int32_t* dord = nullptr;
-    float* dout = nullptr;
-    HIPCHK(hipMalloc((void**)&dq, (size_t)d * 4));
-    hipError_t e = hipMalloc((void**)&dord, (size_t)count * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&dout, (size_t)count * 4);
-    if (e == hipSuccess) e = hipMemcpyAsync(dq, query, (size_t)d * 4, hipMemcpyHostToDevice, c->stream);
+    // context-owned staging: query in d_queries, ordinals + scores in the result arena (no per-call allocation)
+    if ((rc = grow((void**)&c->d_queries, &c->queries_cap, (size_t)d, sizeof(float))) != JV_OK) return rc;
+    const size_t need = (size_t)count * 8;
+    if (need > c->arena_cap) {
+        hipFree(c->d_arena);
+        c->d_arena = nullptr;
+        if (c->h_arena) hipHostFree(c->h_arena);
+        c->h_arena = nullptr;
+        c->arena_cap = 0;
+        const size_t cap = need + need / 4;
+        HIPCHK(hipMalloc((void**)&c->d_arena, cap));
+        HIPCHK(hipHostMalloc((void**)&c->h_arena, cap, hipHostMallocDefault));
+        c->arena_cap = cap;
+    }
+    float* dq = c->d_queries;
+    int32_t* dord = (int32_t*)c->d_arena;
+    float* dout = (float*)(c->d_arena + (size_t)count * 4);
+    hipError_t e = hipMemcpyAsync(dq, query, (size_t)d * 4, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(dord, ordinals, (size_t)count * 4, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = jvk_launch_score_ordinals(&index->dev, dq, dord, count, dout, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out_scores, dout, (size_t)count * 4, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    hipFree(dq);
-    hipFree(dord);
-    hipFree(dout);
     if (e != hipSuccess) return fail(JV_EDEVICE, "jv_score_ordinals: %s", hipGetErrorString(e));
     return JV_OK;
 }

@@ -1385,6 +1385,8 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
         }
         if (idx < 0) break;
         const int64_t pk = pool[idx];
+        const int64_t pk2 = pool[idx2 >= 0 ? idx2 : idx];  // both reads in one LDS round trip
+        const int c2 = idx2 >= 0 ? pnode(pk2) : -1;
         const float sc = key_score(pk);
         if (sc < a.threshold) {
             overflow = true;
@@ -1449,7 +1451,6 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
                 }
             }
         }
-        const int c2 = idx2 >= 0 ? pnode(pool[idx2]) : -1;
         // FILT: the neighbours' accept bits (ord -> doc -> bitset word) are fetched while the ADC runs
         bool accn = true;
         if (FILT) {
