@@ -959,6 +959,7 @@ int jv_search(jv_index* index, const float* query, int32_t topK, int32_t rerankK
     }
     lk.unlock();
     const size_t nb = batch.size(), d = (size_t)index->dev.d;
+    bool passed = false;
     if (nb == 1) {
         rc = jv_search_batch(index, query, 1, topK, rerankK, threshold, rerankFloor, me.accept, me.accept_docs, out_nodes,
                              out_docs, out_scores, out_count, out_stats);
@@ -978,6 +979,12 @@ int jv_search(jv_index* index, const float* query, int32_t topK, int32_t rerankK
         rc = search_batch_host(index, qbuf.data(), (int32_t)nb, topK, rerankK, threshold, rerankFloor, nullptr,
                                me.accept ? abuf.data() : nullptr, me.accept_docs, nbuf.data(), dbuf.data(), sbuf.data(),
                                cbuf.data(), stbuf.data());
+        // the answers are in this thread's buffers: free the leader slot BEFORE handing them out, so the next batch
+        // is on the GPU while this one's owners are being woken (one futex wake per owner)
+        lk.lock();
+        pass_leadership(cb);
+        lk.unlock();
+        passed = true;
         for (size_t i = 0; i < nb; i++) {
             PendingSearch* r = batch[i];
             if (rc == JV_OK) {
@@ -995,9 +1002,11 @@ int jv_search(jv_index* index, const float* query, int32_t topK, int32_t rerankK
             }
         }
     }
-    lk.lock();
-    pass_leadership(cb);
-    lk.unlock();
+    if (!passed) {
+        lk.lock();
+        pass_leadership(cb);
+        lk.unlock();
+    }
     return finish(rc);
 }
 
