@@ -1672,7 +1672,7 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
         while (vslots * 2 <= M * 256) vslots <<= 1;
         const uint32_t vmask = (uint32_t)vslots - 1u;
         const int vshift = 32 - (31 - __clz(vslots));
-        const int vlimit = (vslots / 8) * 7;
+        const int vlimit = (vslots / 16) * 15;
         __syncthreads();
         for (int i = lane; i < vslots; i += JV_WAVE) vh[i] = HASH_EMPTY;
         __syncthreads();
@@ -1680,20 +1680,58 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
         __syncthreads();
         const int rows_per = JV_WAVE / R > 0 ? JV_WAVE / R : 1;  // adjacency rows per wave-instruction
         if (R <= JV_WAVE) {
-            constexpr int VB = 8;  // adjacency batches in flight
+            constexpr int VB = 8;  // adjacency batches per group; the NEXT group's rows are in flight while this one probes
+            // unconditional loads with clamped indices (masked when consumed): a fixed number of loads per group is
+            // what lets the wait for THIS group's rows leave the next group's in flight (vmcnt(VB), not vmcnt(0))
+            auto load_group = [&](int e0, int (&dst)[VB]) {
+#pragma unroll
+                for (int u = 0; u < VB; u++) {
+                    const int e = min(e0 + u * rows_per + lane / R, nexp - 1);
+                    dst[u] = ix.adj[(size_t)explog[e] * R + (lane % R)];
+                }
+            };
+            int nb_next[VB];
+            load_group(0, nb_next);
             for (int e0 = 0; e0 < nexp && !overflow; e0 += rows_per * VB) {
                 int nb[VB];
 #pragma unroll
                 for (int u = 0; u < VB; u++) {
                     const int e = e0 + u * rows_per + lane / R;
-                    nb[u] = (e < nexp && lane < rows_per * R) ? ix.adj[(size_t)explog[e] * R + (lane % R)] : -1;
+                    nb[u] = (e < nexp && lane < rows_per * R) ? nb_next[u] : -1;
                 }
+                load_group(e0 + rows_per * VB, nb_next);
+                int pending = 0;
+#pragma unroll
+                for (int u = 0; u < VB; u++) pending += __popcll(__ballot(nb[u] >= 0));
+                if (visited + pending > vlimit) {
+                    overflow = true;
+                    why = 4;
+                    break;
+                }
+                // all VB batches probe together: the compare-and-swaps of one round are issued back to back and
+                // their LDS latencies overlap (the distinct count does not depend on the insertion order)
+                uint32_t hh[VB];
+                bool pend[VB];
 #pragma unroll
                 for (int u = 0; u < VB; u++) {
-                    if (visited + JV_WAVE > vlimit) overflow = true, why = 4;
-                    bool is_new = false;
-                    if (!overflow && nb[u] >= 0) is_new = visited_insert_lds(vh, vmask, vshift, (uint32_t)nb[u]);
-                    visited += __popcll(__ballot(is_new));
+                    pend[u] = nb[u] >= 0;
+                    hh[u] = ((uint32_t)nb[u] * 0x9E3779B1u) >> vshift;
+                }
+                for (;;) {
+                    uint32_t oldv[VB];
+#pragma unroll
+                    for (int u = 0; u < VB; u++) oldv[u] = pend[u] ? atomicCAS(&vh[hh[u]], HASH_EMPTY, (uint32_t)nb[u]) : 0u;
+                    bool more = false;
+#pragma unroll
+                    for (int u = 0; u < VB; u++) {
+                        const bool fresh = pend[u] && oldv[u] == HASH_EMPTY;
+                        visited += __popcll(__ballot(fresh));
+                        if (pend[u]) {
+                            if (fresh || oldv[u] == (uint32_t)nb[u]) pend[u] = false;
+                            else hh[u] = (hh[u] + 1) & vmask, more = true;
+                        }
+                    }
+                    if (!__any(more)) break;
                 }
             }
         } else {
