@@ -32,8 +32,10 @@ WORKLOADS = {
     "c2": dict(desc="1Mx768 dot-product fp32 resident, rerankK swept for recall@10>=0.95", n=1_000_000, d=768, sim=1,
                pq_M=0, normalize=True),
     # BASELINE.json configs[2] — the configuration the metric is quoted on
+    # (262 144 queries per step: per-query work varies 3x around its mean, and the drain of the slowest queries at
+    # the end of a launch costs ~7 % at 65 536 queries per step, ~2 % here)
     "c3": dict(desc="10Mx768 L2 PQ-32 ADC + full-precision rerank (DiskANN two-pass)", n=10_000_000, d=768, sim=0,
-               pq_M=32, normalize=False),
+               pq_M=32, normalize=False, batch=262144),
     # BASELINE.json configs[4]: 256 concurrent queries on the C3 index.  Run on the fp32 parity path: at B = 256 the
     # only dense contraction (the LUT build, 2*B*256*d = 0.1 GFLOP) is ~0.02 % of a step and the rerank has no
     # candidates shared between queries, so a bf16 MFMA path would change scores without changing throughput
