@@ -960,6 +960,7 @@ int jv_search(jv_index* index, const float* query, int32_t topK, int32_t rerankK
     lk.unlock();
     const size_t nb = batch.size(), d = (size_t)index->dev.d;
     bool passed = false;
+    try {
     if (nb == 1) {
         rc = jv_search_batch(index, query, 1, topK, rerankK, threshold, rerankFloor, me.accept, me.accept_docs, out_nodes,
                              out_docs, out_scores, out_count, out_stats);
@@ -1000,6 +1001,24 @@ int jv_search(jv_index* index, const float* query, int32_t topK, int32_t rerankK
                 r->rc = rc;
                 sem_post(&r->sem);  // r's frame may be gone as soon as this returns: r is not touched afterwards
             }
+        }
+    }
+    } catch (const std::exception& e) {
+        // only the staging-vector resizes can throw, i.e. before any owner has been answered: nobody may be left
+        // waiting, so every call of this batch fails with the same error
+        rc = JV_ENOMEM;
+        snprintf(me.err, sizeof(me.err), "jv_search: %s", e.what());
+        if (!passed) {
+            lk.lock();
+            pass_leadership(cb);
+            lk.unlock();
+            passed = true;
+        }
+        for (PendingSearch* r : batch) {
+            if (r == &me) continue;
+            r->rc = rc;
+            snprintf(r->err, sizeof(r->err), "%s", me.err);
+            sem_post(&r->sem);
         }
     }
     if (!passed) {
