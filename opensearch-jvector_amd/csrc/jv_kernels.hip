@@ -1521,10 +1521,10 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
         bool keep = nn >= 0 && my_c < npass;
         if ((FILT ? have_b : np >= rk) && score < bscore) keep = false;  // below the boundary for good
         const int64_t v = FILT ? make_pool_key_f(score, nn, accn) : make_pool_key(score, nn);
-        int rold = 0;
-        if (__ballot(keep)) {  // (late in a search most expansions bring nothing above the boundary: skip the search)
-            // rold = #{pool entries > v} = first index whose entry is <= v.  Uniform 3-level 8-ary search over
-            // the pool: block sizes 64, 8, 1.
+        int rold;
+        {   // rold = #{pool entries > v} = first index whose entry is <= v.  Uniform 3-level 8-ary search over
+            // the pool: block sizes 64, 8, 1.  (Skipping the search when no key passes the boundary was measured:
+            // the branch costs more than the skipped searches save.)
             const int last = cap - 1;
             int64_t p2[7], p3[9];
             int c1 = 0;
