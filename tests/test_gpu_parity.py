@@ -478,3 +478,27 @@ def test_filtered_tie_storm_parity(pkg, pyoracle, seed):
                 _assert_same(gpu.search_batch(q, k, rk, accept=words, accept_num_docs=n),
                              orc.search_batch(q, k, rk, accept=words, accept_num_docs=n), f"sim={sim} seed={seed} frac={frac} k={k} rk={rk}")
         gpu.close()
+
+
+@pytest.mark.parametrize("d,M", [(768, 32), (1536, 64)])
+def test_headline_dimensions_parity(pkg, pyoracle, d, M):
+    """The compile-time row-length variants the benchmark configs run on (d = 768 -> 12 chunks, d = 1536 -> 24 chunks;
+    PQ-32 single-pass and PQ-64 two-pass fused blocks), at a size the oracle finishes in seconds: exact search, fused
+    PQ + rerank, and a filtered fused search."""
+    b, bl = pkg.binding, pkg.builder
+    n = 1500
+    base = pkg.datagen.splitmix_uniform(81, n, d)
+    q = pkg.datagen.splitmix_uniform(82, 24, d)
+    for sim in (0, 1):
+        ix = bl.build_index_cpu(base, sim, R=32, L=60)
+        gpu, orc = b.GpuIndex(ix), pyoracle.Oracle(b, ix)
+        _assert_same(gpu.search_batch(q, 10, 60), orc.search_batch(q, 10, 60), f"exact d={d} sim={sim}")
+        gpu.close()
+        ixq = bl.build_index_cpu(base, sim, R=32, L=60, pq_M=M)
+        gpu, orc = b.GpuIndex(ixq, flags=b.DESC_FUSED_ADC), pyoracle.Oracle(b, ixq)
+        for k, rk in ((10, 100), (10, 225)):
+            _assert_same(gpu.search_batch(q, k, rk), orc.search_batch(q, k, rk), f"fused d={d} M={M} sim={sim} rk={rk}")
+        words = b.accept_words(np.arange(0, n, 2), n)
+        _assert_same(gpu.search_batch(q, 10, 100, accept=words, accept_num_docs=n),
+                     orc.search_batch(q, 10, 100, accept=words, accept_num_docs=n), f"filtered fused d={d} M={M} sim={sim}")
+        gpu.close()
