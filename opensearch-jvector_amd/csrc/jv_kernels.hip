@@ -1361,6 +1361,12 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
     STAMP_DECL
     STAMP(7)  // staging + LUT build + entry point
     while (true) {
+#ifdef JV_STAMPS
+        // diagnostic build: account the exposed part of the prefetch latency separately (slot 7)
+        STAMP(5)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP(7)
+#endif
         // best and runner-up unexpanded entries from the masks (first two set bits over the CH words)
         int idx = -1, idx2 = -1;
         {

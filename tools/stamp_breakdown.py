@@ -39,7 +39,7 @@ for fused in (1,):
     b.set_option("dbg_ptr", 0)
     v = dbg.cpu().numpy().astype(np.float64)
     st = o[4].cpu().numpy().astype(np.float64).mean(0)
-    names = ["find (masks, pool reads)", "block wait", "ADC + prefetch issue", "rank search + dedupe", "new-key ranks + shift + insert", "trim + mask rebuild", "visited-count pass", "pre-loop (LUT, entry)"]
+    names = ["find (masks, pool reads)", "block wait", "ADC + prefetch issue", "rank search + dedupe", "new-key ranks + shift + insert", "trim + mask rebuild", "visited-count pass", "exposed prefetch wait (loop top)"]
     cyc = v.copy(); hits = 0
     print(f"fused={fused}: {B / dt:.0f} QPS (stamped build), expansions/query {st[2]:.1f}, prefetch hit rate {hits / (st[2] * B):.2f}")
     for i, nme in enumerate(names):
