@@ -1367,31 +1367,26 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         STAMP(7)
 #endif
-        // best and runner-up unexpanded entries from the masks (first two set bits over the CH words)
-        int idx = -1, idx2 = -1;
-        {
-            unsigned int nz = 0;  // bit t set <=> um[t] != 0
+        // best and runner-up unexpanded entries from the masks: per-word first-set-bit + min, the best entry's bit is
+        // cleared right away (it is expanded below or the query bails), then the same again for the runner-up.
+        // (A single wave issues a scalar instruction every ~4 cycles: this form is half the instructions of
+        // selecting the words through compare/select chains.)
+        int idx = 0x7fffffff, idx2 = 0x7fffffff;
 #pragma unroll
-            for (int t = 0; t < CH; t++) nz |= um[t] ? (1u << t) : 0u;
-            if (nz) {
-                const int t1 = __ffs((int)nz) - 1;
-                unsigned long long m1 = 0ull, m2 = 0ull;
-                const unsigned int nz2 = nz & (nz - 1u);
-                const int t2 = nz2 ? __ffs((int)nz2) - 1 : -1;
+        for (int t = 0; t < CH; t++) idx = min(idx, um[t] ? (t << 6) + __ffsll((long long)um[t]) - 1 : 0x7fffffff);
+        if (idx == 0x7fffffff) break;
 #pragma unroll
-                for (int t = 0; t < CH; t++) {
-                    if (t == t1) m1 = um[t];
-                    if (t == t2) m2 = um[t];
-                }
-                idx = (t1 << 6) + __ffsll((long long)m1) - 1;
-                const unsigned long long r1 = m1 & (m1 - 1ull);
-                if (r1) idx2 = (t1 << 6) + __ffsll((long long)r1) - 1;
-                else if (t2 >= 0) idx2 = (t2 << 6) + __ffsll((long long)m2) - 1;
-            }
-        }
-        if (idx < 0) break;
+        for (int t = 0; t < CH; t++) um[t] &= ~((t == (idx >> 6)) ? (1ull << (idx & 63)) : 0ull);
+#pragma unroll
+        for (int t = 0; t < CH; t++) idx2 = min(idx2, um[t] ? (t << 6) + __ffsll((long long)um[t]) - 1 : 0x7fffffff);
+        if (idx2 == 0x7fffffff) idx2 = -1;
         const int64_t pk = pool[idx];
-        const int64_t pk2 = pool[idx2 >= 0 ? idx2 : idx];  // both reads in one LDS round trip
+        int64_t pk2 = pool[max(idx2, 0)];  // unconditional: both reads share one LDS round trip
+        {   // (keeps the compiler from sinking the second read into the idx2 >= 0 branch, behind the first wait)
+            int lo2 = (int)(uint32_t)(pk2 & 0xFFFFFFFFll);
+            asm volatile("" : "+v"(lo2));
+            pk2 = (int64_t)(((uint64_t)pk2 & 0xFFFFFFFF00000000ull) | (uint64_t)(uint32_t)lo2);
+        }
         const int c2 = idx2 >= 0 ? pnode(pk2) : -1;
         const float sc = key_score(pk);
         if (sc < a.threshold) {
@@ -1498,9 +1493,6 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
             explog[nexp] = c;
         }
         nexp++;
-#pragma unroll
-        for (int t = 0; t < CH; t++)
-            if (t == (idx >> 6)) um[t] &= ~(1ull << (idx & 63));
         // ADC of all R stored neighbours; pass ps delivers its scores to the lanes whose chunk index is ps
         float score = 0.0f;
         int nn = -1;
