@@ -17,6 +17,7 @@
 #include <string>
 #include <vector>
 
+#include <errno.h>
 #include <semaphore.h>
 
 #include "../../include/jvgpu.h"
@@ -866,6 +867,12 @@ int jv_search_batch(jv_index* index, const float* queries, int32_t nq, int32_t t
 
 namespace {
 
+// (a JVM delivers signals to its threads: a wait interrupted by one is simply resumed)
+void sem_wait_retry(sem_t* s) {
+    while (sem_wait(s) == -1 && errno == EINTR) {
+    }
+}
+
 // hand the leader slot to a queued request that has no leader yet, or give it up (combiner.mu held)
 void pass_leadership(Combiner& cb) {
     for (PendingSearch* r : cb.queue) {
@@ -922,7 +929,7 @@ int jv_search(jv_index* index, const float* query, int32_t topK, int32_t rerankK
         me.promoted = true;
     } else {
         lk.unlock();
-        sem_wait(&me.sem);  // promotion, or the answer
+        sem_wait_retry(&me.sem);  // promotion, or the answer
         lk.lock();
         if (!me.promoted) return finish(me.rc);
     }
@@ -931,7 +938,7 @@ int jv_search(jv_index* index, const float* query, int32_t topK, int32_t rerankK
         // another leader took this request before the promotion was acted on: give the slot away and wait for it
         pass_leadership(cb);
         lk.unlock();
-        sem_wait(&me.sem);
+        sem_wait_retry(&me.sem);
         return finish(me.rc);
     }
     static thread_local std::vector<PendingSearch*> batch;
