@@ -28,6 +28,17 @@ for opt in os.environ.get("JV_OPTS", "").split(","):
     if "=" in opt:
         k_, v_ = opt.split("=")
         b.set_option(k_, int(v_))
+if os.environ.get("BIG_FIRST"):  # diagnostic: a large device-API launch first, like bench.py does
+    Bb = int(os.environ["BIG_FIRST"])
+    qb = bench.gen_rows_block(torch, Bb, d, 45, 0, zc, Bl, Bg, 0.35, 0.1, 0.005, False, dev)
+    ob = [torch.empty((Bb, 10), dtype=torch.int32, device=dev), torch.empty((Bb, 10), dtype=torch.int32, device=dev),
+          torch.empty((Bb, 10), dtype=torch.float32, device=dev), torch.empty((Bb,), dtype=torch.int32, device=dev),
+          torch.empty((Bb, 4), dtype=torch.int32, device=dev), torch.empty((Bb,), dtype=torch.int32, device=dev)]
+    st = torch.cuda.Stream(device=dev)
+    for _ in range(3):
+        ix.search_batch_device(qb.data_ptr(), Bb, 10, rk, *[t_.data_ptr() for t_ in ob], stream=st.cuda_stream)
+    st.synchronize()
+    ix.search_batch(qh[:4096], 10, rk)
 rows = []
 for T in [int(x) for x in os.environ.get("THREADS", "1,8,32,64,128,256").split(",")]:
     r = host.concurrent_search_bench(ix, qh, 10, rk, T, secs, want)
