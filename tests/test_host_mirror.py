@@ -45,3 +45,13 @@ def test_vector_similarity_mapper(host):
     with pytest.raises(host.HostError) as ei:
         host.ord_to_dist_func(9)
     assert ei.value.code == -1  # IllegalArgumentException
+
+
+def test_host_library_exports_the_mirror_entry_points(host):
+    """libjvhost.so (the C++ mirror of the reference's Java host classes) loads and exports every entry the Python
+    plumbing binds, incl. the concurrent-caller driver (no compute without a GPU)."""
+    lib = host.load_library()
+    for name in ("jvh_reader_open", "jvh_reader_close", "jvh_query_search_leaf", "jvh_reader_search_plain_collector",
+                 "jvh_reader_search_bytes", "jvh_counters", "jvh_docmap_roundtrip", "jvh_similarity_ord_to_dist_func",
+                 "jvh_similarity_dist_func_to_ord", "jvh_concurrent_search_bench", "jvh_last_error"):
+        assert hasattr(lib, name), name
