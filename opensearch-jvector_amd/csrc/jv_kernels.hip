@@ -41,6 +41,9 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define KEY_MIN ((int64_t)0x8000000000000000ll)
 #define KEY_MAX ((int64_t)0x7fffffffffffffffll)
 #define HASH_EMPTY 0xFFFFFFFFu
+#ifndef JV_PQF_RERANK_UMUL
+#define JV_PQF_RERANK_UMUL 2  // rows in flight per rerank step = 4 * RowsInFlight * this
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // NodeQueue keys (jvector NodeQueue.encode)
@@ -1810,7 +1813,7 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
         if (take) todo[__popcll(tm & ((1ull << lane) - 1ull))] = node;
         __syncthreads();
         if (m > 0) {
-            score_rows<NCHT, 2>(ix, q_lds, todo, m, todo_score, qnorm2, 1.0f, lane);
+            score_rows<NCHT, JV_PQF_RERANK_UMUL>(ix, q_lds, todo, m, todo_score, qnorm2, 1.0f, lane);
             __syncthreads();
             if (lane < m) fin[nfin + lane] = make_key(todo_score[lane], todo[lane]);
             nfin += m;

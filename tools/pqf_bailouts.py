@@ -6,6 +6,9 @@ import numpy as np, torch
 import __graft_entry__ as g
 g.load_package()
 b = importlib.import_module("opensearch_jvector_amd.binding")
+if os.environ.get("JV_LIB"):
+    b.LIB_PATH = os.path.join(os.path.dirname(b.LIB_PATH), os.environ["JV_LIB"])
+    b.load_library(b.LIB_PATH)
 gb = importlib.import_module("opensearch_jvector_amd.builder_gpu")
 import bench
 n = int(os.environ.get("N", 10_000_000)); d = 768; M = 32; rk = int(os.environ.get("RK", 160)); B = 65536
