@@ -597,6 +597,50 @@ __device__ __forceinline__ int pool_trim(const int64_t* pool, int np, int rk, in
     return rk + extra;
 }
 
+// rerankFloor above EVERY approximate score with several results tied at the best approximate score: jvector's
+// NodeQueue.rerank then rescores the first best entry in its result heap's ARRAY order, which depends on the
+// push/replace history of that binary heap.  The HBM-scratch rung logs every addTopCandidate call of level 0 and this
+// replays them through a literal BoundedLongHeap (same sift rules as oracle/jv_oracle.c lh_up / lh_down) to find
+// that entry.  One lane, sequential: the corner is a degenerate use of rerankFloor, exactness is all that matters.
+// log entry i lives at log_top[-i]; h has rk + 1 slots (1-based heap).
+__device__ int replay_first_best(const int64_t* log_top, int nlog, int rk, int64_t* h) {
+    int size = 0;
+    for (int i = 0; i < nlog; i++) {
+        const int64_t v = log_top[-i];
+        if (size < rk) {  // push: append + sift up
+            int p = ++size;
+            int j = p >> 1;
+            while (j > 0 && v < h[j]) {
+                h[p] = h[j];
+                p = j;
+                j >>= 1;
+            }
+            h[p] = v;
+        } else if (key_score(v) > key_score(h[1])) {  // strictly better than the worst result: replace it, sift down
+            int p = 1, j = 2, k2 = 3;
+            if (k2 <= size && h[k2] < h[j]) j = k2;
+            while (j <= size && h[j] < v) {
+                h[p] = h[j];
+                p = j;
+                j = p << 1;
+                k2 = j + 1;
+                if (k2 <= size && h[k2] < h[j]) j = k2;
+            }
+            h[p] = v;
+        }
+    }
+    float best = -__builtin_huge_valf();
+    int bi = -1;
+    for (int i = 1; i <= size; i++) {
+        const float a = key_score(h[i]);
+        if (a > best) {
+            best = a;
+            bi = i;
+        }
+    }
+    return bi > 0 ? key_node(h[bi]) : -1;
+}
+
 // POOL: level 0 runs on one sorted pool (exact when there is no filter and threshold <= 0, ties included:
 // DESIGN.md "Single-pool search"); otherwise the two-queue form of jvector is executed literally.
 template <bool PQ, bool BIG, bool POOL, int NCHT>
@@ -787,6 +831,14 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
             }
             // addTopCandidate: a full queue only admits a STRICTLY better score
             if (acc && sc >= thr) {
+                if (BIG && PQ && lvl == 0) {  // call log for replay_first_best (top of the candidate area, like the hand-back list)
+                    if (st.ncand + st.nhand + 1 > cand_cap) {
+                        st.overflow = true;
+                        break;
+                    }
+                    if (lane == 0) cand[cand_cap - 1 - st.nhand] = best;
+                    st.nhand++;
+                }
                 if (st.nres < rk_cur) {
                     if (lane == 0) res[st.nres] = best;
                     st.nres++;
@@ -1120,6 +1172,39 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
         }
     }
 
+    // NodeQueue.rerank bookkeeping (PQ): how many results reach rerankFloor; if none, the single entry to rescore
+    int above = 0, only_node = -1;
+    if (PQ && !st.overflow) {
+        __syncthreads();
+        for (int i = lane; i < st.nres; i += JV_WAVE) above += key_score(res[i]) >= a.rerank_floor ? 1 : 0;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) above += __shfl_xor(above, o, 64);
+        if (above == 0 && st.nres > 0) {
+            int64_t bk;
+            int bidx;
+            scan_max(res, st.nres, lane, bk, bidx);
+            only_node = key_node(bk);
+            int ties = 0;
+            for (int b0 = 0; b0 < st.nres; b0 += JV_WAVE) {
+                const int i = b0 + lane;
+                ties += __popcll(__ballot(i < st.nres && key_score(res[i]) == key_score(bk)));
+            }
+            if (ties > 1) {
+                // several results share the best approximate score: jvector's pick is the first in its heap array
+                if (!BIG) {
+                    st.overflow = true;  // -> the HBM-scratch rung replays the heap
+                } else if (st.nhand + rk + 2 > cand_cap) {
+                    st.overflow = true;
+                } else {
+                    int nd = -1;
+                    if (lane == 0) nd = replay_first_best(cand + (cand_cap - 1), st.nhand, rk, cand);
+                    only_node = __shfl(nd, 0, JV_WAVE);
+                    __syncthreads();
+                }
+            }
+        }
+    }
+
     int32_t* o_nodes = a.out_nodes + (size_t)qi * topK;
     int32_t* o_docs = a.out_docs ? a.out_docs + (size_t)qi * topK : nullptr;
     float* o_scores = a.out_scores + (size_t)qi * topK;
@@ -1143,13 +1228,6 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
         // NodeQueue.rerank: exact-rescore entries with approx >= rerankFloor, or only the best one
         fin = cand;  // the candidate queue is dead now; cand_cap >= rk
         nfin = 0;
-        int above = 0;
-        for (int i = lane; i < st.nres; i += JV_WAVE) above += key_score(res[i]) >= a.rerank_floor ? 1 : 0;
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) above += __shfl_xor(above, o, 64);
-        int64_t bk;
-        int bidx;
-        scan_max(res, st.nres, lane, bk, bidx);
         for (int b0 = 0; b0 < st.nres; b0 += JV_WAVE) {
             const int i = b0 + lane;
             bool take = false;
@@ -1157,7 +1235,7 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
             if (i < st.nres) {
                 const int64_t k = res[i];
                 node = key_node(k);
-                take = above > 0 ? key_score(k) >= a.rerank_floor : i == bidx;
+                take = above > 0 ? key_score(k) >= a.rerank_floor : node == only_node;
             }
             const unsigned long long tm = __ballot(take);
             const int m = __popcll(tm);
@@ -1799,6 +1877,20 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
     for (int i = lane; i < nres; i += JV_WAVE) above += key_score(pool[i]) >= a.rerank_floor ? 1 : 0;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) above += __shfl_xor(above, o, JV_WAVE);
+    if (above == 0 && nres >= 2 && key_score(pool[0]) == key_score(pool[1])) {
+        // rerankFloor above every approximate score AND a tie at the best one: jvector rescores the first best entry of
+        // its result heap's array, which only the HBM-scratch rung reconstructs (replay_first_best)
+        if (lane == 0) {
+            a.out_flags[qi] = (int32_t)(JV_FLAG_OVERFLOW | (6u << 8));
+            a.out_count[qi] = 0;
+        }
+        for (int i = lane; i < topK; i += JV_WAVE) {
+            o_nodes[i] = -1;
+            if (o_docs) o_docs[i] = -1;
+            o_scores[i] = 0.0f;
+        }
+        return;
+    }
     for (int b0 = 0; b0 < nres; b0 += JV_WAVE) {
         const int i = b0 + lane;
         bool take = false;

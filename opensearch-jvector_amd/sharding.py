@@ -2,7 +2,7 @@
 
 Shard g owns docs [g*n/G, (g+1)*n/G) with its own graph, entry node and ord->doc map (global doc ids);
 there is no traversal-time communication.  Per batch every rank searches all queries on its shard, then ONE
-all-gather of k x (doc, score) per query and a k-way merge by (score desc, doc asc) — the same shape as
+all-gather of k x (doc, score) 8-byte pairs per query and a k-way merge by (score desc, doc asc) — the same shape as
 Lucene's per-leaf search + TopDocs.merge that already wraps this path in the reference.
 
 The collective is torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests);
@@ -18,24 +18,24 @@ def shard_range(n_total: int, world: int, rank: int):
     return lo, hi
 
 
-def gather_topk(dist, torch, docs, scores, world: int, out_docs=None, out_scores=None):
-    """all-gather per-shard top-k lists.  docs/scores: [nq][k] -> [nq][world*k] (shard-major per query)."""
+def gather_topk(dist, torch, docs, scores, world: int, buf=None):
+    """ONE all-gather of the per-shard top-k lists as 8-byte (doc, score bits) pairs.
+    docs/scores: [nq][k] -> ([nq][world*k] docs, [nq][world*k] scores), shard-major per query.
+    `buf` (optional, [world][nq][k][2] int32 on the same device) avoids a per-call allocation."""
     nq, k = docs.shape
-    if out_docs is None:
-        out_docs = torch.empty((world, nq, k), dtype=docs.dtype, device=docs.device)
-        out_scores = torch.empty((world, nq, k), dtype=scores.dtype, device=scores.device)
+    pairs = torch.stack((docs.to(torch.int32), scores.contiguous().view(torch.int32)), dim=-1).contiguous()  # [nq][k][2]
+    if buf is None or tuple(buf.shape) != (world, nq, k, 2):
+        buf = torch.empty((world, nq, k, 2), dtype=torch.int32, device=docs.device)
     if docs.is_cuda and dist.get_backend() == "gloo":  # debug path (several ranks on one GPU): stage through the host
         torch.cuda.current_stream(docs.device).synchronize()
-        hd, hs = torch.empty(out_docs.shape, dtype=docs.dtype), torch.empty(out_scores.shape, dtype=scores.dtype)
-        dist.all_gather_into_tensor(hd.view(-1), docs.contiguous().view(-1).cpu())
-        dist.all_gather_into_tensor(hs.view(-1), scores.contiguous().view(-1).cpu())
-        out_docs.copy_(hd)
-        out_scores.copy_(hs)
+        hb = torch.empty(buf.shape, dtype=torch.int32)
+        dist.all_gather_into_tensor(hb.view(-1), pairs.view(-1).cpu())
+        buf.copy_(hb)
     else:
-        dist.all_gather_into_tensor(out_docs.view(-1), docs.contiguous().view(-1))
-        dist.all_gather_into_tensor(out_scores.view(-1), scores.contiguous().view(-1))
-    gd = out_docs.permute(1, 0, 2).reshape(nq, world * k).contiguous()
-    gs = out_scores.permute(1, 0, 2).reshape(nq, world * k).contiguous()
+        dist.all_gather_into_tensor(buf.view(-1), pairs.view(-1))
+    g = buf.permute(1, 0, 2, 3).reshape(nq, world * k, 2)
+    gd = g[..., 0].contiguous()
+    gs = g[..., 1].contiguous().view(torch.float32)
     return gd, gs
 
 

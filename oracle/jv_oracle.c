@@ -133,12 +133,10 @@ void jvo_pq_sub_layout(int d, int M, const int32_t* sub_sizes, int32_t* sizes, i
 
 /* lut[m*256 + c] = dot(q'_m, codebook[m][c]) (DOT/COSINE) or sum (q'_m - codebook[m][c])^2 (L2),
  * a sequential fmaf chain over the subspace; q' = q - globalCentroid when a centroid is present. */
-void jvo_pq_build_lut(const jv_index_desc* ix, const float* q, float* lut) {
+static void pq_build_lut_with(const jv_index_desc* ix, const float* q, float* lut, int32_t* sizes, float* qc) {
     int M = ix->pq_M, K = ix->pq_K, d = ix->d;
-    int32_t* sizes = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)M);
     int32_t* offs = sizes + M;
     jvo_pq_sub_layout(d, M, ix->pq_sub_sizes, sizes, offs);
-    float* qc = (float*)malloc(sizeof(float) * (size_t)d);
     for (int i = 0; i < d; i++) qc[i] = ix->pq_centroid ? q[i] - ix->pq_centroid[i] : q[i];
     const float* cb = ix->pq_codebooks;
     for (int m = 0; m < M; m++) {
@@ -161,6 +159,12 @@ void jvo_pq_build_lut(const jv_index_desc* ix, const float* q, float* lut) {
         }
         cb += (size_t)K * s;
     }
+}
+
+void jvo_pq_build_lut(const jv_index_desc* ix, const float* q, float* lut) {
+    int32_t* sizes = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)ix->pq_M);
+    float* qc = (float*)malloc(sizeof(float) * (size_t)ix->d);
+    pq_build_lut_with(ix, q, lut, sizes, qc);
     free(qc);
     free(sizes);
 }
@@ -233,6 +237,18 @@ static void lh_init(lheap* q, int cap) {
     q->h = (int64_t*)malloc(sizeof(int64_t) * (size_t)(q->cap + 1));
 }
 static void lh_free(lheap* q) { free(q->h); }
+/* re-use a heap's storage for the next query (searcher scratch, below) */
+static void lh_reset(lheap* q, int cap) {
+    if (!q->h) {
+        lh_init(q, cap);
+        return;
+    }
+    q->size = 0;
+    if (q->cap < cap) {
+        q->cap = cap;
+        q->h = (int64_t*)realloc(q->h, sizeof(int64_t) * (size_t)(q->cap + 1));
+    }
+}
 static void lh_up(lheap* q, int i) {
     int64_t v = q->h[i];
     int j = i >> 1;
@@ -339,7 +355,9 @@ typedef struct {
     float* norm_lut;       /* PQ cosine */
     const uint64_t* accept;
     int64_t accept_docs;
-    uint64_t* visited;     /* n bits */
+    uint64_t* visited;     /* n bits (thread scratch, all zero between queries) */
+    int32_t* touched;      /* indices of the visited words this query made non-zero */
+    int n_touched, cap_touched;
     lheap candidates;      /* MAX heap: stores -key */
     lheap results;         /* bounded MIN heap (approximateResults) */
     int64_t* evicted;      /* evictedResults keys */
@@ -372,6 +390,13 @@ static inline int visited_add(searcher* s, int node) {
     uint64_t bit = 1ull << (node & 63);
     uint64_t* w = &s->visited[node >> 6];
     if (*w & bit) return 0;
+    if (*w == 0) { /* remember the word so that the set is cleared in O(visited), not O(n) */
+        if (s->n_touched == s->cap_touched) {
+            s->cap_touched = s->cap_touched ? s->cap_touched * 2 : 4096;
+            s->touched = (int32_t*)realloc(s->touched, sizeof(int32_t) * (size_t)s->cap_touched);
+        }
+        s->touched[s->n_touched++] = node >> 6;
+    }
     *w |= bit;
     return 1;
 }
@@ -459,6 +484,32 @@ static int cmp_key_desc(const void* a, const void* b) {
     return x > y ? -1 : x < y ? 1 : 0;
 }
 
+/* Per-thread reusable searcher state, as jvector keeps inside a GraphSearcher (one per Lucene search
+ * thread, re-used across queries): visited bitset cleared through the list of touched words, both
+ * heaps, the evicted list, the PQ tables and the result buffer.  No allocation per query once warm. */
+typedef struct {
+    uint64_t* visited;
+    size_t visited_words;
+    int32_t* touched;
+    int cap_touched;
+    lheap candidates, results;
+    int64_t* evicted;
+    int cap_evicted;
+    float* lut;
+    size_t lut_floats;
+    float* norm_lut;
+    size_t norm_floats;
+    const float* norm_for_codebooks; /* norm_lut is a function of the index only: cached per (codebooks, M, K) */
+    int norm_M, norm_K;
+    int32_t* sizes;
+    int sizes_cap;
+    float* qc;
+    int qc_cap;
+    int64_t* fin;
+    int fin_cap;
+} jvo_scratch;
+static _Thread_local jvo_scratch tls_scratch;
+
 int jvo_search(const jv_index_desc* ix, const float* query, int32_t topK, int32_t rerankK,
                float threshold, float rerankFloor, const uint64_t* accept_doc_words,
                int64_t accept_num_docs, int32_t* out_nodes, int32_t* out_docs, float* out_scores,
@@ -473,6 +524,7 @@ int jvo_search(const jv_index_desc* ix, const float* query, int32_t topK, int32_
     if (out_stats) memset(out_stats, 0, sizeof(int32_t) * JV_NUM_STATS);
     if (ix->n <= 0 || ix->entry_node < 0 || topK == 0) return JV_OK;
 
+    jvo_scratch* sc = &tls_scratch;
     searcher s;
     memset(&s, 0, sizeof(s));
     s.ix = ix;
@@ -481,16 +533,57 @@ int jvo_search(const jv_index_desc* ix, const float* query, int32_t topK, int32_
     s.accept_docs = accept_num_docs;
     s.qnorm2 = ix->similarity == JV_SIM_COSINE ? jvo_raw_dot(query, query, ix->d) : 0.0f;
     if (ix->pq_M > 0) {
-        s.lut = (float*)malloc(sizeof(float) * 256 * (size_t)ix->pq_M);
-        jvo_pq_build_lut(ix, query, s.lut);
+        const size_t lf = 256 * (size_t)ix->pq_M;
+        if (sc->lut_floats < lf) {
+            free(sc->lut);
+            sc->lut = (float*)malloc(sizeof(float) * lf);
+            sc->lut_floats = lf;
+        }
+        if (sc->sizes_cap < 2 * ix->pq_M) {
+            free(sc->sizes);
+            sc->sizes = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)ix->pq_M);
+            sc->sizes_cap = 2 * ix->pq_M;
+        }
+        if (sc->qc_cap < ix->d) {
+            free(sc->qc);
+            sc->qc = (float*)malloc(sizeof(float) * (size_t)ix->d);
+            sc->qc_cap = ix->d;
+        }
+        s.lut = sc->lut;
+        pq_build_lut_with(ix, query, s.lut, sc->sizes, sc->qc);
         if (ix->similarity == JV_SIM_COSINE) {
-            s.norm_lut = (float*)malloc(sizeof(float) * 256 * (size_t)ix->pq_M);
-            jvo_pq_build_norm_lut(ix, s.norm_lut);
+            if (sc->norm_floats < lf) {
+                free(sc->norm_lut);
+                sc->norm_lut = (float*)malloc(sizeof(float) * lf);
+                sc->norm_floats = lf;
+                sc->norm_for_codebooks = NULL;
+            }
+            if (sc->norm_for_codebooks != ix->pq_codebooks || sc->norm_M != ix->pq_M || sc->norm_K != ix->pq_K) {
+                jvo_pq_build_norm_lut(ix, sc->norm_lut);
+                sc->norm_for_codebooks = ix->pq_codebooks;
+                sc->norm_M = ix->pq_M;
+                sc->norm_K = ix->pq_K;
+            }
+            s.norm_lut = sc->norm_lut;
         }
     }
-    s.visited = (uint64_t*)calloc(((size_t)ix->n + 63) / 64, sizeof(uint64_t));
-    lh_init(&s.candidates, 1024);
-    lh_init(&s.results, rerankK > 0 ? rerankK : 1);
+    {
+        const size_t words = ((size_t)ix->n + 63) / 64;
+        if (sc->visited_words < words) {
+            free(sc->visited);
+            sc->visited = (uint64_t*)calloc(words, sizeof(uint64_t));
+            sc->visited_words = words;
+        }
+    }
+    s.visited = sc->visited;
+    s.touched = sc->touched;
+    s.cap_touched = sc->cap_touched;
+    s.evicted = sc->evicted;
+    s.cap_evicted = sc->cap_evicted;
+    lh_reset(&sc->candidates, 1024);
+    lh_reset(&sc->results, rerankK > 0 ? rerankK : 1);
+    s.candidates = sc->candidates;
+    s.results = sc->results;
 
     /* initializeInternal: score the entry point, mark visited (not counted), push */
     int ep = ix->entry_node;
@@ -510,7 +603,12 @@ int jvo_search(const jv_index_desc* ix, const float* query, int32_t topK, int32_
     search_one_layer(&s, rerankK, threshold, 0, 0);
 
     /* result assembly (App. A.3) */
-    int64_t* fin = (int64_t*)malloc(sizeof(int64_t) * (size_t)(s.results.size + 1));
+    if (sc->fin_cap < s.results.size + 1) {
+        free(sc->fin);
+        sc->fin_cap = s.results.size + 1 + 256;
+        sc->fin = (int64_t*)malloc(sizeof(int64_t) * (size_t)sc->fin_cap);
+    }
+    int64_t* fin = sc->fin;
     int nfin = 0;
     if (!s.lut) {
         /* exact provider: pop down to topK (worst first) => keep the topK largest keys */
@@ -553,13 +651,14 @@ int jvo_search(const jv_index_desc* ix, const float* query, int32_t topK, int32_
         out_stats[JV_STAT_EXPANDED] = s.expanded;
         out_stats[JV_STAT_EXPANDED_BASE] = s.expanded_base;
     }
-    free(fin);
-    free(s.evicted);
-    lh_free(&s.candidates);
-    lh_free(&s.results);
-    free(s.visited);
-    free(s.lut);
-    free(s.norm_lut);
+    /* hand the (possibly re-allocated) buffers back to the thread's scratch; clear the visited set */
+    for (int i = 0; i < s.n_touched; i++) s.visited[s.touched[i]] = 0;
+    sc->touched = s.touched;
+    sc->cap_touched = s.cap_touched;
+    sc->evicted = s.evicted;
+    sc->cap_evicted = s.cap_evicted;
+    sc->candidates = s.candidates;
+    sc->results = s.results;
     return JV_OK;
 }
 

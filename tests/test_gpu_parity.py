@@ -502,3 +502,45 @@ def test_headline_dimensions_parity(pkg, pyoracle, d, M):
         _assert_same(gpu.search_batch(q, 10, 100, accept=words, accept_num_docs=n),
                      orc.search_batch(q, 10, 100, accept=words, accept_num_docs=n), f"filtered fused d={d} M={M} sim={sim}")
         gpu.close()
+
+
+@pytest.mark.parametrize("seed", [31, 32, 33])
+def test_rerank_floor_above_all_scores_with_tied_best(pkg, pyoracle, seed):
+    """rerankFloor above EVERY approximate score: jvector's NodeQueue.rerank then rescores only the best approximate
+    entry — with several entries tied at that best score, the first one in its result heap's ARRAY order (the oracle
+    keeps a literal binary heap, oracle/jv_oracle.c "NodeQueue.rerank").  Grid-valued vectors and duplicated vectors
+    make such ties the norm; the on-chip rungs hand the case to the HBM-scratch rung, which replays the heap."""
+    b, bl = pkg.binding, pkg.builder
+    rng = np.random.default_rng(seed)
+    n, d, R = 500, 4, 16
+    grid = rng.integers(0, 3, size=(n, d)).astype(np.float32)
+    adj = np.stack([rng.permutation(n)[:R] for _ in range(n)]).astype(np.int32)
+    q = rng.integers(0, 3, size=(48, d)).astype(np.float32) + np.float32(0.5) * (rng.random((48, d)) < 0.3)
+    for sim in (0, 1):
+        cb, cen, codes, K = bl.pq_train_encode_cpu(grid, 2, sim)
+        ixq = b.IndexData(vectors=grid, adj=adj, entry_node=int(rng.integers(0, n)), similarity=sim, pq_codebooks=cb,
+                          pq_centroid=cen, pq_codes=codes, pq_M=2, pq_K=K)
+        orc = pyoracle.Oracle(b, ixq)
+        for flags, name in ((0, "pq"), (b.DESC_FUSED_ADC, "pq-fused")):
+            gpu = b.GpuIndex(ixq, flags=flags)
+            for k, rk in ((1, 1), (1, 4), (3, 8), (5, 16), (10, 40), (10, 100)):
+                want = orc.search_batch(q, k, rk, rerank_floor=1e9)
+                assert (want.stats[:, 1] <= 1).all()
+                _assert_same(gpu.search_batch(q, k, rk, rerank_floor=1e9), want, f"{name} sim={sim} seed={seed} k={k} rk={rk}")
+            # with a doc filter as well (filtered fused kernel -> ladder -> replay over the ACCEPTED pops)
+            words = b.accept_words(np.nonzero(rng.random(n) < 0.6)[0], n)
+            want = orc.search_batch(q, 5, 16, rerank_floor=1e9, accept=words, accept_num_docs=n)
+            _assert_same(gpu.search_batch(q, 5, 16, rerank_floor=1e9, accept=words, accept_num_docs=n), want, f"{name} filtered sim={sim}")
+            gpu.close()
+    # duplicated vectors (identical PQ codes => identical approximate scores), built graph
+    uniq = rng.random((300, 32)).astype(np.float32)
+    base = np.repeat(uniq, 6, axis=0)[rng.permutation(1800)]
+    q2 = rng.random((32, 32)).astype(np.float32)
+    ix = bl.build_index_cpu(base, 0, R=32, L=60, pq_M=16)
+    orc = pyoracle.Oracle(b, ix)
+    for flags in (0, b.DESC_FUSED_ADC):
+        gpu = b.GpuIndex(ix, flags=flags)
+        for k, rk in ((1, 1), (10, 30), (10, 100)):
+            want = orc.search_batch(q2, k, rk, rerank_floor=50.0)
+            _assert_same(gpu.search_batch(q2, k, rk, rerank_floor=50.0), want, f"dups flags={flags} k={k} rk={rk}")
+        gpu.close()

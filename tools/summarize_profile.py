@@ -63,7 +63,7 @@ def main(src, name):
                   f"* **HBM bytes per launch = {hbm / 1e9:.3f} GB** vs algorithmic {bench['roofline']['algorithmic_bytes_per_launch'] / 1e9:.3f} GB",
                   ""]
         tj = {"workload": bench["config"]["workload"].split(":")[0], "n": bench["config"]["docs_per_gpu"], "batch": B,
-              "rerankK": bench["config"]["rerankK"], "hbm_bytes_per_launch": round(hbm, 1),
+              "rerankK": bench["config"]["rerankK"], "dist": bench["config"].get("distribution", "aligned"), "hbm_bytes_per_launch": round(hbm, 1),
               "fetch_size_kib": traffic["FETCH_SIZE"], "write_size_kib": traffic.get("WRITE_SIZE"), "source": f"profiles/{name}"}
         path = os.path.join(root, "profiles", "traffic_latest.json")
         allj = {}
