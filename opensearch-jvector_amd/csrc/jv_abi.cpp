@@ -34,6 +34,11 @@ hipError_t jvk_launch_score_ordinals(const JvIndexDev* ix, const float* d_query,
                                      int count, float* d_out, hipStream_t s);
 hipError_t jvk_launch_merge_topk(const int32_t* d_docs, const float* d_scores, int nq, int lists, int k,
                                  int32_t* d_out_docs, float* d_out_scores, hipStream_t s);
+// register-pool kernel (jv_kernels_pqr.hip)
+hipError_t jvk_pqr_set_max_lds(int bytes);
+int jvk_pqr_capacity(void);
+int jvk_pqr_blocks_per_cu(const JvIndexDev* ix, int lds_bytes);
+hipError_t jvk_launch_search_pqr(const JvIndexDev* ix, const JvSearchArgs* a, int lds_bytes, int blocks, hipStream_t s);
 }
 
 namespace {
@@ -68,6 +73,7 @@ std::atomic<int64_t> opt_force_general{0};
 std::atomic<int64_t> opt_no_escalation{0};
 std::atomic<int64_t> opt_dbg_ptr{0};
 std::atomic<int64_t> opt_no_pqf{0};
+std::atomic<int64_t> opt_no_pqr{0};  // diagnostics: use the round-1 LDS-pool kernel instead of the register-pool kernel
 std::atomic<int64_t> opt_pqf_only{0};  // diagnostics: skip the ladder after the PQF launch (flags stay visible)
 std::atomic<int64_t> opt_spill_tables{2048};  // per context: 2048 x 8192 x 4 B = 64 MB (a launch that needs more falls to the ladder)
 std::atomic<int64_t> opt_spill_slots{8192};
@@ -111,6 +117,9 @@ struct Ctx {
     int big_blocks = 0;
     int big_cand_cap = 0;
     size_t big_words = 0;
+    // register-pool kernel: per-resident-workgroup expansion logs
+    int32_t* pqr_log = nullptr;
+    size_t pqr_log_ints = 0;
 };
 
 // One caller's jv_search waiting to be served.  Lives on the caller's stack.
@@ -148,6 +157,8 @@ struct jv_index {
     int device = 0;
     bool build_client = false;  // JV_DESC_BUILD_CLIENT: searches are launched under the builder's kernel name
     JvIndexDev dev{};
+    int cu_count = 256;
+    std::vector<int32_t> pq_sub_off;  // host copy of dev.pq_sub_off
     jv_index_info info{};
     std::vector<void*> owned;  // device allocations to free
     std::mutex mu;
@@ -207,6 +218,7 @@ void ctx_destroy(Ctx* c) {
     hipFree(c->big_cand);
     hipFree(c->work_counter);
     hipFree(c->spill);
+    hipFree(c->pqr_log);
     if (c->last_use) hipEventDestroy(c->last_use);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -278,7 +290,9 @@ int ensure_big(jv_index* ix, Ctx* c, int rk) {
     int cap = (int)opt_big_cand_cap.load();
     int res_cap = ((rk + 1) & ~1);
     if (cap < 4 * rk) cap = 4 * rk;
-    if (cap > ix->dev.n + 64) cap = ix->dev.n + 64;  // the candidate queue never holds more than every node once
+    // the candidate queue never holds more than every node once; the addTopCandidate log of the PQ rungs (one entry per
+    // expanded node at most) shares the area
+    if (cap > 2 * ix->dev.n + 64) cap = 2 * ix->dev.n + 64;
     cap += res_cap;
     size_t words = ((size_t)ix->dev.n + 31) / 32;
     if (words == 0) words = 1;
@@ -372,9 +386,47 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
     const bool filtered = d_accept != nullptr;
     // filtered variant: single-pass blocks, ordinals below 2^30 (one key bit carries "accepted")
     const bool pqf_shape = filtered ? (thr <= 0.0f && ix->dev.R * ix->dev.pq_lanes <= JV_WAVE && ix->dev.n < (1 << 30)) : g.pool;
-    if (!force_big && pq && pqf_shape && ix->dev.pq_fused && ix->dev.num_upper == 0 && ix->dev.R <= JV_WAVE && ix->dev.R * ix->dev.pq_lanes <= 4 * JV_WAVE &&
-        (ix->dev.R * ix->dev.pq_lanes + JV_WAVE - 1) / JV_WAVE <= ix->dev.pq_lanes &&
-        rk + 64 + ix->dev.R <= 1024 && opt_no_pqf.load() == 0) {
+    const bool pqf_index = pq && ix->dev.pq_fused && ix->dev.num_upper == 0 && ix->dev.R <= JV_WAVE && ix->dev.R * ix->dev.pq_lanes <= 4 * JV_WAVE &&
+                           (ix->dev.R * ix->dev.pq_lanes + JV_WAVE - 1) / JV_WAVE <= ix->dev.pq_lanes;
+    // headline path: the register-pool kernel (jv_kernels_pqr.hip): no filter, threshold <= 0, pool of rk + 64 boundary
+    // ties + one expansion's R new keys in at most 2 048 register slots; LDS = the look-up table only
+    if (!force_big && !filtered && g.pool && pqf_index && rk + 64 + ix->dev.R <= jvk_pqr_capacity() && opt_no_pqf.load() == 0 &&
+        opt_no_pqr.load() == 0) {
+        JvSearchArgs ap = a;
+        const int lut_b = ix->dev.pq_M * 256 * 4;
+        const int qc_b = ix->dev.nch * 64 * 4;
+        ap.cand_cap = rk + 64 + ix->dev.R;
+        ap.pqr_log_cap = (3 * rk + 64 + 3) & ~3;
+        // the centred query is only needed while the table is built: it may sit in the table's own tail when no row
+        // is written over dimensions a later row still reads (row m covers floats [256 m, 256 m + 256) of the table)
+        bool alias = qc_b <= lut_b;
+        const int off_f = ix->dev.pq_M * 256 - ix->dev.nch * 64;
+        for (int m = 0; alias && m + 1 < ix->dev.pq_M; m++)
+            if ((m + 1) * 256 - off_f > ix->pq_sub_off[(size_t)m + 1]) alias = false;
+        ap.pqr_qc_off = alias ? lut_b - qc_b : lut_b;
+        int lds = alias ? lut_b : lut_b + qc_b;
+        const int rerank_b = qc_b + JV_TODO * 8 + ((rk + 1) & ~1) * 8 + rk * 4;
+        if (lds < rerank_b) lds = rerank_b;
+        lds = (lds + 15) & ~15;
+        if (lds <= kMaxLds) {
+            const int per_cu = jvk_pqr_blocks_per_cu(&ix->dev, lds);
+            int blocks = ix->cu_count * per_cu;
+            if (blocks > nq) blocks = nq;
+            const size_t need = (size_t)blocks * (size_t)ap.pqr_log_cap;
+            if (need > c->pqr_log_ints) {
+                if (c->pqr_log) HIPCHK(hipFree(c->pqr_log));
+                c->pqr_log = nullptr;
+                c->pqr_log_ints = 0;
+                HIPCHK(hipMalloc((void**)&c->pqr_log, need * sizeof(int32_t)));
+                c->pqr_log_ints = need;
+            }
+            ap.pqr_log = c->pqr_log;
+            ap.pqr_counter = c->work_counter + 6;
+            HIPCHK(jvk_launch_search_pqr(&ix->dev, &ap, lds, blocks, stream));
+            pqf = true;
+        }
+    }
+    if (!pqf && !force_big && pqf_index && pqf_shape && rk + 64 + ix->dev.R <= 1024 && opt_no_pqf.load() == 0) {
         JvSearchArgs ap = a;
         const int lut_b = ix->dev.pq_M * 256 * 4;
         ap.cand_cap = (rk + 64 + ix->dev.R + 1) & ~1;  // pool entries: rk + 64 boundary ties + one merge of <= R new keys
@@ -465,6 +517,7 @@ int jv_set_option(const char* name, int64_t value) {
     else if (n == "no_escalation") opt_no_escalation = value;
     else if (n == "dbg_ptr") opt_dbg_ptr = value;
     else if (n == "no_pqf") opt_no_pqf = value;
+    else if (n == "no_pqr") opt_no_pqr = value;
     else if (n == "pqf_only") opt_pqf_only = value;
     else if (n == "spill_tables") opt_spill_tables = value;
     else if (n == "spill_slots") opt_spill_slots = value;
@@ -623,6 +676,7 @@ int jv_index_create(const jv_index_desc* desc, jv_index** out) {
             TRY(dev_alloc(ix, &doff, (size_t)M + 1));
             TRYHIP(hipMemcpy(doff, off.data(), (size_t)(M + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
             D.pq_sub_off = doff;
+            ix->pq_sub_off = off;
             // codebooks (host) -> transposed [dim][256]
             std::vector<float> cbT((size_t)d * 256, 0.0f);
             std::vector<float> norm;
@@ -683,6 +737,11 @@ int jv_index_create(const jv_index_desc* desc, jv_index** out) {
             ix->info.fused_adc = 1;
         }
         TRYHIP(jvk_set_max_lds(kMaxLds));
+        TRYHIP(jvk_pqr_set_max_lds(kMaxLds));
+        {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, desc->device) == hipSuccess && prop.multiProcessorCount > 0) ix->cu_count = prop.multiProcessorCount;
+        }
         TRY(ctx_create(ix, &ix->async_ctx));
     }
     ix->info.n = n;

@@ -72,6 +72,11 @@ struct JvSearchArgs {
     int32_t spill_tables;
     int32_t* spill_counter;  // zeroed per call
     int64_t* dbg;            // diagnostic build (-DJV_STAMPS) only: 8 cycle accumulators; nullptr in the product
+    // register-pool kernel (jv_kernels_pqr.hip): persistent grid
+    int32_t* pqr_log;        // [blocks][pqr_log_cap] expansion log scratch
+    int32_t pqr_log_cap;
+    int32_t pqr_qc_off;      // LDS byte offset of the centred query during the LUT build
+    int32_t* pqr_counter;    // query dequeue counter (zeroed per call)
 };
 
 #define JV_FLAG_OVERFLOW 0x80000000u /* on-chip scratch overflow: query must be re-run on the big path */

@@ -15,9 +15,7 @@ import bench
 
 n = int(os.environ.get("N", 2_000_000)); d = 768; M = 32; rk = int(os.environ.get("RK", 200)); B = 65536
 dev = torch.device("cuda", 0)
-zc, Bl, Bg = bench.make_block_generators(torch, d, dev, max(64, min(4096, n // 256)), M=M, per=2)
-base = bench.gen_rows_block(torch, n, d, 42, 0, zc, Bl, Bg, 0.35, 0.1, 0.005, False, dev)
-q = bench.gen_rows_block(torch, B, d, 43, 0, zc, Bl, Bg, 0.35, 0.1, 0.005, False, dev)
+base, q = bench.make_pq_data(torch, os.environ.get("DIST", "rotated"), n, B, d, M, 0, n, False, dev)
 adj, entry = gb.build_graph_gpu(torch, base, 0, R=32, L=100, verbose=False)
 pq = gb.pq_train_encode_gpu(torch, base, M, 0)
 for fused in (1,):
@@ -25,7 +23,7 @@ for fused in (1,):
                                     pq_codebooks=pq["codebooks"], pq_centroid=pq["centroid"], pq_codes_ptr=pq["codes"].data_ptr(),
                                     borrow=True, extra_flags=(b.DESC_FUSED_ADC if fused else 0))
     ix = b.GpuIndex(desc=desc, keepalive=keep, flags=b.DESC_BORROW)
-    dbg = torch.zeros(8, dtype=torch.int64, device=dev)
+    dbg = torch.zeros(16, dtype=torch.int64, device=dev)
     o = [torch.empty((B, 10), dtype=torch.int32, device=dev), torch.empty((B, 10), dtype=torch.int32, device=dev),
          torch.empty((B, 10), dtype=torch.float32, device=dev), torch.empty((B,), dtype=torch.int32, device=dev),
          torch.empty((B, 4), dtype=torch.int32, device=dev), torch.empty((B,), dtype=torch.int32, device=dev)]
@@ -39,10 +37,14 @@ for fused in (1,):
     b.set_option("dbg_ptr", 0)
     v = dbg.cpu().numpy().astype(np.float64)
     st = o[4].cpu().numpy().astype(np.float64).mean(0)
-    names = ["find (masks, pool reads)", "block wait", "ADC + prefetch issue", "rank search + dedupe", "new-key ranks + shift + insert", "trim + mask rebuild", "visited-count pass", "exposed prefetch wait (loop top)"]
-    cyc = v.copy(); hits = 0
-    print(f"fused={fused}: {B / dt:.0f} QPS (stamped build), expansions/query {st[2]:.1f}, prefetch hit rate {hits / (st[2] * B):.2f}")
+    # register-pool kernel (jv_kernels_pqr.hip) stamp slots; JV_OPT no_pqr=1 shows the round-1 LDS-pool kernel's slots instead
+    names = ["find best/runner-up + block request", "mark expanded + log", "ADC + prefetch issue", "rank + dedupe + insert", "boundary + trim", "loop exit",
+             "visited-count pass", "LUT build + entry point"]
+    cyc = v[:8].copy()
+    ne = max(st[2], 1) * B
+    print(f"fused={fused} rk={rk}: {B / dt:.0f} QPS (stamped build), expansions/query {st[2]:.1f}, visited/query {st[0]:.1f}")
     for i, nme in enumerate(names):
-        if True:
-            print(f"   {nme:24s} {100 * cyc[i] / cyc.sum():5.1f} %   {cyc[i] / B / max(st[2], 1):8.0f} cycles/expansion")
+        print(f"   {nme:36s} {100 * cyc[i] / cyc.sum():5.1f} %   {cyc[i] / ne:8.0f} cycles/expansion")
+    print(f"   per expansion: candidates past the boundary {v[8] / ne:.2f}, already-in-pool (chunk-first) {v[9] / ne:.2f}, already-in-pool {v[10] / ne:.2f}, "
+          f"inserts {v[11] / ne:.2f}, whole chunks shifted per insert {v[12] / max(v[11], 1):.2f}")
     ix.close()
