@@ -207,7 +207,7 @@ def recall_of(found_docs, truth):
 
 
 # ------------------------------------------------------------------------------------------------
-SWEEP = list(range(20, 200, 10)) + [200, 225, 250, 300, 350, 400, 500, 600, 700, 800, 900]
+SWEEP = list(range(20, 200, 10)) + [200, 225, 250, 300, 350, 400, 500, 600, 700, 800, 900, 1000, 1100, 1200, 1300, 1400, 1600, 1800, 2000, 2400, 2800, 3200]
 JV_FLAG_FAILED = 0x40000000
 JV_FLAG_OVERFLOW = 0x80000000
 

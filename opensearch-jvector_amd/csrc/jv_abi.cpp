@@ -39,6 +39,11 @@ hipError_t jvk_pqr_set_max_lds(int bytes);
 int jvk_pqr_capacity(void);
 int jvk_pqr_blocks_per_cu(const JvIndexDev* ix, int lds_bytes);
 hipError_t jvk_launch_search_pqr(const JvIndexDev* ix, const JvSearchArgs* a, int lds_bytes, int blocks, hipStream_t s);
+// LDS-pool persistent kernel (jv_kernels_pqp.hip): the headline path
+hipError_t jvk_pqp_set_max_lds(int bytes);
+int jvk_pqp_max_entries(void);
+int jvk_pqp_blocks_per_cu(const JvIndexDev* ix, int cap, int lds_bytes);
+hipError_t jvk_launch_search_pqp(const JvIndexDev* ix, const JvSearchArgs* a, int lds_bytes, int blocks, hipStream_t s);
 }
 
 namespace {
@@ -73,7 +78,8 @@ std::atomic<int64_t> opt_force_general{0};
 std::atomic<int64_t> opt_no_escalation{0};
 std::atomic<int64_t> opt_dbg_ptr{0};
 std::atomic<int64_t> opt_no_pqf{0};
-std::atomic<int64_t> opt_no_pqr{0};  // diagnostics: use the round-1 LDS-pool kernel instead of the register-pool kernel
+std::atomic<int64_t> opt_no_pqr{1};  // diagnostics: 0 = use the register-pool kernel (measured slower than pqp; kept for comparison)
+std::atomic<int64_t> opt_no_pqp{0};  // diagnostics: 1 = skip the persistent LDS-pool kernel
 std::atomic<int64_t> opt_pqf_only{0};  // diagnostics: skip the ladder after the PQF launch (flags stay visible)
 std::atomic<int64_t> opt_spill_tables{2048};  // per context: 2048 x 8192 x 4 B = 64 MB (a launch that needs more falls to the ladder)
 std::atomic<int64_t> opt_spill_slots{8192};
@@ -388,9 +394,46 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
     const bool pqf_shape = filtered ? (thr <= 0.0f && ix->dev.R * ix->dev.pq_lanes <= JV_WAVE && ix->dev.n < (1 << 30)) : g.pool;
     const bool pqf_index = pq && ix->dev.pq_fused && ix->dev.num_upper == 0 && ix->dev.R <= JV_WAVE && ix->dev.R * ix->dev.pq_lanes <= 4 * JV_WAVE &&
                            (ix->dev.R * ix->dev.pq_lanes + JV_WAVE - 1) / JV_WAVE <= ix->dev.pq_lanes;
-    // headline path: the register-pool kernel (jv_kernels_pqr.hip): no filter, threshold <= 0, pool of rk + 64 boundary
+    // headline path: the persistent LDS-pool kernel (jv_kernels_pqp.hip): no filter, threshold <= 0; LDS = look-up table +
+    // pool of rk + 64 boundary ties + one expansion's R new keys (+ 1 sentinel slot); the expansion log lives in HBM
+    if (!force_big && !filtered && g.pool && pqf_index && rk + 64 + ix->dev.R <= jvk_pqp_max_entries() && opt_no_pqf.load() == 0 &&
+        opt_no_pqp.load() == 0) {
+        JvSearchArgs ap = a;
+        const int lut_b = ix->dev.pq_M * 256 * 4;
+        const int qc_b = ix->dev.nch * 64 * 4;
+        ap.cand_cap = rk + 64 + ix->dev.R;
+        ap.pqr_log_cap = (3 * rk + 64 + 3) & ~3;
+        bool alias = qc_b <= lut_b;
+        const int off_f = ix->dev.pq_M * 256 - ix->dev.nch * 64;
+        for (int m = 0; alias && m + 1 < ix->dev.pq_M; m++)
+            if ((m + 1) * 256 - off_f > ix->pq_sub_off[(size_t)m + 1]) alias = false;
+        const int rerank_b = qc_b + JV_TODO * 8 + ((rk + 1) & ~1) * 8;   // after the search, in front of the pool
+        ap.pqr_pool_off = (std::max(lut_b, rerank_b) + 15) & ~15;
+        int lds = ap.pqr_pool_off + (ap.cand_cap + 1) * 8;
+        ap.pqr_qc_off = alias ? lut_b - qc_b : ((lds + 15) & ~15);
+        if (!alias) lds = ap.pqr_qc_off + qc_b;
+        lds = (lds + 15) & ~15;
+        if (lds <= kMaxLds) {
+            const int per_cu = jvk_pqp_blocks_per_cu(&ix->dev, ap.cand_cap, lds);
+            int blocks = ix->cu_count * per_cu;
+            if (blocks > nq) blocks = nq;
+            const size_t need = (size_t)blocks * (size_t)ap.pqr_log_cap;
+            if (need > c->pqr_log_ints) {
+                if (c->pqr_log) HIPCHK(hipFree(c->pqr_log));
+                c->pqr_log = nullptr;
+                c->pqr_log_ints = 0;
+                HIPCHK(hipMalloc((void**)&c->pqr_log, need * sizeof(int32_t)));
+                c->pqr_log_ints = need;
+            }
+            ap.pqr_log = c->pqr_log;
+            ap.pqr_counter = c->work_counter + 6;
+            HIPCHK(jvk_launch_search_pqp(&ix->dev, &ap, lds, blocks, stream));
+            pqf = true;
+        }
+    }
+    // (comparison only, option no_pqr = 0) the register-pool kernel (jv_kernels_pqr.hip): no filter, threshold <= 0, pool of rk + 64 boundary
     // ties + one expansion's R new keys in at most 2 048 register slots; LDS = the look-up table only
-    if (!force_big && !filtered && g.pool && pqf_index && rk + 64 + ix->dev.R <= jvk_pqr_capacity() && opt_no_pqf.load() == 0 &&
+    if (!pqf && !force_big && !filtered && g.pool && pqf_index && rk + 64 + ix->dev.R <= jvk_pqr_capacity() && opt_no_pqf.load() == 0 &&
         opt_no_pqr.load() == 0) {
         JvSearchArgs ap = a;
         const int lut_b = ix->dev.pq_M * 256 * 4;
@@ -518,6 +561,7 @@ int jv_set_option(const char* name, int64_t value) {
     else if (n == "dbg_ptr") opt_dbg_ptr = value;
     else if (n == "no_pqf") opt_no_pqf = value;
     else if (n == "no_pqr") opt_no_pqr = value;
+    else if (n == "no_pqp") opt_no_pqp = value;
     else if (n == "pqf_only") opt_pqf_only = value;
     else if (n == "spill_tables") opt_spill_tables = value;
     else if (n == "spill_slots") opt_spill_slots = value;
@@ -738,6 +782,7 @@ int jv_index_create(const jv_index_desc* desc, jv_index** out) {
         }
         TRYHIP(jvk_set_max_lds(kMaxLds));
         TRYHIP(jvk_pqr_set_max_lds(kMaxLds));
+        TRYHIP(jvk_pqp_set_max_lds(kMaxLds));
         {
             hipDeviceProp_t prop;
             if (hipGetDeviceProperties(&prop, desc->device) == hipSuccess && prop.multiProcessorCount > 0) ix->cu_count = prop.multiProcessorCount;

@@ -38,9 +38,9 @@ for fused in (1,):
     v = dbg.cpu().numpy().astype(np.float64)
     st = o[4].cpu().numpy().astype(np.float64).mean(0)
     # register-pool kernel (jv_kernels_pqr.hip) stamp slots; JV_OPT no_pqr=1 shows the round-1 LDS-pool kernel's slots instead
-    names = ["find best/runner-up + block request", "mark expanded + log", "ADC + prefetch issue", "rank + dedupe + insert", "boundary + trim", "loop exit",
-             "visited-count pass", "LUT build + entry point"]
-    cyc = v[:8].copy()
+    names = ["find best/runner-up + block select", "prefetch issue + mark expanded + log", "ADC", "boundary test + rank search + dedupe", "ranks among new + shift + insert",
+             "boundary + trim", "visited-count pass", "LUT build + entry point", "rerank + top-K"]
+    cyc = np.concatenate([v[:8], v[13:14]])
     ne = max(st[2], 1) * B
     print(f"fused={fused} rk={rk}: {B / dt:.0f} QPS (stamped build), expansions/query {st[2]:.1f}, visited/query {st[0]:.1f}")
     for i, nme in enumerate(names):
