@@ -42,8 +42,9 @@ hipError_t jvk_launch_search_pqr(const JvIndexDev* ix, const JvSearchArgs* a, in
 // LDS-pool persistent kernel (jv_kernels_pqp.hip): the headline path
 hipError_t jvk_pqp_set_max_lds(int bytes);
 int jvk_pqp_max_entries(void);
-int jvk_pqp_blocks_per_cu(const JvIndexDev* ix, int cap, int lds_bytes);
-hipError_t jvk_launch_search_pqp(const JvIndexDev* ix, const JvSearchArgs* a, int lds_bytes, int blocks, hipStream_t s);
+int jvk_pqp_blocks_per_cu(const JvIndexDev* ix, int cap, int lds_bytes, int lutr);
+int jvk_pqp_lutr_ok(const JvIndexDev* ix, int cap);
+hipError_t jvk_launch_search_pqp(const JvIndexDev* ix, const JvSearchArgs* a, int lds_bytes, int blocks, int lutr, hipStream_t s);
 }
 
 namespace {
@@ -80,6 +81,7 @@ std::atomic<int64_t> opt_dbg_ptr{0};
 std::atomic<int64_t> opt_no_pqf{0};
 std::atomic<int64_t> opt_no_pqr{1};  // diagnostics: 0 = use the register-pool kernel (measured slower than pqp; kept for comparison)
 std::atomic<int64_t> opt_no_pqp{0};  // diagnostics: 1 = skip the persistent LDS-pool kernel
+std::atomic<int64_t> opt_no_lutr{0}; // diagnostics: 1 = keep the look-up table in LDS even where the register variant applies
 std::atomic<int64_t> opt_pqf_only{0};  // diagnostics: skip the ladder after the PQF launch (flags stay visible)
 std::atomic<int64_t> opt_spill_tables{2048};  // per context: 2048 x 8192 x 4 B = 64 MB (a launch that needs more falls to the ladder)
 std::atomic<int64_t> opt_spill_slots{8192};
@@ -408,13 +410,27 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
         for (int m = 0; alias && m + 1 < ix->dev.pq_M; m++)
             if ((m + 1) * 256 - off_f > ix->pq_sub_off[(size_t)m + 1]) alias = false;
         const int rerank_b = qc_b + JV_TODO * 8 + ((rk + 1) & ~1) * 8;   // after the search, in front of the pool
-        ap.pqr_pool_off = (std::max(lut_b, rerank_b) + 15) & ~15;
-        int lds = ap.pqr_pool_off + (ap.cand_cap + 1) * 8;
-        ap.pqr_qc_off = alias ? lut_b - qc_b : ((lds + 15) & ~15);
-        if (!alias) lds = ap.pqr_qc_off + qc_b;
+        // Table in registers (8 resident queries per CU, +34 % throughput at rerankK = 1 200, but 1.7x the latency of
+        // one query): only when the launch has more queries than the LDS-table variant could keep resident anyway
+        const int lutr = (opt_no_lutr.load() == 0 && jvk_pqp_lutr_ok(&ix->dev, ap.cand_cap) && nq > 4 * ix->cu_count) ? 1 : 0;
+        int lds;
+        if (lutr) {
+            // table in registers: LDS = the pool while searching, one hash set afterwards (>= 4 096 slots), then the
+            // rerank scratch with the pool written back behind the query and todo lists
+            const int pool_b = (ap.cand_cap + 1) * 8;
+            ap.pqr_pool_off = 0;
+            ap.pqr_qc_off = 0;
+            lds = std::max(std::max(pool_b, qc_b), std::max(16384, qc_b + JV_TODO * 8 + pool_b));
+        } else {
+            ap.pqr_pool_off = (std::max(lut_b, rerank_b) + 15) & ~15;
+            lds = ap.pqr_pool_off + (ap.cand_cap + 1) * 8;
+            ap.pqr_qc_off = alias ? lut_b - qc_b : ((lds + 15) & ~15);
+            if (!alias) lds = ap.pqr_qc_off + qc_b;
+        }
         lds = (lds + 15) & ~15;
+        ap.pqr_lds_bytes = lds;
         if (lds <= kMaxLds) {
-            const int per_cu = jvk_pqp_blocks_per_cu(&ix->dev, ap.cand_cap, lds);
+            const int per_cu = jvk_pqp_blocks_per_cu(&ix->dev, ap.cand_cap, lds, lutr);
             int blocks = ix->cu_count * per_cu;
             if (blocks > nq) blocks = nq;
             const size_t need = (size_t)blocks * (size_t)ap.pqr_log_cap;
@@ -427,7 +443,7 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
             }
             ap.pqr_log = c->pqr_log;
             ap.pqr_counter = c->work_counter + 6;
-            HIPCHK(jvk_launch_search_pqp(&ix->dev, &ap, lds, blocks, stream));
+            HIPCHK(jvk_launch_search_pqp(&ix->dev, &ap, lds, blocks, lutr, stream));
             pqf = true;
         }
     }
@@ -562,6 +578,7 @@ int jv_set_option(const char* name, int64_t value) {
     else if (n == "no_pqf") opt_no_pqf = value;
     else if (n == "no_pqr") opt_no_pqr = value;
     else if (n == "no_pqp") opt_no_pqp = value;
+    else if (n == "no_lutr") opt_no_lutr = value;
     else if (n == "pqf_only") opt_pqf_only = value;
     else if (n == "spill_tables") opt_spill_tables = value;
     else if (n == "spill_slots") opt_spill_slots = value;

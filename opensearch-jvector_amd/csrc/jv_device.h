@@ -77,6 +77,7 @@ struct JvSearchArgs {
     int32_t pqr_log_cap;
     int32_t pqr_qc_off;      // LDS byte offset of the centred query during the LUT build
     int32_t pqr_pool_off;    // LDS byte offset of the pool (jv_kernels_pqp.hip)
+    int32_t pqr_lds_bytes;   // dynamic LDS bytes of the launch (register-LUT variant: the visited-count hash set uses all of it)
     int32_t* pqr_counter;    // query dequeue counter (zeroed per call)
 };
 

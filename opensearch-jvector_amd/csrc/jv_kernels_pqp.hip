@@ -44,7 +44,11 @@ __device__ __forceinline__ int rank_level(const int64_t* pool, int lo, int last,
 // NP:   fused-block passes (1: R * lanes-per-node <= 64; 4: up to 4 passes)
 // FAST: pq_M % 16 == 0 and not cosine (only the unmasked look-up is compiled)
 // CAPK: pool capacity class: 0 -> <= 512 entries, 1 -> <= 1 024, 2 -> <= 2 048, 3 -> <= 4 096
-template <int NCHT, int NP, bool FAST, int CAPK>
+// LUTR: the look-up table lives in REGISTERS (PQ-32, FAST, single pass only): lutr[m][e], lane l = lut[m][4 l + e]; a
+//       look-up is ds_bpermute (lane = code >> 2) of the four e-registers + a bit-select by code & 3.  Costs ~3x the
+//       instructions of an LDS gather, but LDS then only holds the pool: 8 resident queries per CU (two waves per SIMD
+//       fill each other's stalls) instead of 3-4.
+template <int NCHT, int NP, bool FAST, int CAPK, bool LUTR>
 __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, const int qi, unsigned char* smem, int32_t* explog) {
     const int lane = threadIdx.x;
     const int rk = a.rk, topK = a.topK;
@@ -72,7 +76,43 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
         qnorm2 = __shfl(qnorm2, 0, JV_WAVE);
     }
     __syncthreads();
-    build_lut<24>(ix, qc_lds, lut, lane);
+    float lutr[LUTR ? 32 : 1][4];
+    if (LUTR) {
+        const bool l2 = ix.sim == 0;
+#pragma unroll
+        for (int m = 0; m < 32; m++) {  // (same fmaf chains as build_lut, results kept in registers)
+            const int d0 = ix.pq_sub_off[m], d1 = ix.pq_sub_off[m + 1];
+            float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+            constexpr int PF = 8;
+            for (int db = d0; db < d1; db += PF) {
+                f32x4 cb[PF];
+#pragma unroll
+                for (int u = 0; u < PF; u++) {
+                    if (db + u < d1) cb[u] = *(const f32x4*)(ix.pq_cbT + (size_t)(db + u) * 256 + 4 * lane);
+                    else cb[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int u = 0; u < PF; u++) {
+                    if (db + u < d1) {
+                        const float qc = qc_lds[db + u];
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            if (l2) {
+                                const float df = qc - cb[u][e];
+                                acc4[e] = fmaf(df, df, acc4[e]);
+                            } else {
+                                acc4[e] = fmaf(qc, cb[u][e], acc4[e]);
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++) lutr[LUTR ? m : 0][e] = acc4[e];
+        }
+    } else {
+        build_lut<24>(ix, qc_lds, lut, lane);
+    }
     __syncthreads();
 
     const int my_c = lane & (lpn - 1);
@@ -81,9 +121,29 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
     const int my_slot = lane / lpn;
     const bool my_chunk = my_c * 16 < M;
     const bool full16 = (M & 15) == 0;
+    auto adc_regs = [&](const u32x4 cw) -> float {  // this lane's 16 subspaces (chunk my_c), summed left to right like adc_chunk
+        float sum = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int w = (int)cw[i >> 2];
+            const int sh = (i & 3) * 8;
+            const int addr = (int)(((uint32_t)w >> sh) & 0xFFu);       // ds_bpermute reads lane (addr >> 2) & 63 = code >> 2
+            const int m0 = __builtin_amdgcn_sbfe(w, sh, 1), m1 = __builtin_amdgcn_sbfe(w, sh + 1, 1);  // -1 / 0: code bits 0, 1
+            int x[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int t0 = __builtin_amdgcn_ds_bpermute(addr, __float_as_int(lutr[LUTR ? i : 0][e]));
+                const int t1 = __builtin_amdgcn_ds_bpermute(addr, __float_as_int(lutr[LUTR ? 16 + i : 0][e]));
+                x[e] = my_c ? t1 : t0;
+            }
+            const int s01 = (m0 & x[1]) | (~m0 & x[0]), s23 = (m0 & x[3]) | (~m0 & x[2]);
+            sum = sum + __int_as_float((m1 & s23) | (~m1 & s01));
+        }
+        return sum;
+    };
     auto adc_score = [&](const u32x4 cw, bool have) -> float {
         if (FAST) {
-            const float s_ = adc_chunk<true>(lut, cw, my_c * 16, M);
+            const float s_ = LUTR ? adc_regs(cw) : adc_chunk<true>(lut, cw, my_c * 16, M);
             return map_score(ix.sim == 0 ? 0 : 1, lanes_tree_sum(have ? s_ : 0.0f, lpn));
         }
         float s = full16 ? adc_chunk<true>(lut, cw, my_c * 16, M) : adc_chunk<false>(lut, cw, my_c * 16, M);
@@ -348,14 +408,30 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
     }
     STAMP(5)
 
+    // LUTR: the pool moves to registers so that the whole LDS allocation can serve as the visited-count hash set
+    i32x32 PL, PH;
+    if (LUTR && why == 0) {
+#pragma unroll
+        for (int t = 0; t < 32; t++) {
+            PL[t] = 0;
+            PH[t] = (int)0x80000000;
+            if ((t << 6) < np) {
+                const int64_t e = pool[min((t << 6) + lane, cap)];
+                PL[t] = (int)(uint32_t)(e & 0xFFFFFFFFll);
+                PH[t] = (int)(e >> 32);
+            }
+        }
+        __syncthreads();
+    }
     int visited = 0;
     if (why == 0) {
         // ---- jvector's visitedCount: distinct neighbours of the expanded nodes, entry point excluded.  The hash set
         // lives where the LUT was; node ids are split into `parts` hash classes counted one after the other when one
         // table cannot hold them all (adjacency rows are re-read once per class). ----
-        uint32_t* vh = (uint32_t*)lut;
+        uint32_t* vh = (uint32_t*)smem;
+        const int hash_bytes = LUTR ? a.pqr_lds_bytes : lut_bytes;
         int vslots = 1;
-        while (vslots * 2 * 4 <= lut_bytes) vslots <<= 1;
+        while (vslots * 2 * 4 <= hash_bytes) vslots <<= 1;
         const uint32_t vmask = (uint32_t)vslots - 1u;
         const int vshift = 32 - (31 - __clz(vslots));
         const int vlimit = (vslots / 16) * 13;
@@ -475,14 +551,33 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
     STAMP(6)  // visited-count pass
     STAMP_FLUSH
     const int nres = np < rk ? np : rk;
+    // ---- rerank scratch (where the LUT / the hash set was): query, todo lists, exact keys ----
+    float* q_lds = (float*)smem;
+    size_t roff = (size_t)ix.nch * 64 * sizeof(float);
+    float* todo_score = (float*)(smem + roff);
+    roff += JV_TODO * sizeof(float);
+    int32_t* todo = (int32_t*)(smem + roff);
+    roff += JV_TODO * sizeof(int32_t);
+    int64_t* fin = (int64_t*)(smem + roff);  // [rk]
+    const int64_t* rpool = pool;
+    if (LUTR && why == 0) {
+        // the pool returns from the registers; the exact keys overwrite it in place (entry i is written only after
+        // the 64-entry batch containing position i has been read)
+        int64_t* wp = (int64_t*)(smem + roff);
+#pragma unroll
+        for (int t = 0; t < 32; t++)
+            if ((t << 6) < np) wp[(t << 6) + lane] = (int64_t)(((uint64_t)(uint32_t)PH[t] << 32) | (uint64_t)(uint32_t)PL[t]);
+        rpool = wp;
+        __syncthreads();
+    }
     int above = 0;
     if (why == 0) {
-        for (int i = lane; i < nres; i += JV_WAVE) above += key_score(pool[i]) >= a.rerank_floor ? 1 : 0;
+        for (int i = lane; i < nres; i += JV_WAVE) above += key_score(rpool[i]) >= a.rerank_floor ? 1 : 0;
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) above += __shfl_xor(above, o, JV_WAVE);
         // rerankFloor above every approximate score AND a tie at the best one: jvector rescores the first best entry of
         // its result heap's array, which only the HBM-scratch rung reconstructs (replay_first_best)
-        if (above == 0 && nres >= 2 && key_score(pool[0]) == key_score(pool[1])) why = 6;
+        if (above == 0 && nres >= 2 && key_score(rpool[0]) == key_score(rpool[1])) why = 6;
     }
     if (why != 0) {
         if (lane == 0) {
@@ -496,14 +591,7 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
         }
         return;
     }
-    // ---- rerank (NodeQueue.rerank) with the exact scorer; scratch lives where the LUT was ----
-    float* q_lds = (float*)smem;
-    size_t roff = (size_t)ix.nch * 64 * sizeof(float);
-    float* todo_score = (float*)(smem + roff);
-    roff += JV_TODO * sizeof(float);
-    int32_t* todo = (int32_t*)(smem + roff);
-    roff += JV_TODO * sizeof(int32_t);
-    int64_t* fin = (int64_t*)(smem + roff);  // [rk]
+    // ---- rerank (NodeQueue.rerank) with the exact scorer ----
     for (int i = lane; i < ix.nch * 64; i += JV_WAVE) q_lds[i] = i < ix.d ? qg[i] : 0.0f;
     __syncthreads();
     if (ix.sim == 2) qnorm2 = query_norm2(ix, q_lds, lane), qnorm2 = __shfl(qnorm2, 0, JV_WAVE);
@@ -513,9 +601,9 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
         bool take = false;
         int node = 0;
         if (i < nres) {
-            const int64_t k = pool[i];
+            const int64_t k = rpool[i];
             node = pool_node(k);
-            take = above > 0 ? key_score(k) >= a.rerank_floor : i == 0;  // pool[0] is the best approximate entry
+            take = above > 0 ? key_score(k) >= a.rerank_floor : i == 0;  // position 0 is the best approximate entry
         }
         const unsigned long long tm = __ballot(take);
         const int m = __popcll(tm);
@@ -563,8 +651,8 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
 }
 
 // Persistent grid: one workgroup per resident LDS slot, queries dequeued in order.
-template <int NCHT, int NP, bool FAST, int CAPK>
-__global__ __launch_bounds__(JV_WAVE) void jv_search_pqp_kernel(const JvIndexDev ix, const JvSearchArgs a) {
+template <int NCHT, int NP, bool FAST, int CAPK, bool LUTR = false>
+__global__ __launch_bounds__(JV_WAVE, LUTR ? 2 : 1) void jv_search_pqp_kernel(const JvIndexDev ix, const JvSearchArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int32_t* explog = a.pqr_log + (size_t)blockIdx.x * (size_t)a.pqr_log_cap;
     for (;;) {
@@ -572,7 +660,7 @@ __global__ __launch_bounds__(JV_WAVE) void jv_search_pqp_kernel(const JvIndexDev
         if (threadIdx.x == 0) qi = atomicAdd(a.pqr_counter, 1);
         qi = __builtin_amdgcn_readfirstlane(qi);
         if (qi >= a.nq) break;
-        search_one_pqp<NCHT, NP, FAST, CAPK>(ix, a, qi, smem, explog);
+        search_one_pqp<NCHT, NP, FAST, CAPK, LUTR>(ix, a, qi, smem, explog);
         __syncthreads();
     }
 }
@@ -584,14 +672,24 @@ typedef void (*pqp_kernel_t)(const JvIndexDev, const JvSearchArgs);
 // [0 single-pass | 1 multi-pass | 2 single-pass FAST | 3 multi-pass FAST][capacity class][nch slot]
 static const pqp_kernel_t g_pqp_kernels[4][4][4] = {JV_PQP_CAPS(1, false), JV_PQP_CAPS(4, false), JV_PQP_CAPS(1, true), JV_PQP_CAPS(4, true)};
 
+// register-LUT variants: PQ-32, FAST, single pass; [capacity class 0..2][nch slot]
+#define JV_PQV_ROW(CAPK) \
+    { jv_search_pqp_kernel<0, 1, true, CAPK, true>, jv_search_pqp_kernel<2, 1, true, CAPK, true>, jv_search_pqp_kernel<12, 1, true, CAPK, true>, jv_search_pqp_kernel<24, 1, true, CAPK, true> }
+static const pqp_kernel_t g_pqv_kernels[3][4] = {JV_PQV_ROW(0), JV_PQV_ROW(1), JV_PQV_ROW(2)};
+
 static int pqp_nch_slot(const JvIndexDev* ix) {
     if (ix->stride != ix->nch * 64) return 0;
     return ix->nch == 2 ? 1 : ix->nch == 12 ? 2 : ix->nch == 24 ? 3 : 0;
 }
 static int pqp_capk(int cap) { return cap <= 512 ? 0 : cap <= 1024 ? 1 : cap <= 2048 ? 2 : 3; }
-static pqp_kernel_t pqp_pick(const JvIndexDev* ix, int cap) {
+// lutr: look-up table in registers (jvk_pqp_lutr_ok shapes only)
+extern "C" int jvk_pqp_lutr_ok(const JvIndexDev* ix, int cap) {
+    return ix->pq_M == 32 && ix->sim != 2 && ix->R * ix->pq_lanes <= JV_WAVE && cap <= 2048 ? 1 : 0;
+}
+static pqp_kernel_t pqp_pick(const JvIndexDev* ix, int cap, int lutr) {
     const int multi = ix->R * ix->pq_lanes > JV_WAVE ? 1 : 0;
     const int fast = (ix->pq_M % 16 == 0 && ix->sim != 2) ? 1 : 0;
+    if (lutr && jvk_pqp_lutr_ok(ix, cap)) return g_pqv_kernels[pqp_capk(cap)][pqp_nch_slot(ix)];
     return g_pqp_kernels[fast * 2 + multi][pqp_capk(cap)][pqp_nch_slot(ix)];
 }
 
@@ -600,6 +698,8 @@ extern "C" hipError_t jvk_pqp_set_max_lds(int bytes) {
         for (int c = 0; c < 4; c++)
             for (int s = 0; s < 4; s++) {
                 hipError_t e = hipFuncSetAttribute((const void*)g_pqp_kernels[v][c][s], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+                if (e == hipSuccess && v == 0 && c < 3)
+                    e = hipFuncSetAttribute((const void*)g_pqv_kernels[c][s], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
                 if (e != hipSuccess) return e;
             }
     return hipSuccess;
@@ -608,15 +708,15 @@ extern "C" hipError_t jvk_pqp_set_max_lds(int bytes) {
 extern "C" int jvk_pqp_max_entries(void) { return 4096; }
 
 // resident workgroups per CU for this index shape, pool capacity and LDS size
-extern "C" int jvk_pqp_blocks_per_cu(const JvIndexDev* ix, int cap, int lds_bytes) {
+extern "C" int jvk_pqp_blocks_per_cu(const JvIndexDev* ix, int cap, int lds_bytes, int lutr) {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)pqp_pick(ix, cap), JV_WAVE, (size_t)lds_bytes) != hipSuccess) return 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)pqp_pick(ix, cap, lutr), JV_WAVE, (size_t)lds_bytes) != hipSuccess) return 1;
     return nb < 1 ? 1 : nb;
 }
 
 // blocks = resident workgroups (the host sizes the log scratch to it); a->cand_cap = pool entries
-extern "C" hipError_t jvk_launch_search_pqp(const JvIndexDev* ix, const JvSearchArgs* a, int lds_bytes, int blocks, hipStream_t stream) {
+extern "C" hipError_t jvk_launch_search_pqp(const JvIndexDev* ix, const JvSearchArgs* a, int lds_bytes, int blocks, int lutr, hipStream_t stream) {
     if (a->nq <= 0) return hipSuccess;
-    pqp_pick(ix, a->cand_cap)<<<blocks, JV_WAVE, lds_bytes, stream>>>(*ix, *a);
+    pqp_pick(ix, a->cand_cap, lutr)<<<blocks, JV_WAVE, lds_bytes, stream>>>(*ix, *a);
     return hipGetLastError();
 }
