@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define JVGPU_ABI_VERSION 1
+#define JVGPU_ABI_VERSION 2
 
 /* ---- status codes (the Java shim maps them to the reference's exception types,
  *      SURVEY §8(b) "Errors": EINVAL -> IllegalArgumentException, EUNSUPPORTED ->
@@ -108,6 +108,8 @@ enum { JV_STAT_VISITED = 0, JV_STAT_RERANKED = 1, JV_STAT_EXPANDED = 2, JV_STAT_
 
 /* Extended per-query status written to out_flags by the batch calls. */
 #define JV_QFLAG_RETRIED_BIG 0x1 /* on-chip scratch overflowed; query was re-run on the HBM-scratch variant */
+#define JV_QFLAG_EARLY_TERMINATED 0x2 /* visit_limit reached: the search stopped and returned nothing; out_stats holds the
+                                         counters so far (Lucene then runs the exact scan, see jv_search_params.visit_limit) */
 
 /* Replaces: FieldEntry constructor (J/JVectorReader.java:284-337) — once per segment x field. */
 int jv_index_create(const jv_index_desc* desc, jv_index** out);
@@ -138,10 +140,42 @@ int jv_search(jv_index* index, const float* query, int32_t topK, int32_t rerankK
               int32_t* out_nodes, int32_t* out_docs, float* out_scores, int32_t* out_count,
               int32_t* out_stats);
 
+/* Optional search parameters beyond the reference's call (jv_search_ex / jv_search_batch_ex). */
+typedef struct jv_search_params {
+    uint32_t struct_size;  /* sizeof(jv_search_params) */
+    int32_t topK, rerankK;
+    float threshold, rerankFloor;
+    const uint64_t* accept_doc_words; /* doc-space bitset or NULL */
+    int64_t accept_num_docs;
+    /* Lucene's KnnCollector.visitLimit() (= the filter's cardinality for a filtered query).  The reference never checks it
+     * while searching (J/JVectorReader.java:202-207 only reports visited + expanded afterwards) and
+     * AbstractKnnVectorQuery then DISCARDS the approximate result when that sum reached the limit and runs the exact
+     * scan (-> jv_score_ordinals).  With visit_limit > 0 the engine stops such a search as soon as visited + expanded
+     * reaches the limit and sets JV_QFLAG_EARLY_TERMINATED instead of finishing work that is going to be thrown away;
+     * searches that stay below the limit are unchanged (same ids, scores, counters).  0 = never stop early. */
+    int64_t visit_limit;
+    /* Identity of the filter's CONTENTS for the device-side filter cache (option "filter_cache", per index): a bitset
+     * that was uploaded before is served from HBM instead of crossing PCIe again.  0 = the library hashes the words. */
+    uint64_t accept_key;
+} jv_search_params;
+
+/* jv_search with jv_search_params; out_flags (optional) receives the query's JV_QFLAG_* word. */
+int jv_search_ex(jv_index* index, const float* query, const jv_search_params* params, int32_t* out_nodes,
+                 int32_t* out_docs, float* out_scores, int32_t* out_count, int32_t* out_stats, int32_t* out_flags);
+
+/* jv_search_batch with jv_search_params and PER-QUERY status: out_status[i] = JV_OK or the reason query i has no answer
+ * (JV_ENOMEM: it outgrew even the HBM scratch); the call returns JV_OK only if every query succeeded, but the rows of
+ * the successful queries are valid either way — one pathological query does not fail its batch. */
+int jv_search_batch_ex(jv_index* index, const float* queries, int32_t nq, const jv_search_params* params,
+                       int32_t* out_nodes, int32_t* out_docs, float* out_scores, int32_t* out_count,
+                       int32_t* out_stats, int32_t* out_status, int32_t* out_flags);
+
 /* nq independent searches with shared parameters (the GPU's natural unit of work; the reference
  * has no batch call — Lucene issues one search per leaf per thread).  Row-major outputs:
  * out_nodes/out_docs/out_scores [nq][topK], out_count [nq], out_stats [nq][JV_NUM_STATS].
- * Unused tail entries of a row are ordinal/doc -1 and score 0.  Host pointers. */
+ * Unused tail entries of a row are ordinal/doc -1 and score 0.  Host pointers.
+ * Returns JV_ENOMEM if any query could not be answered (see jv_search_batch_ex for per-query status); the rows of the
+ * other queries are valid. */
 int jv_search_batch(jv_index* index, const float* queries, int32_t nq, int32_t topK, int32_t rerankK,
                     float threshold, float rerankFloor, const uint64_t* accept_doc_words,
                     int64_t accept_num_docs, int32_t* out_nodes, int32_t* out_docs, float* out_scores,
@@ -150,8 +184,9 @@ int jv_search_batch(jv_index* index, const float* queries, int32_t nq, int32_t t
 /* Same, but every pointer is a DEVICE pointer on the index's device and the work is enqueued on
  * `hip_stream` (a hipStream_t passed as void*; NULL = the library's own stream, synchronous).
  * With a caller stream the call returns after enqueueing; results are valid after the caller
- * synchronises that stream.  Queries that overflow the on-chip scratch are reported through
- * out_flags (bit 31 set = needs retry) and must be resolved with jv_search_batch_device_finish. */
+ * synchronises that stream.  The whole ladder (on-chip kernels, retry, HBM-scratch rung) is enqueued without host
+ * round trips; d_out_flags (strongly recommended) receives per query JV_QFLAG_* in the low bits and 0x40000000 if the
+ * query exhausted even the HBM scratch (its row is then empty) — without d_out_flags such a failure is invisible. */
 int jv_search_batch_device(jv_index* index, const float* d_queries, int32_t nq, int32_t topK,
                            int32_t rerankK, float threshold, float rerankFloor,
                            const uint64_t* d_accept_doc_words, int64_t accept_num_docs,
@@ -179,14 +214,34 @@ typedef struct jv_index_info {
     int64_t hbm_bytes;          /* bytes resident in HBM for this index          */
     int32_t row_stride_floats;  /* padded vector row stride                       */
     int32_t fused_adc;          /* 1 if the fused layout is present               */
+    int64_t scratch_bytes;      /* HBM scratch currently held on behalf of this index: launch contexts (staging, spill
+                                   tables, expansion logs), cached filters, and the device's SHARED HBM-scratch rung    */
+    int64_t filter_cache_hits, filter_cache_misses;
 } jv_index_info;
 int jv_index_get_info(const jv_index* index, jv_index_info* out);
 
-/* Tunables (process-wide, read at call time): name = "lds_visited_slots", "lds_candidates",
- * "force_big_path", "force_general_path", "big_blocks", "big_cand_cap", "spill_tables", "spill_slots",
- * "combine", "combine_leaders", "combine_max_batch" (+ diagnostics: "no_escalation", "no_pqf", "pqf_only",
- * "dbg_ptr"). Returns JV_EINVAL for unknown names. */
+/* Tunables are PER INDEX: jv_index_set_option changes one handle; jv_set_option only changes the defaults that indexes
+ * created afterwards start from (nothing process-wide is read at call time).  Names: "lds_visited_slots",
+ * "lds_candidates", "force_big_path", "force_general_path", "big_blocks", "big_cand_cap", "big_budget_mb",
+ * "spill_tables", "spill_slots", "combine", "combine_leaders", "combine_max_batch", "max_contexts", "filter_cache"
+ * (+ diagnostics: "no_escalation", "no_pqf", "no_pqp", "no_pqr", "no_lutr", "pqf_only", "dbg_ptr").
+ * JV_EINVAL for unknown names. */
 int jv_set_option(const char* name, int64_t value);
+int jv_index_set_option(jv_index* index, const char* name, int64_t value);
+
+/* ---- doc-ID-range sharding inside ONE process (the reference's host is one JVM per node) ----
+ * A shard group bundles the per-shard handles of one logical field: shard g owns a contiguous doc-id range, with its own
+ * graph and an ord2doc map of GLOBAL doc ids, on any device of the node.  jv_search_sharded_batch runs every query on every
+ * shard (concurrently, one stream per shard), gathers the per-shard top-k lists of (doc, score) onto the first shard's
+ * device with peer-to-peer copies over xGMI (one 8-byte-pair buffer per shard), and merges them there
+ * (jv_merge_topk kernel: score desc, doc asc) — Lucene's per-leaf search + TopDocs.merge in one call.  out_docs are
+ * global doc ids; out_stats are summed over the shards.  The group borrows the handles (destroy the group first). */
+typedef struct jv_shard_group jv_shard_group;
+int jv_shard_group_create(jv_index* const* shards, int32_t num_shards, jv_shard_group** out);
+void jv_shard_group_destroy(jv_shard_group* group);
+int jv_search_sharded_batch(jv_shard_group* group, const float* queries, int32_t nq, int32_t topK, int32_t rerankK,
+                            float threshold, float rerankFloor, int32_t* out_docs, float* out_scores,
+                            int32_t* out_count, int32_t* out_stats);
 
 /* Thread-local message of the calling thread's most recent failing call ("" if none). */
 const char* jv_last_error(void);

@@ -24,8 +24,10 @@ NUM_STATS = 4
 ABI_SYMBOLS = [
     "jv_index_create", "jv_index_destroy", "jv_search", "jv_search_batch", "jv_search_batch_device",
     "jv_score_ordinals", "jv_merge_topk_device", "jv_index_get_info", "jv_set_option", "jv_last_error",
-    "jv_abi_version",
+    "jv_abi_version", "jv_search_ex", "jv_search_batch_ex", "jv_index_set_option", "jv_shard_group_create",
+    "jv_shard_group_destroy", "jv_search_sharded_batch",
 ]
+QFLAG_RETRIED_BIG, QFLAG_EARLY_TERMINATED = 0x1, 0x2
 
 
 class JvError(RuntimeError):
@@ -56,7 +58,16 @@ class JvIndexInfo(C.Structure):
     _fields_ = [
         ("n", C.c_int32), ("d", C.c_int32), ("R", C.c_int32), ("similarity", C.c_int32), ("pq_M", C.c_int32),
         ("pq_K", C.c_int32), ("num_upper_layers", C.c_int32), ("device", C.c_int32), ("hbm_bytes", C.c_int64),
-        ("row_stride_floats", C.c_int32), ("fused_adc", C.c_int32),
+        ("row_stride_floats", C.c_int32), ("fused_adc", C.c_int32), ("scratch_bytes", C.c_int64),
+        ("filter_cache_hits", C.c_int64), ("filter_cache_misses", C.c_int64),
+    ]
+
+
+class JvSearchParams(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("topK", C.c_int32), ("rerankK", C.c_int32), ("threshold", C.c_float),
+        ("rerankFloor", C.c_float), ("accept_doc_words", C.c_void_p), ("accept_num_docs", C.c_int64),
+        ("visit_limit", C.c_int64), ("accept_key", C.c_uint64),
     ]
 
 
@@ -220,6 +231,18 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.jv_last_error.restype = C.c_char_p
     lib.jv_abi_version.argtypes = []
     lib.jv_abi_version.restype = C.c_int
+    lib.jv_search_ex.argtypes = [vp, vp, C.POINTER(JvSearchParams), vp, vp, vp, vp, vp, vp]
+    lib.jv_search_ex.restype = C.c_int
+    lib.jv_search_batch_ex.argtypes = [vp, vp, i32, C.POINTER(JvSearchParams), vp, vp, vp, vp, vp, vp, vp]
+    lib.jv_search_batch_ex.restype = C.c_int
+    lib.jv_index_set_option.argtypes = [vp, C.c_char_p, i64]
+    lib.jv_index_set_option.restype = C.c_int
+    lib.jv_shard_group_create.argtypes = [C.POINTER(vp), i32, C.POINTER(vp)]
+    lib.jv_shard_group_create.restype = C.c_int
+    lib.jv_shard_group_destroy.argtypes = [vp]
+    lib.jv_shard_group_destroy.restype = None
+    lib.jv_search_sharded_batch.argtypes = [vp, vp, i32, i32, i32, f32, f32, vp, vp, vp, vp]
+    lib.jv_search_sharded_batch.restype = C.c_int
     _lib = lib
     return lib
 
@@ -230,6 +253,7 @@ def _check(lib, rc: int):
 
 
 def set_option(name: str, value: int):
+    """Default of a tunable for indexes created AFTER this call (existing handles: GpuIndex.set_option)."""
     lib = load_library()
     _check(lib, lib.jv_set_option(name.encode(), int(value)))
 
@@ -270,6 +294,57 @@ class GpuIndex:
             self.close()
         except Exception:
             pass
+
+    def set_option(self, name: str, value: int):
+        """Per-index tunable (jv_index_set_option)."""
+        _check(self.lib, self.lib.jv_index_set_option(self.handle, name.encode(), int(value)))
+
+    def _params(self, topK, rerankK, threshold, rerank_floor, acc, accept_num_docs, visit_limit, accept_key):
+        p = JvSearchParams()
+        p.struct_size = C.sizeof(JvSearchParams)
+        p.topK, p.rerankK, p.threshold, p.rerankFloor = topK, rerankK, threshold, rerank_floor
+        p.accept_doc_words = _ptr(acc)
+        p.accept_num_docs = accept_num_docs
+        p.visit_limit = visit_limit
+        p.accept_key = accept_key
+        return p
+
+    def search_batch_ex(self, queries: np.ndarray, topK: int, rerankK: int, threshold: float = 0.0, rerank_floor: float = 0.0,
+                        accept: Optional[np.ndarray] = None, accept_num_docs: int = 0, visit_limit: int = 0, accept_key: int = 0):
+        """jv_search_batch_ex: returns (SearchResult, status [nq], flags [nq], rc) — never raises for per-query failures."""
+        q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, self.d)
+        nq = q.shape[0]
+        nodes = np.full((nq, topK), -1, dtype=np.int32)
+        docs = np.full((nq, topK), -1, dtype=np.int32)
+        scores = np.zeros((nq, topK), dtype=np.float32)
+        count = np.zeros(nq, dtype=np.int32)
+        stats = np.zeros((nq, NUM_STATS), dtype=np.int32)
+        status = np.zeros(nq, dtype=np.int32)
+        flags = np.zeros(nq, dtype=np.int32)
+        acc = None if accept is None else np.ascontiguousarray(accept, dtype=np.uint64)
+        p = self._params(topK, rerankK, threshold, rerank_floor, acc, accept_num_docs, visit_limit, accept_key)
+        rc = self.lib.jv_search_batch_ex(self.handle, q.ctypes.data, nq, C.byref(p), nodes.ctypes.data, docs.ctypes.data,
+                                         scores.ctypes.data, count.ctypes.data, stats.ctypes.data, status.ctypes.data,
+                                         flags.ctypes.data)
+        if rc not in (JV_OK, JV_ENOMEM):
+            _check(self.lib, rc)
+        return SearchResult(nodes, docs, scores, count, stats), status, flags, rc
+
+    def search_ex(self, query: np.ndarray, topK: int, rerankK: int, threshold: float = 0.0, rerank_floor: float = 0.0,
+                  accept: Optional[np.ndarray] = None, accept_num_docs: int = 0, visit_limit: int = 0, accept_key: int = 0):
+        """jv_search_ex: returns (SearchResult, flags)."""
+        q = np.ascontiguousarray(query, dtype=np.float32).reshape(self.d)
+        nodes = np.full((1, topK), -1, dtype=np.int32)
+        docs = np.full((1, topK), -1, dtype=np.int32)
+        scores = np.zeros((1, topK), dtype=np.float32)
+        count = np.zeros(1, dtype=np.int32)
+        stats = np.zeros((1, NUM_STATS), dtype=np.int32)
+        flags = np.zeros(1, dtype=np.int32)
+        acc = None if accept is None else np.ascontiguousarray(accept, dtype=np.uint64)
+        p = self._params(topK, rerankK, threshold, rerank_floor, acc, accept_num_docs, visit_limit, accept_key)
+        _check(self.lib, self.lib.jv_search_ex(self.handle, q.ctypes.data, C.byref(p), nodes.ctypes.data, docs.ctypes.data,
+                                               scores.ctypes.data, count.ctypes.data, stats.ctypes.data, flags.ctypes.data))
+        return SearchResult(nodes, docs, scores, count, stats), int(flags[0])
 
     def info(self) -> JvIndexInfo:
         out = JvIndexInfo()
@@ -321,6 +396,41 @@ class GpuIndex:
         out = np.zeros(o.shape[0], dtype=np.float32)
         _check(self.lib, self.lib.jv_score_ordinals(self.handle, q.ctypes.data, o.ctypes.data, o.shape[0], out.ctypes.data))
         return out
+
+
+class ShardGroup:
+    """jv_shard_group: doc-range shards of one field searched and merged in one call (one process, any devices)."""
+
+    def __init__(self, shards: Sequence[GpuIndex]):
+        self.lib = load_library()
+        self._shards = list(shards)
+        arr = (C.c_void_p * len(shards))(*[s.handle for s in shards])
+        h = C.c_void_p()
+        _check(self.lib, self.lib.jv_shard_group_create(arr, len(shards), C.byref(h)))
+        self.handle = h
+        self.d = shards[0].d
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.jv_shard_group_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def search_batch(self, queries: np.ndarray, topK: int, rerankK: int, threshold: float = 0.0, rerank_floor: float = 0.0):
+        q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, self.d)
+        nq = q.shape[0]
+        docs = np.full((nq, topK), -1, dtype=np.int32)
+        scores = np.zeros((nq, topK), dtype=np.float32)
+        count = np.zeros(nq, dtype=np.int32)
+        stats = np.zeros((nq, NUM_STATS), dtype=np.int32)
+        _check(self.lib, self.lib.jv_search_sharded_batch(self.handle, q.ctypes.data, nq, topK, rerankK, threshold, rerank_floor,
+                                                          docs.ctypes.data, scores.ctypes.data, count.ctypes.data, stats.ctypes.data))
+        return SearchResult(docs.copy(), docs, scores, count, stats)
 
 
 def merge_topk_device(device: int, d_docs: int, d_scores: int, nq: int, lists: int, k: int, d_out_docs: int,

@@ -12,6 +12,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
 #include <deque>
 #include <mutex>
 #include <string>
@@ -34,6 +35,9 @@ hipError_t jvk_launch_score_ordinals(const JvIndexDev* ix, const float* d_query,
                                      int count, float* d_out, hipStream_t s);
 hipError_t jvk_launch_merge_topk(const int32_t* d_docs, const float* d_scores, int nq, int lists, int k,
                                  int32_t* d_out_docs, float* d_out_scores, hipStream_t s);
+hipError_t jvk_launch_merge_topk_strided(const int32_t* d_pairs, const float* unused, int nq, int lists, int k,
+                                         int32_t* d_out_docs, float* d_out_scores, hipStream_t s);
+hipError_t jvk_launch_pack_pairs(const int32_t* d_docs, const float* d_scores, int32_t* d_pairs, long long n, hipStream_t s);
 // register-pool kernel (jv_kernels_pqr.hip)
 hipError_t jvk_pqr_set_max_lds(int bytes);
 int jvk_pqr_capacity(void);
@@ -71,26 +75,56 @@ int fail(int code, const char* fmt, ...) {
                         hipGetErrorString(e_));                                                   \
     } while (0)
 
-// process-wide tunables (jv_set_option)
-std::atomic<int64_t> opt_lds_visited_slots{0};  // 0 = auto
-std::atomic<int64_t> opt_lds_candidates{0};     // 0 = auto
-std::atomic<int64_t> opt_force_big{0};
-std::atomic<int64_t> opt_force_general{0};
-std::atomic<int64_t> opt_no_escalation{0};
-std::atomic<int64_t> opt_dbg_ptr{0};
-std::atomic<int64_t> opt_no_pqf{0};
-std::atomic<int64_t> opt_no_pqr{1};  // diagnostics: 0 = use the register-pool kernel (measured slower than pqp; kept for comparison)
-std::atomic<int64_t> opt_no_pqp{0};  // diagnostics: 1 = skip the persistent LDS-pool kernel
-std::atomic<int64_t> opt_no_lutr{0}; // diagnostics: 1 = keep the look-up table in LDS even where the register variant applies
-std::atomic<int64_t> opt_pqf_only{0};  // diagnostics: skip the ladder after the PQF launch (flags stay visible)
-std::atomic<int64_t> opt_spill_tables{2048};  // per context: 2048 x 8192 x 4 B = 64 MB (a launch that needs more falls to the ladder)
-std::atomic<int64_t> opt_spill_slots{8192};
-std::atomic<int64_t> opt_big_blocks{0};  // 0 = auto: as many resident big-path blocks as fit a 768 MB scratch budget (64..1024)
-std::atomic<int64_t> opt_big_cand_cap{65536};
-// jv_search (one query per call, many caller threads): concurrent calls are combined into batch launches
-std::atomic<int64_t> opt_combine{1};
-std::atomic<int64_t> opt_combine_leaders{2};     // batches in flight at once
-std::atomic<int64_t> opt_combine_max_batch{2048};
+// Tunables.  Every index carries its own set (jv_index_set_option); jv_set_option only changes the DEFAULTS that
+// indexes created afterwards start from — nothing process-wide is read at call time.
+//   lds_visited_slots / lds_candidates   on-chip scratch geometry of the generic kernels (0 = auto)
+//   force_big_path / force_general_path / no_escalation / no_pqf / no_pqr / no_pqp / no_lutr / pqf_only   rung selection (diagnostics)
+//   spill_tables x spill_slots           per-context pool of visited-set spill tables (512 x 8192 x 4 B = 16 MB, allocated on first use)
+//   big_blocks / big_cand_cap / big_budget_mb   HBM-scratch rung: resident blocks (0 = as many as fit the budget), candidate slots
+//   combine / combine_leaders / combine_max_batch   group commit of concurrent jv_search calls
+//   max_contexts                         cap of per-index launch contexts (callers beyond it wait)
+//   filter_cache                         device-resident doc-filter bitsets kept per index (0 = off)
+//   dbg_ptr                              diagnostic build only
+enum OptId { OPT_LDS_VISITED_SLOTS, OPT_LDS_CANDIDATES, OPT_FORCE_BIG, OPT_FORCE_GENERAL, OPT_NO_ESCALATION, OPT_DBG_PTR, OPT_NO_PQF, OPT_NO_PQR, OPT_NO_PQP, OPT_NO_LUTR, OPT_PQF_ONLY, OPT_SPILL_TABLES, OPT_SPILL_SLOTS, OPT_BIG_BLOCKS, OPT_BIG_CAND_CAP, OPT_BIG_BUDGET_MB, OPT_COMBINE, OPT_COMBINE_LEADERS, OPT_COMBINE_MAX_BATCH, OPT_MAX_CONTEXTS, OPT_FILTER_CACHE, OPT_COUNT };
+struct OptName { const char* name; int64_t def; };
+const OptName kOptNames[OPT_COUNT] = {
+    {"lds_visited_slots", 0},
+    {"lds_candidates", 0},
+    {"force_big_path", 0},
+    {"force_general_path", 0},
+    {"no_escalation", 0},
+    {"dbg_ptr", 0},
+    {"no_pqf", 0},
+    {"no_pqr", 1},
+    {"no_pqp", 0},
+    {"no_lutr", 0},
+    {"pqf_only", 0},
+    {"spill_tables", 512},
+    {"spill_slots", 8192},
+    {"big_blocks", 0},
+    {"big_cand_cap", 65536},
+    {"big_budget_mb", 192},
+    {"combine", 1},
+    {"combine_leaders", 2},
+    {"combine_max_batch", 2048},
+    {"max_contexts", 8},
+    {"filter_cache", 8},
+};
+struct Opts {
+    std::atomic<int64_t> v[OPT_COUNT];
+    Opts() {
+        for (int i = 0; i < OPT_COUNT; i++) v[i].store(kOptNames[i].def);
+    }
+    void copy_from(const Opts& o) {
+        for (int i = 0; i < OPT_COUNT; i++) v[i].store(o.v[i].load());
+    }
+    int find(const char* name) const {
+        for (int i = 0; i < OPT_COUNT; i++)
+            if (strcmp(kOptNames[i].name, name) == 0) return i;
+        return -1;
+    }
+};
+Opts g_default_opts;
 
 int next_pow2(int v) {
     int p = 1;
@@ -116,15 +150,10 @@ struct Ctx {
     size_t arena_cap = 0;
     float* h_query = nullptr;    // pinned staging for small query batches
     size_t h_query_cap = 0;
-    // big-path HBM scratch
-    uint32_t* big_visited = nullptr;
-    int64_t* big_cand = nullptr;
-    int32_t* work_counter = nullptr;  // [0] big-path dequeue, [1] spill-table allocator
+    int32_t* work_counter = nullptr;  // [0] big-path dequeue, [1] spill-table allocator, [2..] rung counters
+    // pool of visited-set spill tables of the generic kernels (allocated on the first launch that can use it)
     uint32_t* spill = nullptr;
     int spill_tables = 0, spill_slots = 0;
-    int big_blocks = 0;
-    int big_cand_cap = 0;
-    size_t big_words = 0;
     // register-pool kernel: per-resident-workgroup expansion logs
     int32_t* pqr_log = nullptr;
     size_t pqr_log_ints = 0;
@@ -142,6 +171,8 @@ struct PendingSearch {
     int32_t* out_stats;
     const uint64_t* accept;  // this query's doc filter (host words) or nullptr
     int64_t accept_docs;
+    int64_t visit_limit;
+    int32_t* out_flags;      // optional JV_QFLAG_* word
     int rc = 0;
     char err[256];
     enum { QUEUED, TAKEN } state = QUEUED;
@@ -160,7 +191,38 @@ struct Combiner {
 
 }  // namespace
 
+namespace {
+// The HBM-scratch rung's buffers (visited bitsets + candidate queues of its resident blocks): ONE set per device, shared
+// by every index and context on it, allocated on the first search and grown on demand.  Launches that use it are
+// ordered through `last_use` (they are the rare tail of a batch; the headline kernels never touch it).
+struct DeviceScratch {
+    std::mutex mu;
+    hipEvent_t last_use = nullptr;
+    uint32_t* big_visited = nullptr;
+    int64_t* big_cand = nullptr;
+    int blocks = 0, cand_cap = 0;
+    size_t words = 0;
+    std::atomic<int64_t> bytes{0};
+};
+DeviceScratch g_scratch[64];
+}  // namespace
+
+namespace {
+// device-resident copies of recently used doc-filter bitsets (per index), keyed by content hash + length
+struct FilterEntry {
+    uint64_t key = 0;
+    size_t words = 0;
+    uint64_t* d_words = nullptr;
+    size_t cap_words = 0;
+    uint64_t stamp = 0;
+    int users = 0;  // launches in flight that read it
+    hipEvent_t ready = nullptr;  // recorded after the upload: consumers on other streams wait for it
+};
+
+}  // namespace
+
 struct jv_index {
+    Opts opts;
     Combiner combiner;
     int device = 0;
     bool build_client = false;  // JV_DESC_BUILD_CLIENT: searches are launched under the builder's kernel name
@@ -170,11 +232,18 @@ struct jv_index {
     jv_index_info info{};
     std::vector<void*> owned;  // device allocations to free
     std::mutex mu;
+    std::condition_variable ctx_cv;
     std::vector<Ctx*> free_ctx;
     std::vector<Ctx*> all_ctx;
+    std::mutex filter_mu;
+    std::vector<FilterEntry> filters;  // device-side doc-filter cache
+    uint64_t filter_clock = 0;
+    int64_t filter_hits = 0, filter_misses = 0;
     Ctx* async_ctx = nullptr;
     std::mutex async_mu;
 };
+
+#define OPT(ixp, id) ((ixp)->opts.v[id].load(std::memory_order_relaxed))
 
 namespace {
 
@@ -222,8 +291,6 @@ void ctx_destroy(Ctx* c) {
     hipFree(c->d_arena);
     if (c->h_arena) hipHostFree(c->h_arena);
     if (c->h_query) hipHostFree(c->h_query);
-    hipFree(c->big_visited);
-    hipFree(c->big_cand);
     hipFree(c->work_counter);
     hipFree(c->spill);
     hipFree(c->pqr_log);
@@ -232,21 +299,46 @@ void ctx_destroy(Ctx* c) {
     delete c;
 }
 
+// a launch context: from the free list, a new one while the index is below its cap, else wait for a release
 int ctx_acquire(jv_index* ix, Ctx** out) {
-    {
-        std::lock_guard<std::mutex> lk(ix->mu);
+    std::unique_lock<std::mutex> lk(ix->mu);
+    for (;;) {
         if (!ix->free_ctx.empty()) {
             *out = ix->free_ctx.back();
             ix->free_ctx.pop_back();
             return JV_OK;
         }
+        const size_t cap = (size_t)std::max<int64_t>(1, OPT(ix, OPT_MAX_CONTEXTS));
+        if (ix->all_ctx.size() < cap + 1) return ctx_create(ix, out);  // (+1: the device-pointer API's own context)
+        ix->ctx_cv.wait(lk);
     }
-    std::lock_guard<std::mutex> lk(ix->mu);
-    return ctx_create(ix, out);
 }
 void ctx_release(jv_index* ix, Ctx* c) {
-    std::lock_guard<std::mutex> lk(ix->mu);
-    ix->free_ctx.push_back(c);
+    {
+        std::lock_guard<std::mutex> lk(ix->mu);
+        ix->free_ctx.push_back(c);
+    }
+    ix->ctx_cv.notify_one();
+}
+
+uint64_t hash_words(const uint64_t* w, size_t n) {
+    // 4 independent multiply-xorshift lanes over 64-bit words (~10 GB/s on one core), folded at the end
+    uint64_t h0 = 0x9E3779B97F4A7C15ull ^ n, h1 = 0xC2B2AE3D27D4EB4Full, h2 = 0x165667B19E3779F9ull, h3 = 0x27D4EB2F165667C5ull;
+    size_t i = 0;
+    for (; i + 4 <= n; i += 4) {
+        h0 = (h0 ^ w[i]) * 0xFF51AFD7ED558CCDull; h0 ^= h0 >> 29;
+        h1 = (h1 ^ w[i + 1]) * 0xC4CEB9FE1A85EC53ull; h1 ^= h1 >> 31;
+        h2 = (h2 ^ w[i + 2]) * 0x9FB21C651E98DF25ull; h2 ^= h2 >> 30;
+        h3 = (h3 ^ w[i + 3]) * 0xD6E8FEB86659FD93ull; h3 ^= h3 >> 28;
+    }
+    for (; i < n; i++) {
+        h0 = (h0 ^ w[i]) * 0xFF51AFD7ED558CCDull; h0 ^= h0 >> 29;
+    }
+    uint64_t h = h0 ^ (h1 * 3) ^ (h2 * 5) ^ (h3 * 7);
+    h ^= h >> 32;
+    h *= 0xD6E8FEB86659FD93ull;
+    h ^= h >> 29;
+    return h ? h : 1;
 }
 
 struct Geometry {
@@ -263,9 +355,9 @@ Geometry plan_geometry(const jv_index* ix, int rk, bool pool_ok, int force_slots
     const bool pq = d.pq_M > 0;
     int fixed = d.nch * 64 * 4 + JV_TODO * 16 + (pq ? d.pq_M * 256 * 4 + d.nch * 64 * 4 : 0) + (tracker ? JV_TRACKER_LDS : 0);
     g.lds_big = fixed;
-    int64_t hs = opt_lds_visited_slots.load();
-    int64_t cc = opt_lds_candidates.load();
-    g.pool = pool_ok && opt_force_general.load() == 0;
+    int64_t hs = OPT(ix, OPT_LDS_VISITED_SLOTS);
+    int64_t cc = OPT(ix, OPT_LDS_CANDIDATES);
+    g.pool = pool_ok && OPT(ix, OPT_FORCE_GENERAL) == 0;
     // visited set: ~10-25 x rerankK nodes at R=32; the table may fill to 75 %.  Overflow is not an error:
     // the query is re-run exactly on the HBM-scratch path.
     g.hash_slots = hs > 0 ? next_pow2((int)hs) : next_pow2(rk * 24 < 1024 ? 1024 : rk * 24);
@@ -294,8 +386,9 @@ Geometry plan_geometry(const jv_index* ix, int rk, bool pool_ok, int force_slots
     return g;
 }
 
-int ensure_big(jv_index* ix, Ctx* c, int rk) {
-    int cap = (int)opt_big_cand_cap.load();
+// size / grow the device's shared HBM-scratch (caller holds sc.mu)
+int ensure_big(jv_index* ix, DeviceScratch& sc, int rk) {
+    int cap = (int)OPT(ix, OPT_BIG_CAND_CAP);
     int res_cap = ((rk + 1) & ~1);
     if (cap < 4 * rk) cap = 4 * rk;
     // the candidate queue never holds more than every node once; the addTopCandidate log of the PQ rungs (one entry per
@@ -304,31 +397,38 @@ int ensure_big(jv_index* ix, Ctx* c, int rk) {
     cap += res_cap;
     size_t words = ((size_t)ix->dev.n + 31) / 32;
     if (words == 0) words = 1;
-    int blocks = (int)opt_big_blocks.load();
+    if (!sc.last_use) HIPCHK(hipEventCreateWithFlags(&sc.last_use, hipEventDisableTiming));
+    int blocks = (int)OPT(ix, OPT_BIG_BLOCKS);
     if (blocks < 1) {
         // queries that outgrow the on-chip scratch (selective filters, huge rerankK) run here: the more resident
-        // blocks, the more of them run side by side
-        if (c->big_blocks > 0 && c->big_words == words && c->big_cand_cap >= cap) {
-            blocks = c->big_blocks;
-        } else {
-            const size_t per = words * sizeof(uint32_t) + (size_t)cap * sizeof(int64_t);
-            blocks = (int)std::min<size_t>(1024, std::max<size_t>(64, ((size_t)768 << 20) / per));
-        }
+        // blocks, the more of them run side by side; sized to the budget
+        const size_t per = words * sizeof(uint32_t) + (size_t)cap * sizeof(int64_t);
+        const size_t budget = (size_t)std::max<int64_t>(16, OPT(ix, OPT_BIG_BUDGET_MB)) << 20;
+        blocks = (int)std::min<size_t>(1024, std::max<size_t>(16, budget / per));
     }
-    if (c->big_blocks != blocks || c->big_words != words) {
-        if (c->big_visited) HIPCHK(hipFree(c->big_visited));
-        c->big_visited = nullptr;
-        HIPCHK(hipMalloc((void**)&c->big_visited, (size_t)blocks * words * sizeof(uint32_t)));
-        c->big_words = words;
-    }
-    if (c->big_blocks != blocks || c->big_cand_cap < cap) {
-        if (c->big_cand) HIPCHK(hipFree(c->big_cand));
-        c->big_cand = nullptr;
-        HIPCHK(hipMalloc((void**)&c->big_cand, (size_t)blocks * (size_t)cap * sizeof(int64_t)));
-        c->big_cand_cap = cap;
-    }
-    c->big_blocks = blocks;
-    const int st = (int)opt_spill_tables.load(), ss = next_pow2((int)opt_spill_slots.load());
+    if (sc.big_visited && sc.blocks >= blocks && sc.words >= words && sc.cand_cap >= cap) return JV_OK;
+    // grow: wait for the launches still using the old buffers
+    HIPCHK(hipEventSynchronize(sc.last_use));
+    blocks = std::max(blocks, sc.blocks);
+    words = std::max(words, sc.words);
+    cap = std::max(cap, sc.cand_cap);
+    if (sc.big_visited) HIPCHK(hipFree(sc.big_visited));
+    if (sc.big_cand) HIPCHK(hipFree(sc.big_cand));
+    sc.big_visited = nullptr;
+    sc.big_cand = nullptr;
+    sc.blocks = 0;
+    sc.bytes = 0;
+    HIPCHK(hipMalloc((void**)&sc.big_visited, (size_t)blocks * words * sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void**)&sc.big_cand, (size_t)blocks * (size_t)cap * sizeof(int64_t)));
+    sc.blocks = blocks;
+    sc.words = words;
+    sc.cand_cap = cap;
+    sc.bytes = (int64_t)((size_t)blocks * words * sizeof(uint32_t) + (size_t)blocks * (size_t)cap * sizeof(int64_t));
+    return JV_OK;
+}
+
+int ensure_spill(jv_index* ix, Ctx* c) {
+    const int st = (int)OPT(ix, OPT_SPILL_TABLES), ss = next_pow2((int)OPT(ix, OPT_SPILL_SLOTS));
     if (c->spill_tables != st || c->spill_slots != ss) {
         if (c->spill) HIPCHK(hipFree(c->spill));
         c->spill = nullptr;
@@ -346,14 +446,14 @@ int ensure_big(jv_index* ix, Ctx* c, int rk) {
 int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queries, int nq, int topK, int rk,
                   float thr, float floor_, const uint64_t* d_accept, int64_t accept_docs, int32_t* d_nodes,
                   int32_t* d_docs, float* d_scores, int32_t* d_count, int32_t* d_stats, int32_t* d_flags,
-                  int64_t accept_stride = 0) {
+                  int64_t accept_stride = 0, int64_t visit_limit = 0) {
     const bool pq = ix->dev.pq_M > 0;
     // the single-pool form is exact only without a filter and with threshold <= 0 (kernel re-checks scores)
     Geometry g = plan_geometry(ix, rk, d_accept == nullptr && thr <= 0.0f, 0, thr > 0.0f);
     if (g.lds_big > kMaxLds)
         return fail(JV_EUNSUPPORTED, "query + PQ look-up table need %d B of LDS (> %d): pq_M=%d too large", g.lds_big,
                     kMaxLds, ix->dev.pq_M);
-    int rc = ensure_big(ix, c, rk);
+    int rc = ensure_spill(ix, c);
     if (rc != JV_OK) return rc;
     JvSearchArgs a{};
     a.queries = d_queries;
@@ -375,9 +475,7 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
     a.hash_slots = g.hash_slots;
     a.cand_cap = g.cand_cap;
     a.res_cap = g.res_cap;
-    a.big_visited = c->big_visited;
-    a.big_cand = c->big_cand;
-    a.big_cand_cap = c->big_cand_cap;
+    a.visit_limit = visit_limit > 0 ? (int32_t)std::min<int64_t>(visit_limit, INT32_MAX) : 0;
     a.work_counter = c->work_counter;
     a.retry_only = 0;
     a.spill = c->spill;
@@ -385,8 +483,8 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
     a.spill_tables = c->spill_tables;
     a.spill_counter = c->work_counter + 1;
     a.retry_counter = c->work_counter + 2;
-    a.dbg = (int64_t*)(uintptr_t)opt_dbg_ptr.load();  // always 0 unless a diagnostic run set it
-    const bool force_big = opt_force_big.load() != 0 || !g.fast_ok;
+    a.dbg = (int64_t*)(uintptr_t)OPT(ix, OPT_DBG_PTR);  // always 0 unless a diagnostic run set it
+    const bool force_big = OPT(ix, OPT_FORCE_BIG) != 0 || !g.fast_ok;
     HIPCHK(hipMemsetAsync(c->work_counter, 0, 8 * sizeof(int32_t), stream));
     // headline path: PQ + fused layout + single pool + flat graph -> specialised kernel without an in-loop
     // visited set (jv_kernels.hip "PQF"); anything it cannot hold is flagged and falls through to the ladder
@@ -398,8 +496,8 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
                            (ix->dev.R * ix->dev.pq_lanes + JV_WAVE - 1) / JV_WAVE <= ix->dev.pq_lanes;
     // headline path: the persistent LDS-pool kernel (jv_kernels_pqp.hip): no filter, threshold <= 0; LDS = look-up table +
     // pool of rk + 64 boundary ties + one expansion's R new keys (+ 1 sentinel slot); the expansion log lives in HBM
-    if (!force_big && !filtered && g.pool && pqf_index && rk + 64 + ix->dev.R <= jvk_pqp_max_entries() && opt_no_pqf.load() == 0 &&
-        opt_no_pqp.load() == 0) {
+    if (!force_big && !filtered && g.pool && pqf_index && rk + 64 + ix->dev.R <= jvk_pqp_max_entries() && OPT(ix, OPT_NO_PQF) == 0 &&
+        OPT(ix, OPT_NO_PQP) == 0) {
         JvSearchArgs ap = a;
         const int lut_b = ix->dev.pq_M * 256 * 4;
         const int qc_b = ix->dev.nch * 64 * 4;
@@ -412,7 +510,7 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
         const int rerank_b = qc_b + JV_TODO * 8 + ((rk + 1) & ~1) * 8;   // after the search, in front of the pool
         // Table in registers (8 resident queries per CU, +34 % throughput at rerankK = 1 200, but 1.7x the latency of
         // one query): only when the launch has more queries than the LDS-table variant could keep resident anyway
-        const int lutr = (opt_no_lutr.load() == 0 && jvk_pqp_lutr_ok(&ix->dev, ap.cand_cap) && nq > 4 * ix->cu_count) ? 1 : 0;
+        const int lutr = (OPT(ix, OPT_NO_LUTR) == 0 && jvk_pqp_lutr_ok(&ix->dev, ap.cand_cap) && nq > 4 * ix->cu_count) ? 1 : 0;
         int lds;
         if (lutr) {
             // table in registers: LDS = the pool while searching, one hash set afterwards (>= 4 096 slots), then the
@@ -449,8 +547,8 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
     }
     // (comparison only, option no_pqr = 0) the register-pool kernel (jv_kernels_pqr.hip): no filter, threshold <= 0, pool of rk + 64 boundary
     // ties + one expansion's R new keys in at most 2 048 register slots; LDS = the look-up table only
-    if (!pqf && !force_big && !filtered && g.pool && pqf_index && rk + 64 + ix->dev.R <= jvk_pqr_capacity() && opt_no_pqf.load() == 0 &&
-        opt_no_pqr.load() == 0) {
+    if (!pqf && !force_big && !filtered && g.pool && pqf_index && rk + 64 + ix->dev.R <= jvk_pqr_capacity() && OPT(ix, OPT_NO_PQF) == 0 &&
+        OPT(ix, OPT_NO_PQR) == 0) {
         JvSearchArgs ap = a;
         const int lut_b = ix->dev.pq_M * 256 * 4;
         const int qc_b = ix->dev.nch * 64 * 4;
@@ -485,7 +583,7 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
             pqf = true;
         }
     }
-    if (!pqf && !force_big && pqf_index && pqf_shape && rk + 64 + ix->dev.R <= 1024 && opt_no_pqf.load() == 0) {
+    if (!pqf && !force_big && pqf_index && pqf_shape && rk + 64 + ix->dev.R <= 1024 && OPT(ix, OPT_NO_PQF) == 0) {
         JvSearchArgs ap = a;
         const int lut_b = ix->dev.pq_M * 256 * 4;
         ap.cand_cap = (rk + 64 + ix->dev.R + 1) & ~1;  // pool entries: rk + 64 boundary ties + one merge of <= R new keys
@@ -514,7 +612,7 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
         if (shape_ok && rerank_b <= lut_b && loop_bytes(ap) <= kMaxLds) {
             HIPCHK(jvk_launch_search_pqf(&ix->dev, &ap, (loop_bytes(ap) + 15) & ~15, stream));
             pqf = true;
-            if (second_rung && opt_pqf_only.load() == 0) {
+            if (second_rung && OPT(ix, OPT_PQF_ONLY) == 0) {
                 JvSearchArgs ap2 = ap;
                 ap2.cand_cap = 960;
                 ap2.res_cap = 2048;
@@ -524,14 +622,14 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
             }
         }
     }
-    if (pqf && opt_pqf_only.load() != 0) return JV_OK;
+    if (pqf && OPT(ix, OPT_PQF_ONLY) != 0) return JV_OK;
     if (!force_big) {
         if (!pqf)
             HIPCHK(jvk_launch_search_lds(&ix->dev, &a, pq ? 1 : 0, g.pool ? 1 : 0, ix->build_client ? 2 : 0, g.lds_fast, stream));
         // (after a PQF launch the flagged queries go straight to the rung below: generic kernel, 4x visited table)
         // escalation: queries that overflowed the on-chip visited set are retried with a 4x larger table
         // (fewer resident queries, but only the flagged few run) before the HBM-scratch path
-        if (opt_lds_visited_slots.load() <= 0 && opt_no_escalation.load() == 0) {
+        if (OPT(ix, OPT_LDS_VISITED_SLOTS) <= 0 && OPT(ix, OPT_NO_ESCALATION) == 0) {
             Geometry g2 = plan_geometry(ix, rk, g.pool, g.hash_slots * 4, thr > 0.0f);
             if (g2.fast_ok && g2.hash_slots > g.hash_slots) {
                 JvSearchArgs a2 = a;
@@ -544,7 +642,19 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
             }
         }
     }
-    HIPCHK(jvk_launch_search_big(&ix->dev, &a, pq ? 1 : 0, c->big_blocks, g.lds_big, force_big ? 1 : 0, stream));
+    {
+        // last rung: the device's shared HBM scratch; its users are ordered through the scratch event
+        DeviceScratch& sc = g_scratch[ix->device & 63];
+        std::lock_guard<std::mutex> lk(sc.mu);
+        rc = ensure_big(ix, sc, rk);
+        if (rc != JV_OK) return rc;
+        a.big_visited = sc.big_visited;
+        a.big_cand = sc.big_cand;
+        a.big_cand_cap = sc.cand_cap;
+        HIPCHK(hipStreamWaitEvent(stream, sc.last_use, 0));
+        HIPCHK(jvk_launch_search_big(&ix->dev, &a, pq ? 1 : 0, sc.blocks, g.lds_big, force_big ? 1 : 0, stream));
+        HIPCHK(hipEventRecord(sc.last_use, stream));
+    }
     return JV_OK;
 }
 
@@ -568,26 +678,17 @@ const char* jv_last_error(void) { return g_last_error.c_str(); }
 
 int jv_set_option(const char* name, int64_t value) {
     if (!name) return fail(JV_EINVAL, "option name is NULL");
-    std::string n(name);
-    if (n == "lds_visited_slots") opt_lds_visited_slots = value;
-    else if (n == "lds_candidates") opt_lds_candidates = value;
-    else if (n == "force_big_path") opt_force_big = value;
-    else if (n == "force_general_path") opt_force_general = value;
-    else if (n == "no_escalation") opt_no_escalation = value;
-    else if (n == "dbg_ptr") opt_dbg_ptr = value;
-    else if (n == "no_pqf") opt_no_pqf = value;
-    else if (n == "no_pqr") opt_no_pqr = value;
-    else if (n == "no_pqp") opt_no_pqp = value;
-    else if (n == "no_lutr") opt_no_lutr = value;
-    else if (n == "pqf_only") opt_pqf_only = value;
-    else if (n == "spill_tables") opt_spill_tables = value;
-    else if (n == "spill_slots") opt_spill_slots = value;
-    else if (n == "big_blocks") opt_big_blocks = value;
-    else if (n == "big_cand_cap") opt_big_cand_cap = value;
-    else if (n == "combine") opt_combine = value;
-    else if (n == "combine_leaders") opt_combine_leaders = value;
-    else if (n == "combine_max_batch") opt_combine_max_batch = value;
-    else return fail(JV_EINVAL, "unknown option '%s'", name);
+    const int id = g_default_opts.find(name);
+    if (id < 0) return fail(JV_EINVAL, "unknown option '%s'", name);
+    g_default_opts.v[id].store(value);
+    return JV_OK;
+}
+
+int jv_index_set_option(jv_index* index, const char* name, int64_t value) {
+    if (!index || !name) return fail(JV_EINVAL, "index/name is NULL");
+    const int id = index->opts.find(name);
+    if (id < 0) return fail(JV_EINVAL, "unknown option '%s'", name);
+    index->opts.v[id].store(value);
     return JV_OK;
 }
 
@@ -596,6 +697,10 @@ void jv_index_destroy(jv_index* ix) {
     hipSetDevice(ix->device);
     hipDeviceSynchronize();
     for (Ctx* c : ix->all_ctx) ctx_destroy(c);
+    for (FilterEntry& f : ix->filters) {
+        hipFree(f.d_words);
+        if (f.ready) hipEventDestroy(f.ready);
+    }
     for (void* p : ix->owned) hipFree(p);
     delete ix;
 }
@@ -633,6 +738,7 @@ int jv_index_create(const jv_index_desc* desc, jv_index** out) {
     HIPCHK(hipSetDevice(desc->device));
 
     jv_index* ix = new jv_index();
+    ix->opts.copy_from(g_default_opts);
     ix->device = desc->device;
     ix->build_client = (desc->flags & JV_DESC_BUILD_CLIENT) != 0;
     JvIndexDev& D = ix->dev;
@@ -827,6 +933,21 @@ error:
 int jv_index_get_info(const jv_index* index, jv_index_info* out) {
     if (!index || !out) return fail(JV_EINVAL, "index/out is NULL");
     *out = index->info;
+    jv_index* ix = const_cast<jv_index*>(index);
+    int64_t scratch = g_scratch[index->device & 63].bytes.load();
+    {
+        std::lock_guard<std::mutex> lk(ix->mu);
+        for (const Ctx* c : ix->all_ctx)
+            scratch += (int64_t)(c->queries_cap * 4 + c->nq_cap * 4 + c->accept_cap * 8 + c->arena_cap + c->pqr_log_ints * 4 +
+                                 (size_t)c->spill_tables * (size_t)c->spill_slots * 4 + 32);
+    }
+    {
+        std::lock_guard<std::mutex> lk(ix->filter_mu);
+        for (const FilterEntry& f : ix->filters) scratch += (int64_t)f.cap_words * 8;
+        out->filter_cache_hits = ix->filter_hits;
+        out->filter_cache_misses = ix->filter_misses;
+    }
+    out->scratch_bytes = scratch;
     return JV_OK;
 }
 
@@ -844,6 +965,16 @@ int jv_search_batch_device(jv_index* index, const float* d_queries, int32_t nq, 
     Ctx* c = index->async_ctx;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
     if (c->last_stream && c->last_stream != s) HIPCHK(hipStreamWaitEvent(s, c->last_use, 0));
+    // whatever happens below (also a failure after a partial enqueue), the next call on another stream must be ordered
+    // behind the kernels that may already use this context's counters and scratch
+    struct UseGuard {
+        Ctx* c;
+        hipStream_t s;
+        ~UseGuard() {
+            hipEventRecord(c->last_use, s);
+            c->last_stream = s;
+        }
+    } use_guard{c, s};
     if (!d_out_flags) {
         rc = grow((void**)&c->d_flags, &c->nq_cap, (size_t)nq, sizeof(int32_t));
         if (rc != JV_OK) return rc;
@@ -863,8 +994,6 @@ int jv_search_batch_device(jv_index* index, const float* d_queries, int32_t nq, 
                            accept_num_docs, d_out_nodes, d_out_docs, d_out_scores, d_out_count, d_out_stats, d_out_flags);
         if (rc != JV_OK) return rc;
     }
-    HIPCHK(hipEventRecord(c->last_use, s));
-    c->last_stream = s;
     if (!hip_stream) HIPCHK(hipStreamSynchronize(s));
     return JV_OK;
 }
@@ -873,16 +1002,85 @@ int jv_search_batch_device(jv_index* index, const float* d_queries, int32_t nq, 
 
 namespace {
 
+// Doc-filter cache: a host bitset that was uploaded before (same 64-bit content hash — or caller-supplied key — and
+// length) is served from HBM instead of crossing PCIe again (1.25 MB per call at 10M docs).  Returns slot >= 0 and the
+// device pointer, or slot = -1 when the cache is off / full of filters in use (the caller then stages the words itself).
+int filter_acquire(jv_index* ix, const uint64_t* words, size_t nwords, uint64_t key, hipStream_t stream, const uint64_t** d_out,
+                   int* slot) {
+    *slot = -1;
+    const int cap = (int)OPT(ix, OPT_FILTER_CACHE);
+    if (cap <= 0 || nwords == 0) return JV_OK;
+    if (!key) key = hash_words(words, nwords);
+    std::lock_guard<std::mutex> lk(ix->filter_mu);
+    int victim = -1;
+    for (size_t i = 0; i < ix->filters.size(); i++) {
+        FilterEntry& f = ix->filters[i];
+        if (f.key == key && f.words == nwords && f.d_words) {
+            f.users++;
+            f.stamp = ++ix->filter_clock;
+            ix->filter_hits++;
+            HIPCHK(hipStreamWaitEvent(stream, f.ready, 0));
+            *d_out = f.d_words;
+            *slot = (int)i;
+            return JV_OK;
+        }
+        if (f.users == 0 && (victim < 0 || f.stamp < ix->filters[(size_t)victim].stamp)) victim = (int)i;
+    }
+    if ((int)ix->filters.size() < cap) {
+        ix->filters.emplace_back();
+        victim = (int)ix->filters.size() - 1;
+    }
+    if (victim < 0) return JV_OK;
+    FilterEntry& f = ix->filters[(size_t)victim];
+    if (!f.ready) HIPCHK(hipEventCreateWithFlags(&f.ready, hipEventDisableTiming));
+    if (f.cap_words < nwords) {
+        // (the entry is not in use: every launch that read it has been synchronised by its caller)
+        if (f.d_words) HIPCHK(hipFree(f.d_words));
+        f.d_words = nullptr;
+        f.cap_words = 0;
+        f.key = 0;
+        HIPCHK(hipMalloc((void**)&f.d_words, nwords * 8));
+        f.cap_words = nwords;
+    }
+    f.key = 0;  // not valid until the copy is enqueued
+    HIPCHK(hipMemcpyAsync(f.d_words, words, nwords * 8, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipEventRecord(f.ready, stream));
+    f.key = key;
+    f.words = nwords;
+    f.users = 1;
+    f.stamp = ++ix->filter_clock;
+    ix->filter_misses++;
+    *d_out = f.d_words;
+    *slot = victim;
+    return JV_OK;
+}
+void filter_release(jv_index* ix, int slot) {
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lk(ix->filter_mu);
+    ix->filters[(size_t)slot].users--;
+}
+
+struct HostSearchExtras {
+    int64_t visit_limit = 0;
+    uint64_t accept_key = 0;
+    int32_t* out_status = nullptr;  // [nq] per-query JV_OK / JV_ENOMEM
+    int32_t* out_flags = nullptr;   // [nq] JV_QFLAG_*
+};
+
 // host-pointer batch.  `accept_list` (optional, nq host pointers) gives every query its own doc filter of
 // accept_num_docs bits; `accept_doc_words` is one filter shared by the whole batch.
+// Returns JV_ENOMEM when at least one query could not be answered (its row is empty and out_status[i] says so); the
+// rows of every other query are valid.
 int search_batch_host(jv_index* index, const float* queries, int32_t nq, int32_t topK, int32_t rerankK,
                       float threshold, float rerankFloor, const uint64_t* accept_doc_words,
                       const uint64_t* const* accept_list, int64_t accept_num_docs, int32_t* out_nodes, int32_t* out_docs,
-                      float* out_scores, int32_t* out_count, int32_t* out_stats) {
+                      float* out_scores, int32_t* out_count, int32_t* out_stats, const HostSearchExtras& ex = HostSearchExtras()) {
     int rc = check_common(index, queries, nq, topK, rerankK, threshold);
     if (rc != JV_OK) return rc;
     if (nq == 0) return JV_OK;
     const size_t outn = (size_t)nq * (size_t)topK;
+    if (ex.out_status) memset(ex.out_status, 0, sizeof(int32_t) * (size_t)nq);
+    if (ex.out_flags) memset(ex.out_flags, 0, sizeof(int32_t) * (size_t)nq);
     if (topK == 0 || index->dev.n == 0 || index->dev.entry < 0) {
         for (size_t i = 0; i < outn; i++) {
             if (out_nodes) out_nodes[i] = -1;
@@ -897,11 +1095,19 @@ int search_batch_host(jv_index* index, const float* queries, int32_t nq, int32_t
     Ctx* c = nullptr;
     rc = ctx_acquire(index, &c);
     if (rc != JV_OK) return rc;
+    int filter_slot = -1;
     struct Releaser {
         jv_index* ix;
         Ctx* c;
-        ~Releaser() { ctx_release(ix, c); }
-    } rel{index, c};
+        int* slot;
+        ~Releaser() {
+            // (a failed call may leave work in flight on the context's stream: drain it before the context or the
+            // cached filter can be handed to another caller)
+            hipStreamSynchronize(c->stream);
+            filter_release(ix, *slot);
+            ctx_release(ix, c);
+        }
+    } rel{index, c, &filter_slot};
     const int d = index->dev.d;
     if ((rc = grow((void**)&c->d_queries, &c->queries_cap, (size_t)nq * d, sizeof(float))) != JV_OK) return rc;
     // arena layout (4-byte units)
@@ -929,16 +1135,31 @@ int search_batch_host(jv_index* index, const float* queries, int32_t nq, int32_t
     int64_t accept_stride = 0;
     if (accept_doc_words || accept_list) {
         if (accept_num_docs < 0) return fail(JV_EINVAL, "accept_num_docs < 0");
-        size_t words = ((size_t)accept_num_docs + 63) / 64;
-        if (words == 0) words = 1;
-        const size_t sets = accept_list ? (size_t)nq : 1;
-        if ((rc = grow((void**)&c->d_accept, &c->accept_cap, words * sets, 8)) != JV_OK) return rc;
         const size_t copy_words = ((size_t)accept_num_docs + 63) / 64;
-        for (size_t i = 0; i < sets && copy_words; i++)
-            HIPCHK(hipMemcpyAsync(c->d_accept + i * words, accept_list ? accept_list[i] : accept_doc_words, copy_words * 8,
-                                  hipMemcpyHostToDevice, c->stream));
-        d_accept = c->d_accept;
-        accept_stride = accept_list ? (int64_t)words : 0;
+        size_t words = copy_words ? copy_words : 1;
+        // one filter for the whole batch (given as such, or every caller of a combined batch passed the same bits)?
+        const uint64_t* shared = accept_doc_words;
+        uint64_t key = ex.accept_key;
+        if (!shared && accept_list && copy_words && OPT(index, OPT_FILTER_CACHE) > 0) {
+            key = hash_words(accept_list[0], copy_words);
+            bool same = true;
+            for (int i = 1; i < nq && same; i++)
+                same = accept_list[i] == accept_list[0] || hash_words(accept_list[i], copy_words) == key;
+            if (same) shared = accept_list[0];
+            else key = 0;
+        }
+        if (shared && copy_words) {
+            if ((rc = filter_acquire(index, shared, copy_words, key, c->stream, &d_accept, &filter_slot)) != JV_OK) return rc;
+        }
+        if (!d_accept) {
+            const size_t sets = shared ? 1 : (size_t)nq;
+            if ((rc = grow((void**)&c->d_accept, &c->accept_cap, words * sets, 8)) != JV_OK) return rc;
+            for (size_t i = 0; i < sets && copy_words; i++)
+                HIPCHK(hipMemcpyAsync(c->d_accept + i * words, shared ? shared : accept_list[i], copy_words * 8,
+                                      hipMemcpyHostToDevice, c->stream));
+            d_accept = c->d_accept;
+            accept_stride = shared ? 0 : (int64_t)words;
+        }
     }
     const size_t qbytes = (size_t)nq * d * sizeof(float);
     if (qbytes <= (1u << 20)) {  // small batches: stage through pinned memory (a pageable H2D is a blocking staged copy)
@@ -954,7 +1175,7 @@ int search_batch_host(jv_index* index, const float* queries, int32_t nq, int32_t
         HIPCHK(hipMemcpyAsync(c->d_queries, queries, qbytes, hipMemcpyHostToDevice, c->stream));
     }
     rc = enqueue_batch(index, c, c->stream, c->d_queries, nq, topK, rerankK, threshold, rerankFloor, d_accept,
-                       accept_num_docs, dn, dd, dsc, dc, dst, dfl, accept_stride);
+                       accept_num_docs, dn, dd, dsc, dc, dst, dfl, accept_stride, ex.visit_limit);
     if (rc != JV_OK) return rc;
     HIPCHK(hipMemcpyAsync(c->h_arena, c->d_arena, total4 * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -965,11 +1186,19 @@ int search_batch_host(jv_index* index, const float* queries, int32_t nq, int32_t
     if (out_count) memcpy(out_count, h32 + o_count, (size_t)nq * 4);
     if (out_stats) memcpy(out_stats, h32 + o_stats, (size_t)nq * 16);
     const int32_t* flags = h32 + o_flags;
+    int failed = 0, first = -1;
     for (int i = 0; i < nq; i++) {
-        if ((uint32_t)flags[i] & (JV_FLAG_FAILED | JV_FLAG_OVERFLOW))
-            return fail(JV_ENOMEM, "query %d overflowed the HBM scratch (big_cand_cap=%d); raise option big_cand_cap", i,
-                        c->big_cand_cap);
+        const uint32_t f = (uint32_t)flags[i];
+        if (ex.out_flags) ex.out_flags[i] = (int32_t)(f & (JV_FLAG_BIG | JV_FLAG_EARLY));
+        if (f & (JV_FLAG_FAILED | JV_FLAG_OVERFLOW)) {
+            if (ex.out_status) ex.out_status[i] = JV_ENOMEM;
+            if (first < 0) first = i;
+            failed++;
+        }
     }
+    if (failed)
+        return fail(JV_ENOMEM, "%d of %d queries (first: %d) overflowed the HBM scratch; raise option big_cand_cap (the other rows are valid)",
+                    failed, nq, first);
     return JV_OK;
 }
 
@@ -1010,16 +1239,28 @@ void pass_leadership(Combiner& cb) {
 
 extern "C" {
 
-int jv_search(jv_index* index, const float* query, int32_t topK, int32_t rerankK, float threshold,
-              float rerankFloor, const uint64_t* accept_doc_words, int64_t accept_num_docs, int32_t* out_nodes,
-              int32_t* out_docs, float* out_scores, int32_t* out_count, int32_t* out_stats) {
+}  // extern "C"
+
+namespace {
+
+// one query per call; concurrent calls on one handle are combined into batch launches (group commit)
+int search_single(jv_index* index, const float* query, int32_t topK, int32_t rerankK, float threshold,
+                  float rerankFloor, const uint64_t* accept_doc_words, int64_t accept_num_docs, int64_t visit_limit,
+                  uint64_t accept_key, int32_t* out_nodes, int32_t* out_docs, float* out_scores, int32_t* out_count,
+                  int32_t* out_stats, int32_t* out_flags) {
     int rc = check_common(index, query, 1, topK, rerankK, threshold);
     if (rc != JV_OK) return rc;
     if (accept_doc_words && accept_num_docs < 0) return fail(JV_EINVAL, "accept_num_docs < 0");
+    if (visit_limit < 0) return fail(JV_EINVAL, "visit_limit < 0");
     // degenerate calls are not combined
-    if (opt_combine.load() == 0 || topK == 0 || index->dev.n == 0 || index->dev.entry < 0)
-        return jv_search_batch(index, query, 1, topK, rerankK, threshold, rerankFloor, accept_doc_words, accept_num_docs,
-                               out_nodes, out_docs, out_scores, out_count, out_stats);
+    if (OPT(index, OPT_COMBINE) == 0 || topK == 0 || index->dev.n == 0 || index->dev.entry < 0) {
+        HostSearchExtras ex;
+        ex.visit_limit = visit_limit;
+        ex.accept_key = accept_key;
+        ex.out_flags = out_flags;
+        return search_batch_host(index, query, 1, topK, rerankK, threshold, rerankFloor, accept_doc_words, nullptr,
+                                 accept_num_docs, out_nodes, out_docs, out_scores, out_count, out_stats, ex);
+    }
     Combiner& cb = index->combiner;
     PendingSearch me;
     me.query = query;
@@ -1034,6 +1275,8 @@ int jv_search(jv_index* index, const float* query, int32_t topK, int32_t rerankK
     me.out_stats = out_stats;
     me.accept = accept_doc_words;
     me.accept_docs = accept_doc_words ? accept_num_docs : 0;
+    me.visit_limit = visit_limit;
+    me.out_flags = out_flags;
     me.err[0] = 0;
     sem_init(&me.sem, 0, 0);
     auto finish = [&](int code) {
@@ -1043,7 +1286,7 @@ int jv_search(jv_index* index, const float* query, int32_t topK, int32_t rerankK
     };
     std::unique_lock<std::mutex> lk(cb.mu);
     cb.queue.push_back(&me);
-    int leaders = (int)opt_combine_leaders.load();
+    int leaders = (int)OPT(index, OPT_COMBINE_LEADERS);
     if (leaders < 1) leaders = 1;
     if (cb.active < leaders) {
         cb.active++;
@@ -1064,10 +1307,10 @@ int jv_search(jv_index* index, const float* query, int32_t topK, int32_t rerankK
     }
     static thread_local std::vector<PendingSearch*> batch;
     static thread_local std::vector<float> qbuf, sbuf;
-    static thread_local std::vector<int32_t> nbuf, dbuf, cbuf, stbuf;
+    static thread_local std::vector<int32_t> nbuf, dbuf, cbuf, stbuf, statusbuf, flagbuf;
     static thread_local std::vector<const uint64_t*> abuf;
     batch.clear();
-    size_t max_batch = (size_t)std::max<int64_t>(1, opt_combine_max_batch.load());
+    size_t max_batch = (size_t)std::max<int64_t>(1, OPT(index, OPT_COMBINE_MAX_BATCH));
     if (me.accept) {  // filtered calls batch with filtered calls over the same doc space; bound the staged filter bytes
         const size_t fbytes = (((size_t)me.accept_docs + 63) / 64) * 8 + 8;
         max_batch = std::min(max_batch, std::max<size_t>(1, ((size_t)64 << 20) / fbytes));
@@ -1076,7 +1319,8 @@ int jv_search(jv_index* index, const float* query, int32_t topK, int32_t rerankK
         PendingSearch* r = *it;
         const bool same = r == &me || (batch.size() + 1 < max_batch && r->state == PendingSearch::QUEUED && r->topK == topK &&
                                        r->rerankK == rerankK && r->threshold == threshold && r->rerankFloor == rerankFloor &&
-                                       (r->accept != nullptr) == (me.accept != nullptr) && r->accept_docs == me.accept_docs);
+                                       (r->accept != nullptr) == (me.accept != nullptr) && r->accept_docs == me.accept_docs &&
+                                       r->visit_limit == me.visit_limit);
         if (same) {
             r->state = PendingSearch::TAKEN;
             batch.push_back(r);
@@ -1090,8 +1334,12 @@ int jv_search(jv_index* index, const float* query, int32_t topK, int32_t rerankK
     bool passed = false;
     try {
     if (nb == 1) {
-        rc = jv_search_batch(index, query, 1, topK, rerankK, threshold, rerankFloor, me.accept, me.accept_docs, out_nodes,
-                             out_docs, out_scores, out_count, out_stats);
+        HostSearchExtras ex;
+        ex.visit_limit = visit_limit;
+        ex.accept_key = accept_key;
+        ex.out_flags = out_flags;
+        rc = search_batch_host(index, query, 1, topK, rerankK, threshold, rerankFloor, me.accept, nullptr, me.accept_docs,
+                               out_nodes, out_docs, out_scores, out_count, out_stats, ex);
         if (rc != JV_OK) snprintf(me.err, sizeof(me.err), "%s", g_last_error.c_str());
     } else {
         qbuf.resize(nb * d);
@@ -1105,9 +1353,21 @@ int jv_search(jv_index* index, const float* query, int32_t topK, int32_t rerankK
             memcpy(qbuf.data() + i * d, batch[i]->query, d * sizeof(float));
             abuf[i] = batch[i]->accept;
         }
+        statusbuf.assign(nb, 0);
+        flagbuf.assign(nb, 0);
+        HostSearchExtras ex;
+        ex.visit_limit = visit_limit;
+        ex.out_status = statusbuf.data();
+        ex.out_flags = flagbuf.data();
         rc = search_batch_host(index, qbuf.data(), (int32_t)nb, topK, rerankK, threshold, rerankFloor, nullptr,
                                me.accept ? abuf.data() : nullptr, me.accept_docs, nbuf.data(), dbuf.data(), sbuf.data(),
-                               cbuf.data(), stbuf.data());
+                               cbuf.data(), stbuf.data(), ex);
+        // every caller gets ITS query's status: a query that outgrew even the HBM scratch fails alone, like a
+        // failing GraphSearcher.search call in the reference would; a launch-level error (rc set, no per-query
+        // status) fails all of them
+        const bool per_query = rc == JV_OK || rc == JV_ENOMEM;
+        const int batch_rc = rc;
+        int my_rc = JV_OK;
         // the answers are in this thread's buffers: free the leader slot BEFORE handing them out, so the next batch
         // is on the GPU while this one's owners are being woken (one futex wake per owner)
         lk.lock();
@@ -1116,20 +1376,27 @@ int jv_search(jv_index* index, const float* query, int32_t topK, int32_t rerankK
         passed = true;
         for (size_t i = 0; i < nb; i++) {
             PendingSearch* r = batch[i];
-            if (rc == JV_OK) {
+            const int rrc = per_query ? statusbuf[i] : batch_rc;
+            if (rrc == JV_OK) {
                 if (r->out_nodes) memcpy(r->out_nodes, nbuf.data() + i * topK, sizeof(int32_t) * topK);
                 if (r->out_docs) memcpy(r->out_docs, dbuf.data() + i * topK, sizeof(int32_t) * topK);
                 if (r->out_scores) memcpy(r->out_scores, sbuf.data() + i * topK, sizeof(float) * topK);
                 if (r->out_count) *r->out_count = cbuf[i];
                 if (r->out_stats) memcpy(r->out_stats, stbuf.data() + i * 4, sizeof(int32_t) * 4);
+                if (r->out_flags) *r->out_flags = flagbuf[i];
+            } else if (per_query) {
+                snprintf(r->err, sizeof(r->err), "the query overflowed the HBM scratch; raise option big_cand_cap");
             } else {
                 snprintf(r->err, sizeof(r->err), "%s", g_last_error.c_str());
             }
             if (r != &me) {
-                r->rc = rc;
+                r->rc = rrc;
                 sem_post(&r->sem);  // r's frame may be gone as soon as this returns: r is not touched afterwards
+            } else {
+                my_rc = rrc;
             }
         }
+        rc = my_rc;
     }
     } catch (const std::exception& e) {
         // only the staging-vector resizes can throw, i.e. before any owner has been answered: nobody may be left
@@ -1155,6 +1422,40 @@ int jv_search(jv_index* index, const float* query, int32_t topK, int32_t rerankK
         lk.unlock();
     }
     return finish(rc);
+}
+
+}  // namespace
+
+extern "C" {
+
+int jv_search(jv_index* index, const float* query, int32_t topK, int32_t rerankK, float threshold,
+              float rerankFloor, const uint64_t* accept_doc_words, int64_t accept_num_docs, int32_t* out_nodes,
+              int32_t* out_docs, float* out_scores, int32_t* out_count, int32_t* out_stats) {
+    return search_single(index, query, topK, rerankK, threshold, rerankFloor, accept_doc_words, accept_num_docs, 0, 0, out_nodes,
+                         out_docs, out_scores, out_count, out_stats, nullptr);
+}
+
+int jv_search_ex(jv_index* index, const float* query, const jv_search_params* p, int32_t* out_nodes, int32_t* out_docs,
+                 float* out_scores, int32_t* out_count, int32_t* out_stats, int32_t* out_flags) {
+    if (!p || p->struct_size != sizeof(jv_search_params)) return fail(JV_EINVAL, "jv_search_params is NULL or has the wrong struct_size");
+    if (out_flags) *out_flags = 0;
+    return search_single(index, query, p->topK, p->rerankK, p->threshold, p->rerankFloor, p->accept_doc_words,
+                         p->accept_num_docs, p->visit_limit, p->accept_key, out_nodes, out_docs, out_scores, out_count, out_stats,
+                         out_flags);
+}
+
+int jv_search_batch_ex(jv_index* index, const float* queries, int32_t nq, const jv_search_params* p, int32_t* out_nodes,
+                       int32_t* out_docs, float* out_scores, int32_t* out_count, int32_t* out_stats, int32_t* out_status,
+                       int32_t* out_flags) {
+    if (!p || p->struct_size != sizeof(jv_search_params)) return fail(JV_EINVAL, "jv_search_params is NULL or has the wrong struct_size");
+    if (p->visit_limit < 0) return fail(JV_EINVAL, "visit_limit < 0");
+    HostSearchExtras ex;
+    ex.visit_limit = p->visit_limit;
+    ex.accept_key = p->accept_key;
+    ex.out_status = out_status;
+    ex.out_flags = out_flags;
+    return search_batch_host(index, queries, nq, p->topK, p->rerankK, p->threshold, p->rerankFloor, p->accept_doc_words, nullptr,
+                             p->accept_num_docs, out_nodes, out_docs, out_scores, out_count, out_stats, ex);
 }
 
 int jv_score_ordinals(jv_index* index, const float* query, const int32_t* ordinals, int32_t count, float* out_scores) {
@@ -1212,4 +1513,223 @@ int jv_merge_topk_device(int32_t device, const int32_t* d_docs, const float* d_s
     return JV_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// doc-ID-range sharding inside one process; see include/jvgpu.h
+// ---------------------------------------------------------------------------------------------------------------
 }  // extern "C"
+
+struct jv_shard_group {
+    std::vector<jv_index*> shards;
+    std::mutex mu;  // one sharded batch at a time per group (the buffers below are reused)
+    struct PerShard {
+        hipStream_t stream = nullptr;
+        hipEvent_t done = nullptr;
+        float* d_queries = nullptr;
+        int32_t *d_nodes = nullptr, *d_docs = nullptr, *d_count = nullptr, *d_stats = nullptr, *d_flags = nullptr;
+        float* d_scores = nullptr;
+        int32_t* d_pairs = nullptr;  // [nq][k] (doc, score bits)
+        size_t cap_q = 0, cap_out = 0, cap_nq = 0;
+    };
+    std::vector<PerShard> per;
+    // on shards[0]'s device: gathered (doc, score) pairs [G][nq][k] + merged output + per-shard stats / flags
+    int32_t *g_docs = nullptr, *m_docs = nullptr;   // g_docs holds the pairs
+    float *g_scores = nullptr, *m_scores = nullptr; // (g_scores unused: kept null)
+    int32_t* g_stats = nullptr;  // [G][nq][4]
+    int32_t* g_flags = nullptr;  // [G][nq]
+    size_t cap_g = 0, cap_m = 0, cap_s = 0;
+    hipStream_t merge_stream = nullptr;
+};
+
+namespace {
+template <typename T>
+int regrow(T** p, size_t* cap, size_t need) {
+    if (need <= *cap && *p) return JV_OK;
+    if (*p) HIPCHK(hipFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    HIPCHK(hipMalloc((void**)p, (need ? need : 1) * sizeof(T)));
+    *cap = need;
+    return JV_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int jv_shard_group_create(jv_index* const* shards, int32_t num_shards, jv_shard_group** out) {
+    if (!shards || !out || num_shards <= 0) return fail(JV_EINVAL, "shards/out is NULL or num_shards <= 0");
+    *out = nullptr;
+    for (int g = 0; g < num_shards; g++) {
+        if (!shards[g]) return fail(JV_EINVAL, "shard %d is NULL", g);
+        if (shards[g]->dev.d != shards[0]->dev.d) return fail(JV_EINVAL, "shard %d has dimension %d, shard 0 has %d", g, shards[g]->dev.d, shards[0]->dev.d);
+    }
+    jv_shard_group* grp = new jv_shard_group();
+    grp->shards.assign(shards, shards + num_shards);
+    grp->per.resize((size_t)num_shards);
+    for (int g = 0; g < num_shards; g++) {
+        hipError_t e = hipSetDevice(shards[g]->device);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&grp->per[(size_t)g].stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&grp->per[(size_t)g].done, hipEventDisableTiming);
+        if (e == hipSuccess && g > 0 && shards[g]->device != shards[0]->device) {
+            // peer access both ways where the fabric offers it (xGMI); the gather falls back to staged copies otherwise
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, shards[g]->device, shards[0]->device) == hipSuccess && can) {
+                hipError_t pe = hipDeviceEnablePeerAccess(shards[0]->device, 0);
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+            }
+        }
+        if (e != hipSuccess) {
+            jv_shard_group_destroy(grp);
+            return fail(JV_EDEVICE, "shard group: %s", hipGetErrorString(e));
+        }
+    }
+    hipError_t e = hipSetDevice(shards[0]->device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&grp->merge_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        jv_shard_group_destroy(grp);
+        return fail(JV_EDEVICE, "shard group: %s", hipGetErrorString(e));
+    }
+    *out = grp;
+    return JV_OK;
+}
+
+void jv_shard_group_destroy(jv_shard_group* grp) {
+    if (!grp) return;
+    for (size_t g = 0; g < grp->per.size(); g++) {
+        hipSetDevice(grp->shards[g]->device);
+        jv_shard_group::PerShard& p = grp->per[g];
+        if (p.stream) hipStreamSynchronize(p.stream);
+        hipFree(p.d_queries);
+        hipFree(p.d_nodes);
+        hipFree(p.d_docs);
+        hipFree(p.d_scores);
+        hipFree(p.d_pairs);
+        hipFree(p.d_count);
+        hipFree(p.d_stats);
+        hipFree(p.d_flags);
+        if (p.done) hipEventDestroy(p.done);
+        if (p.stream) hipStreamDestroy(p.stream);
+    }
+    if (!grp->shards.empty()) hipSetDevice(grp->shards[0]->device);
+    hipFree(grp->g_docs);
+    hipFree(grp->g_scores);
+    hipFree(grp->m_docs);
+    hipFree(grp->m_scores);
+    hipFree(grp->g_stats);
+    hipFree(grp->g_flags);
+    if (grp->merge_stream) hipStreamDestroy(grp->merge_stream);
+    delete grp;
+}
+
+int jv_search_sharded_batch(jv_shard_group* grp, const float* queries, int32_t nq, int32_t topK, int32_t rerankK,
+                            float threshold, float rerankFloor, int32_t* out_docs, float* out_scores,
+                            int32_t* out_count, int32_t* out_stats) {
+    if (!grp) return fail(JV_EINVAL, "group is NULL");
+    const int G = (int)grp->shards.size();
+    int rc = check_common(grp->shards[0], queries, nq, topK, rerankK, threshold);
+    if (rc != JV_OK) return rc;
+    if (nq == 0) return JV_OK;
+    if (!out_docs || !out_scores) return fail(JV_EINVAL, "output pointer is NULL");
+    if ((int64_t)G * topK * 8 > 64 * 1024) return fail(JV_EUNSUPPORTED, "shards * topK too large for one merge tile");
+    const size_t outn = (size_t)nq * (size_t)topK;
+    if (topK == 0) {
+        if (out_count) memset(out_count, 0, sizeof(int32_t) * (size_t)nq);
+        if (out_stats) memset(out_stats, 0, sizeof(int32_t) * 4 * (size_t)nq);
+        return JV_OK;
+    }
+    std::lock_guard<std::mutex> lk(grp->mu);
+    const int d = grp->shards[0]->dev.d;
+    const int dev0 = grp->shards[0]->device;
+    HIPCHK(hipSetDevice(dev0));
+    if ((rc = regrow(&grp->g_docs, &grp->cap_g, 2 * outn * (size_t)G)) != JV_OK) return rc;
+    if (!grp->g_stats || grp->cap_s < (size_t)G * (size_t)nq) {
+        if (grp->g_stats) HIPCHK(hipFree(grp->g_stats));
+        grp->g_stats = nullptr;
+        HIPCHK(hipMalloc((void**)&grp->g_stats, (size_t)G * (size_t)nq * 4 * sizeof(int32_t)));
+        if (grp->g_flags) HIPCHK(hipFree(grp->g_flags));
+        grp->g_flags = nullptr;
+        HIPCHK(hipMalloc((void**)&grp->g_flags, (size_t)G * (size_t)nq * sizeof(int32_t)));
+        grp->cap_s = (size_t)G * (size_t)nq;
+    }
+    if (!grp->m_docs || grp->cap_m < outn) {
+        if (grp->m_docs) HIPCHK(hipFree(grp->m_docs));
+        if (grp->m_scores) HIPCHK(hipFree(grp->m_scores));
+        grp->m_docs = nullptr;
+        grp->m_scores = nullptr;
+        HIPCHK(hipMalloc((void**)&grp->m_docs, outn * sizeof(int32_t)));
+        HIPCHK(hipMalloc((void**)&grp->m_scores, outn * sizeof(float)));
+        grp->cap_m = outn;
+    }
+    // 1. every shard searches the whole batch on its own device and stream
+    for (int g = 0; g < G; g++) {
+        jv_index* ix = grp->shards[(size_t)g];
+        jv_shard_group::PerShard& p = grp->per[(size_t)g];
+        HIPCHK(hipSetDevice(ix->device));
+        if ((rc = regrow(&p.d_queries, &p.cap_q, (size_t)nq * d)) != JV_OK) return rc;
+        if (p.cap_out < outn) {
+            hipFree(p.d_nodes);
+            hipFree(p.d_docs);
+            hipFree(p.d_scores);
+            hipFree(p.d_pairs);
+            p.d_nodes = p.d_docs = p.d_pairs = nullptr;
+            p.d_scores = nullptr;
+            p.cap_out = 0;
+            HIPCHK(hipMalloc((void**)&p.d_nodes, outn * 4));
+            HIPCHK(hipMalloc((void**)&p.d_docs, outn * 4));
+            HIPCHK(hipMalloc((void**)&p.d_scores, outn * 4));
+            HIPCHK(hipMalloc((void**)&p.d_pairs, outn * 8));
+            p.cap_out = outn;
+        }
+        if (p.cap_nq < (size_t)nq) {
+            hipFree(p.d_count);
+            hipFree(p.d_stats);
+            hipFree(p.d_flags);
+            p.d_count = p.d_stats = p.d_flags = nullptr;
+            p.cap_nq = 0;
+            HIPCHK(hipMalloc((void**)&p.d_count, (size_t)nq * 4));
+            HIPCHK(hipMalloc((void**)&p.d_stats, (size_t)nq * 16));
+            HIPCHK(hipMalloc((void**)&p.d_flags, (size_t)nq * 4));
+            p.cap_nq = (size_t)nq;
+        }
+        HIPCHK(hipMemcpyAsync(p.d_queries, queries, (size_t)nq * d * sizeof(float), hipMemcpyHostToDevice, p.stream));
+        rc = jv_search_batch_device(ix, p.d_queries, nq, topK, rerankK, threshold, rerankFloor, nullptr, 0, p.d_nodes, p.d_docs,
+                                    p.d_scores, p.d_count, p.d_stats, p.d_flags, (void*)p.stream);
+        if (rc != JV_OK) return rc;
+        // 2. gather: this shard's [nq][k] (doc, score) pairs go to slot g of the [G][nq][k] buffer on device 0 in ONE
+        //    peer copy over xGMI (+ the counters and flags)
+        HIPCHK(jvk_launch_pack_pairs(p.d_docs, p.d_scores, p.d_pairs, (long long)outn, p.stream));
+        HIPCHK(hipMemcpyPeerAsync(grp->g_docs + 2 * (size_t)g * outn, dev0, p.d_pairs, ix->device, outn * 8, p.stream));
+        HIPCHK(hipMemcpyPeerAsync(grp->g_stats + (size_t)g * (size_t)nq * 4, dev0, p.d_stats, ix->device, (size_t)nq * 16, p.stream));
+        HIPCHK(hipMemcpyPeerAsync(grp->g_flags + (size_t)g * (size_t)nq, dev0, p.d_flags, ix->device, (size_t)nq * 4, p.stream));
+        HIPCHK(hipEventRecord(p.done, p.stream));
+    }
+    // 3. merge on device 0 once every shard's lists have arrived
+    HIPCHK(hipSetDevice(dev0));
+    for (int g = 0; g < G; g++) HIPCHK(hipStreamWaitEvent(grp->merge_stream, grp->per[(size_t)g].done, 0));
+    HIPCHK(jvk_launch_merge_topk_strided(grp->g_docs, grp->g_scores, nq, G, topK, grp->m_docs, grp->m_scores, grp->merge_stream));
+    std::vector<int32_t> h_stats((size_t)G * (size_t)nq * 4), h_flags((size_t)G * (size_t)nq);
+    HIPCHK(hipMemcpyAsync(out_docs, grp->m_docs, outn * 4, hipMemcpyDeviceToHost, grp->merge_stream));
+    HIPCHK(hipMemcpyAsync(out_scores, grp->m_scores, outn * 4, hipMemcpyDeviceToHost, grp->merge_stream));
+    HIPCHK(hipMemcpyAsync(h_stats.data(), grp->g_stats, h_stats.size() * 4, hipMemcpyDeviceToHost, grp->merge_stream));
+    HIPCHK(hipMemcpyAsync(h_flags.data(), grp->g_flags, h_flags.size() * 4, hipMemcpyDeviceToHost, grp->merge_stream));
+    HIPCHK(hipStreamSynchronize(grp->merge_stream));
+    int failed = 0;
+    for (int i = 0; i < nq; i++) {
+        int32_t st[4] = {0, 0, 0, 0};
+        for (int g = 0; g < G; g++) {
+            for (int j = 0; j < 4; j++) st[j] += h_stats[((size_t)g * (size_t)nq + (size_t)i) * 4 + (size_t)j];
+            if ((uint32_t)h_flags[(size_t)g * (size_t)nq + (size_t)i] & (JV_FLAG_FAILED | JV_FLAG_OVERFLOW)) failed++;
+        }
+        if (out_stats) memcpy(out_stats + (size_t)i * 4, st, sizeof(st));
+        if (out_count) {
+            int c = 0;
+            while (c < topK && out_docs[(size_t)i * topK + (size_t)c] >= 0) c++;
+            out_count[i] = c;
+        }
+    }
+    if (failed) return fail(JV_ENOMEM, "%d (query, shard) searches overflowed the HBM scratch; raise option big_cand_cap", failed);
+    return JV_OK;
+}
+
+}  // extern "C"
+

@@ -64,6 +64,7 @@ struct JvSearchArgs {
     int64_t* big_cand;       // [blocks][big_cand_cap]
     int32_t big_cand_cap;
     int32_t* work_counter;   // big path: dynamic query dequeue
+    int32_t visit_limit;     // > 0: stop (flag EARLY) once visited + expanded reaches it (Lucene KnnCollector.visitLimit)
     int32_t retry_only;      // filtered PQF kernel: 1 = walk the flag array and redo pool/log overflows only
     int32_t* retry_counter;  // escalation launches: flag-chunk dequeue counter (zeroed per call, one per rung)
     // two-level visited set: pool of per-query spill tables in HBM (taken with spill_counter)
@@ -84,3 +85,4 @@ struct JvSearchArgs {
 #define JV_FLAG_OVERFLOW 0x80000000u /* on-chip scratch overflow: query must be re-run on the big path */
 #define JV_FLAG_FAILED   0x40000000u /* big path overflowed as well */
 #define JV_FLAG_BIG      0x1u
+#define JV_FLAG_EARLY    0x2u /* visit_limit reached: the search stopped, no results (the caller falls back to the exact scan) */

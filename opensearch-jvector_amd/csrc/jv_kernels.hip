@@ -135,6 +135,7 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
         return vs.nspill + JV_WAVE <= spill_limit;
     };
 
+    bool early = false;  // visit_limit reached
     QState st;
     st.ncand = st.nhand = st.nres = 0;
     st.worst = KEY_MAX;
@@ -165,7 +166,7 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
     }
 
     // ---- searchOneLayer for lvl = top .. 0 ----
-    for (int lvl = ix.num_upper; lvl >= (POOL ? 1 : 0) && !st.overflow; lvl--) {
+    for (int lvl = ix.num_upper; lvl >= (POOL ? 1 : 0) && !st.overflow && !early; lvl--) {
         const int rk_cur = lvl > 0 ? 1 : rk;
         const float thr = lvl > 0 ? 0.0f : a.threshold;
         const bool accept_all = lvl > 0 || a.accept == nullptr;
@@ -176,6 +177,10 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
             scan_max(cand, st.ncand, lane, best, bi);
             const float sc = key_score(best);
             if (st.nres >= rk_cur && sc < key_score(st.worst)) break;
+            if (a.visit_limit > 0 && st.visited + st.expanded >= a.visit_limit) {  // Lucene discards this search: stop now
+                early = true;
+                break;
+            }
             // when querying by threshold, also stop when more qualifying results are improbable
             if (thr > 0.0f && tracker_should_stop(trk, thr, lane)) break;
             // pop
@@ -316,7 +321,7 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
         }
     }
 
-    if (POOL && !st.overflow) {
+    if (POOL && !st.overflow && !early) {
         // ---- level 0 on a single sorted pool ----
         // The pool holds every scored node whose score >= the rk-th best score seen so far (so ties at the
         // boundary stay), in NodeQueue order, with an "unexpanded" bit.  jvector pops the best unexpanded
@@ -416,6 +421,10 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
                 }
             }
             if (idx < 0) break;
+            if (a.visit_limit > 0 && st.visited + st.expanded >= a.visit_limit) {
+                early = true;
+                break;
+            }
             lo_un = idx + 1;
             STAMP(0)  // find the best / runner-up unexpanded entries
             const int64_t pk = cur[idx];
@@ -544,7 +553,7 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
         }
         STAMP(5)  // non-fused expansions / loop exit
         STAMP_FLUSH
-        if (!st.overflow) {
+        if (!st.overflow && !early) {
             // approximateResults = the best rk expanded nodes = the first rk pool entries
             st.nres = np < rk ? np : rk;
             for (int i = lane; i < st.nres; i += JV_WAVE) nxt[i] = pool_to_key(cur[i]);
@@ -556,7 +565,7 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
 
     // NodeQueue.rerank bookkeeping (PQ): how many results reach rerankFloor; if none, the single entry to rescore
     int above = 0, only_node = -1;
-    if (PQ && !st.overflow) {
+    if (PQ && !st.overflow && !early) {
         __syncthreads();
         for (int i = lane; i < st.nres; i += JV_WAVE) above += key_score(res[i]) >= a.rerank_floor ? 1 : 0;
 #pragma unroll
@@ -590,9 +599,18 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
     int32_t* o_nodes = a.out_nodes + (size_t)qi * topK;
     int32_t* o_docs = a.out_docs ? a.out_docs + (size_t)qi * topK : nullptr;
     float* o_scores = a.out_scores + (size_t)qi * topK;
-    if (st.overflow) {
+    if (st.overflow || early) {
         if (lane == 0) {
-            a.out_flags[qi] = BIG ? (int32_t)(JV_FLAG_FAILED | JV_FLAG_BIG) : (int32_t)JV_FLAG_OVERFLOW;
+            if (early && !st.overflow) {
+                a.out_flags[qi] = (int32_t)(JV_FLAG_EARLY | (BIG ? JV_FLAG_BIG : 0u));
+                int32_t* s = a.out_stats + (size_t)qi * 4;
+                s[0] = st.visited;
+                s[1] = 0;
+                s[2] = st.expanded;
+                s[3] = st.expanded_base;
+            } else {
+                a.out_flags[qi] = BIG ? (int32_t)(JV_FLAG_FAILED | JV_FLAG_BIG) : (int32_t)JV_FLAG_OVERFLOW;
+            }
             a.out_count[qi] = 0;
         }
         for (int i = lane; i < topK; i += JV_WAVE) {
@@ -783,7 +801,7 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
 
     // ---- entry point ----
     int np = 0, nexp = 0, expanded = 0;
-    bool overflow = false;
+    bool overflow = false, early = false;
     int why = 0;  // bail-out reason, reported in bits 8..11 of the flag word (diagnostics)
     float bscore = 0.0f;  // score of pool[rk-1] once the pool holds rk entries (the boundary)
     // level-1 pivots of the rank search (pool[63], pool[127], ...): wave-uniform, refreshed from the registers
@@ -949,6 +967,10 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
         if (nexp >= log_cap) {
             overflow = true;
             why = 2;
+            break;
+        }
+        if (a.visit_limit > 0 && expanded >= a.visit_limit) {  // (visited is only known after the loop: expansions alone reach it)
+            early = true;
             break;
         }
         if (lane == 0) {
@@ -1127,6 +1149,23 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
     int32_t* o_docs = a.out_docs ? a.out_docs + (size_t)qi * topK : nullptr;
     float* o_scores = a.out_scores + (size_t)qi * topK;
     int visited = 0;
+    if (early && !overflow) {
+        if (lane == 0) {
+            a.out_flags[qi] = (int32_t)JV_FLAG_EARLY;
+            a.out_count[qi] = 0;
+            int32_t* st = a.out_stats + (size_t)qi * 4;
+            st[0] = 0;
+            st[1] = 0;
+            st[2] = expanded;
+            st[3] = expanded;
+        }
+        for (int i = lane; i < topK; i += JV_WAVE) {
+            o_nodes[i] = -1;
+            if (o_docs) o_docs[i] = -1;
+            o_scores[i] = 0.0f;
+        }
+        return;
+    }
     if (!overflow) {
         // ---- jvector's visitedCount: distinct neighbours of the expanded nodes, entry point excluded ----
         uint32_t* vh = (uint32_t*)lut;
@@ -1477,6 +1516,9 @@ __global__ __launch_bounds__(JV_WAVE) void jv_score_ordinals_kernel(const JvInde
 // Merge of per-shard top-k lists (TopDocs.merge; the exchange step after the RCCL all-gather):
 // one wave per query, lists*k candidates -> k best by (score desc, doc asc).
 // ---------------------------------------------------------------------------------------------
+// LISTMAJOR: input = (doc, score) 8-byte pairs laid out [lists][nq][k] (each shard's block as it arrives from its device)
+// instead of separate doc / score arrays [nq][lists*k]
+template <bool LISTMAJOR>
 __global__ __launch_bounds__(JV_WAVE) void jv_merge_topk_kernel(const int32_t* docs, const float* scores, int nq,
                                                                  int lists, int k, int32_t* out_docs,
                                                                  float* out_scores) {
@@ -1487,8 +1529,17 @@ __global__ __launch_bounds__(JV_WAVE) void jv_merge_topk_kernel(const int32_t* d
     if (qi >= nq) return;
     const int total = lists * k;
     for (int i = lane; i < total; i += JV_WAVE) {
-        const int doc = docs[(size_t)qi * total + i];
-        keys[i] = doc >= 0 ? make_key(scores[(size_t)qi * total + i], doc) : KEY_MIN;
+        int doc;
+        float sc;
+        if (LISTMAJOR) {  // `docs` holds (doc, score bits) pairs, `scores` is unused
+            const size_t src = ((size_t)(i / k) * (size_t)nq + (size_t)qi) * (size_t)k + (size_t)(i % k);
+            doc = docs[2 * src];
+            sc = __int_as_float(docs[2 * src + 1]);
+        } else {
+            doc = docs[(size_t)qi * total + i];
+            sc = scores[(size_t)qi * total + i];
+        }
+        keys[i] = doc >= 0 ? make_key(sc, doc) : KEY_MIN;
     }
     __syncthreads();
     int n = total;
@@ -1647,6 +1698,31 @@ extern "C" hipError_t jvk_launch_merge_topk(const int32_t* d_docs, const float* 
                                             hipStream_t stream) {
     if (nq <= 0) return hipSuccess;
     int lds = lists * k * 8;
-    jv_merge_topk_kernel<<<nq, JV_WAVE, lds, stream>>>(d_docs, d_scores, nq, lists, k, d_out_docs, d_out_scores);
+    jv_merge_topk_kernel<false><<<nq, JV_WAVE, lds, stream>>>(d_docs, d_scores, nq, lists, k, d_out_docs, d_out_scores);
+    return hipGetLastError();
+}
+
+// (doc, score) -> one 8-byte pair per result, so that a shard's top-k lists travel in ONE peer copy
+__global__ void jv_pack_pairs_kernel(const int32_t* docs, const float* scores, int32_t* pairs, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        pairs[2 * i] = docs[i];
+        pairs[2 * i + 1] = __float_as_int(scores[i]);
+    }
+}
+extern "C" hipError_t jvk_launch_pack_pairs(const int32_t* d_docs, const float* d_scores, int32_t* d_pairs, long long n,
+                                            hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    jv_pack_pairs_kernel<<<blocks, 256, 0, stream>>>(d_docs, d_scores, d_pairs, n);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t jvk_launch_merge_topk_strided(const int32_t* d_docs, const float* d_scores, int nq, int lists,
+                                                    int k, int32_t* d_out_docs, float* d_out_scores,
+                                                    hipStream_t stream) {
+    if (nq <= 0) return hipSuccess;
+    int lds = lists * k * 8;
+    jv_merge_topk_kernel<true><<<nq, JV_WAVE, lds, stream>>>(d_docs, d_scores, nq, lists, k, d_out_docs, d_out_scores);
     return hipGetLastError();
 }

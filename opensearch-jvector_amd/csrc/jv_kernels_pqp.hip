@@ -271,6 +271,10 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
             why = 2;
             break;
         }
+        if (a.visit_limit > 0 && expanded >= a.visit_limit) {  // Lucene discards this search (visited + expanded >= visitLimit)
+            why = 15;
+            break;
+        }
         // mark the entry expanded; log the node
         if (lane == b1) ((int*)pool)[2 * idx] = pk_lo & ~1;
         if (lane == 0) explog[nexp] = c;
@@ -581,8 +585,15 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
     }
     if (why != 0) {
         if (lane == 0) {
-            a.out_flags[qi] = (int32_t)(JV_FLAG_OVERFLOW | ((uint32_t)why << 8));
+            a.out_flags[qi] = why == 15 ? (int32_t)JV_FLAG_EARLY : (int32_t)(JV_FLAG_OVERFLOW | ((uint32_t)why << 8));
             a.out_count[qi] = 0;
+            if (why == 15) {
+                int32_t* st = a.out_stats + (size_t)qi * 4;
+                st[0] = 0;
+                st[1] = 0;
+                st[2] = expanded;
+                st[3] = expanded;
+            }
         }
         for (int i = lane; i < topK; i += JV_WAVE) {
             o_nodes[i] = -1;

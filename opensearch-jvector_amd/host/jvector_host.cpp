@@ -229,9 +229,21 @@ void JVectorReader::search(const std::string& field, const float* target, KnnCol
     std::vector<float> scores((size_t)std::max(topK, 1));
     int32_t count = 0, stats[JV_NUM_STATS] = {0, 0, 0, 0};
     // :165-173 — graphSearcher.search(ssp, k, k * overQueryFactor, threshold, rerankFloor, compatibleBits)
-    throwForStatus(jv_search(fieldEntry->index, target, topK, rerankK, jvectorKnnCollector->getThreshold(),
-                             jvectorKnnCollector->getRerankFloor(), b ? b->getBits() : nullptr, b ? b->length() : 0,
-                             nodes.data(), docs.data(), scores.data(), &count, stats));
+    // (the engine also receives Lucene's visit limit: a search that reaches it is going to be discarded by
+    //  AbstractKnnVectorQuery for the exact scan, so the engine stops it instead of finishing it — include/jvgpu.h)
+    jv_search_params sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.struct_size = sizeof(sp);
+    sp.topK = topK;
+    sp.rerankK = rerankK;
+    sp.threshold = jvectorKnnCollector->getThreshold();
+    sp.rerankFloor = jvectorKnnCollector->getRerankFloor();
+    sp.accept_doc_words = b ? b->getBits() : nullptr;
+    sp.accept_num_docs = b ? b->length() : 0;
+    const int64_t limit = jvectorKnnCollector->visitLimit();
+    sp.visit_limit = (limit > 0 && limit < INT32_MAX) ? limit : 0;
+    int32_t qflags = 0;
+    throwForStatus(jv_search_ex(fieldEntry->index, target, &sp, nodes.data(), docs.data(), scores.data(), &count, stats, &qflags));
     // :175-177
     for (int i = 0; i < count; i++) jvectorKnnCollector->collect(docs[(size_t)i], scores[(size_t)i]);
     const auto searchTime = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - graphSearchStart).count();

@@ -1,0 +1,187 @@
+"""ABI v2 additions through the C ABI on a real GPU: per-index options, visit-limit early termination, per-query
+status, the device-side filter cache, the in-process shard group, scratch accounting."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, b):
+    return (np.array_equal(a.nodes, b.nodes) and np.array_equal(a.scores.view(np.uint32), b.scores.view(np.uint32)) and
+            np.array_equal(a.stats, b.stats) and np.array_equal(a.count, b.count))
+
+
+@pytest.fixture(scope="module")
+def small(pkg):
+    dg, bl = pkg.datagen, pkg.builder
+    base = dg.splitmix_uniform(91, 6000, 64)
+    q = dg.splitmix_uniform(92, 64, 64)
+    return base, q, bl.build_index_cpu(base, 0, R=32, L=80, pq_M=16), bl.build_index_cpu(base, 0, R=16, L=60)
+
+
+def test_options_are_per_index(pkg, pyoracle, small):
+    """jv_index_set_option changes one handle only; jv_set_option only seeds indexes created afterwards."""
+    b = pkg.binding
+    base, q, ixq, ix = small
+    want = pyoracle.Oracle(b, ixq).search_batch(q, 10, 50)
+    a = b.GpuIndex(ixq, flags=b.DESC_FUSED_ADC)
+    c = b.GpuIndex(ixq, flags=b.DESC_FUSED_ADC)
+    a.set_option("force_big_path", 1)             # handle `a` takes the HBM-scratch rung, `c` is untouched
+    ra, fa = a.search_batch_ex(q, 10, 50)[0], a.search_batch_ex(q, 10, 50)[2]
+    rc_, fc = c.search_batch_ex(q, 10, 50)[0], c.search_batch_ex(q, 10, 50)[2]
+    assert _same(ra, want) and _same(rc_, want)
+    assert (fa & b.QFLAG_RETRIED_BIG).all() and not (fc & b.QFLAG_RETRIED_BIG).any()
+    try:
+        b.set_option("force_big_path", 1)         # default for NEW handles
+        d = b.GpuIndex(ixq, flags=b.DESC_FUSED_ADC)
+    finally:
+        b.set_option("force_big_path", 0)
+    assert (d.search_batch_ex(q, 10, 50)[2] & b.QFLAG_RETRIED_BIG).all()
+    assert not (c.search_batch_ex(q, 10, 50)[2] & b.QFLAG_RETRIED_BIG).any()
+    with pytest.raises(b.JvError):
+        a.set_option("no_such_option", 1)
+    for g in (a, c, d):
+        g.close()
+
+
+def test_visit_limit_stops_searches_lucene_would_discard(pkg, pyoracle, small):
+    """visit_limit = Lucene's KnnCollector.visitLimit(): a search whose visited + expanded stays below it is unchanged;
+    one that reaches it stops early with JV_QFLAG_EARLY_TERMINATED and counters that already reach the limit (so the
+    collector's earlyTerminated() is true and AbstractKnnVectorQuery runs the exact scan), never with a wrong answer."""
+    b = pkg.binding
+    base, q, ixq, ix = small
+    n = base.shape[0]
+    rng = np.random.default_rng(3)
+    words = b.accept_words(np.nonzero(rng.random(n) < 0.3)[0], n)
+    for data, flags in ((ix, 0), (ixq, 0), (ixq, b.DESC_FUSED_ADC)):
+        gpu = b.GpuIndex(data, flags=flags)
+        orc = pyoracle.Oracle(b, data)
+        for acc in (None, words):
+            kw = dict(accept=acc, accept_num_docs=(n if acc is not None else 0))
+            want = orc.search_batch(q, 10, 60, **kw)
+            work = want.stats[:, 0] + want.stats[:, 2]
+            limit = int(np.median(work))
+            res, status, fl, rc = gpu.search_batch_ex(q, 10, 60, visit_limit=limit, **kw)
+            assert rc == b.JV_OK and (status == 0).all()
+            early = (fl & b.QFLAG_EARLY_TERMINATED) != 0
+            assert early.any() and (~early).any()
+            # untouched searches: identical to the oracle; they really were below the limit
+            for i in np.nonzero(~early)[0]:
+                assert np.array_equal(res.nodes[i], want.nodes[i]) and np.array_equal(res.stats[i], want.stats[i])
+                assert np.array_equal(res.scores[i].view(np.uint32), want.scores[i].view(np.uint32))
+            # stopped searches: no results, and the full search would have reached the limit as well
+            assert (res.count[early] == 0).all() and (res.nodes[early] == -1).all()
+            assert (work[early] >= limit).all()
+            # the generic kernels know visited while searching and stop exactly at the limit; the fused-PQ kernels only
+            # count expansions while searching (a later, but still safe, stop)
+            if flags == 0:
+                assert (work[~early] < limit).all()
+                assert (res.stats[early, 0] + res.stats[early, 2] >= limit).all()
+            one, f1 = gpu.search_ex(q[0], 10, 60, visit_limit=limit, **kw)
+            assert bool(f1 & b.QFLAG_EARLY_TERMINATED) == bool(early[0])
+        gpu.close()
+
+
+def test_per_query_status_one_bad_query_does_not_fail_its_batch(pkg, pyoracle, small):
+    """A query that outgrows even the HBM scratch is reported alone (out_status / the caller's own return code in a
+    combined jv_search batch); every other row of the launch stays valid."""
+    import threading
+    b = pkg.binding
+    base, q, ixq, ix = small
+    n = base.shape[0]
+    gpu = b.GpuIndex(ix)
+    orc = pyoracle.Oracle(b, ix)
+    gpu.set_option("force_big_path", 1)
+    gpu.set_option("big_cand_cap", 8)       # the HBM candidate queue holds 4 * rerankK entries at least: far too few for some
+    want = orc.search_batch(q, 10, 40)
+    res, status, fl, rc = gpu.search_batch_ex(q, 10, 40)
+    bad = status != 0
+    assert rc == b.JV_ENOMEM and bad.any() and (~bad).any(), (rc, int(bad.sum()))
+    assert (status[bad] == b.JV_ENOMEM).all()
+    for i in np.nonzero(~bad)[0]:
+        assert np.array_equal(res.nodes[i], want.nodes[i]) and np.array_equal(res.stats[i], want.stats[i])
+    with pytest.raises(b.JvError):
+        gpu.search_batch(q, 10, 40)          # the plain call still reports the failure
+    # combined single-query calls: only the callers of the bad queries see an error
+    outcome = {}
+
+    def worker(i):
+        try:
+            r = gpu.search(q[i], 10, 40)
+            outcome[i] = np.array_equal(r.nodes[0], want.nodes[i])
+        except b.JvError as e:
+            outcome[i] = e.code
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(len(q))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for i in range(len(q)):
+        assert outcome[i] == (b.JV_ENOMEM if bad[i] else True), (i, outcome[i], bool(bad[i]))
+    gpu.close()
+
+
+def test_filter_cache_serves_repeated_filters_from_hbm(pkg, pyoracle, small):
+    b = pkg.binding
+    base, q, ixq, ix = small
+    n = base.shape[0]
+    rng = np.random.default_rng(8)
+    gpu = b.GpuIndex(ixq, flags=b.DESC_FUSED_ADC)
+    orc = pyoracle.Oracle(b, ixq)
+    filters = [b.accept_words(np.nonzero(rng.random(n) < f)[0], n) for f in (0.5, 0.2, 0.7)]
+    wants = [orc.search_batch(q, 10, 50, accept=w, accept_num_docs=n) for w in filters]
+    for rounds in range(3):
+        for w, want in zip(filters, wants):
+            assert _same(gpu.search_batch(q, 10, 50, accept=w, accept_num_docs=n), want)
+            assert _same(gpu.search(q[3], 10, 50, accept=w.copy(), accept_num_docs=n), b.SearchResult(
+                want.nodes[3:4], want.docs[3:4], want.scores[3:4], want.count[3:4], want.stats[3:4]))  # same CONTENTS, other buffer
+    info = gpu.info()
+    assert info.filter_cache_misses == 3 and info.filter_cache_hits == 3 * 3 * 2 - 3, (info.filter_cache_hits, info.filter_cache_misses)
+    # a changed bit is a different filter
+    w2 = filters[0].copy()
+    w2[5] ^= np.uint64(1 << 7)
+    assert _same(gpu.search_batch(q, 10, 50, accept=w2, accept_num_docs=n), orc.search_batch(q, 10, 50, accept=w2, accept_num_docs=n))
+    assert gpu.info().filter_cache_misses == 4
+    gpu.set_option("filter_cache", 0)        # off: every call stages its words
+    assert _same(gpu.search_batch(q, 10, 50, accept=filters[1], accept_num_docs=n), wants[1])
+    assert gpu.info().filter_cache_misses == 4 and gpu.info().filter_cache_hits == 15
+    gpu.close()
+
+
+def test_shard_group_in_one_process_equals_oracle_merge(pkg, pyoracle):
+    """jv_shard_group: doc-range shards (here 3, all on GPU 0) searched concurrently, (doc, score) pairs gathered with one
+    peer copy per shard, merged on the first shard's device — equal to the oracle's merge of the oracle's shard answers."""
+    b, bl, dg = pkg.binding, pkg.builder, pkg.datagen
+    sh = __import__("importlib").import_module("opensearch_jvector_amd.sharding")
+    n_total, d, k, rk, G = 9000, 48, 10, 40, 3
+    q = dg.splitmix_uniform(43, 80, d)
+    shards, gd, gs, stats = [], [], [], 0
+    for g in range(G):
+        lo, hi = sh.shard_range(n_total, G, g)
+        base = dg.splitmix_uniform(42, hi - lo, d, row_offset=lo)
+        ix = bl.build_index_cpu(base, 0, R=16, L=60, pq_M=16, ord2doc=np.arange(lo, hi, dtype=np.int32), max_doc=n_total)
+        shards.append(b.GpuIndex(ix, flags=b.DESC_FUSED_ADC))
+        w = pyoracle.Oracle(b, ix).search_batch(q, k, rk)
+        gd.append(w.docs)
+        gs.append(w.scores)
+        stats = stats + w.stats
+    grp = b.ShardGroup(shards)
+    for _ in range(2):
+        got = grp.search_batch(q, k, rk)
+        od, os_ = pyoracle.merge_topk(b, np.concatenate(gd, axis=1), np.concatenate(gs, axis=1), k)
+        assert np.array_equal(got.docs, od) and np.array_equal(got.scores.view(np.uint32), os_.view(np.uint32))
+        assert np.array_equal(got.stats, stats) and (got.count == k).all()
+    grp.close()
+    [s.close() for s in shards]
+
+
+def test_scratch_is_shared_per_device_and_accounted(pkg, small):
+    b = pkg.binding
+    base, q, ixq, ix = small
+    handles = [b.GpuIndex(ixq, flags=b.DESC_FUSED_ADC) for _ in range(6)]
+    for h in handles:
+        h.search_batch(q, 10, 50)
+    sb = [h.info().scratch_bytes for h in handles]
+    # every handle reports its own contexts + the ONE shared HBM-scratch of the device: far below 0.7 GB per context
+    assert max(sb) < 300 * 2**20 and min(sb) > 0, sb
+    [h.close() for h in handles]

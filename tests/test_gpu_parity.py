@@ -117,33 +117,33 @@ def test_big_path_parity_forced_and_on_overflow(pkg, pyoracle, small_sets):
     gpu = b.GpuIndex(ix)
     want = pyoracle.Oracle(b, ix).search_batch(q, 10, 100)
     try:
-        b.set_option("force_big_path", 1)
+        gpu.set_option("force_big_path", 1)
         _assert_same(gpu.search_batch(q, 10, 100), want, "forced big path")
-        b.set_option("force_big_path", 0)
-        b.set_option("force_general_path", 1)    # literal two-queue form in LDS instead of the single pool
+        gpu.set_option("force_big_path", 0)
+        gpu.set_option("force_general_path", 1)    # literal two-queue form in LDS instead of the single pool
         _assert_same(gpu.search_batch(q, 10, 100), want, "general (two-queue) LDS path")
-        b.set_option("force_general_path", 0)
-        b.set_option("lds_visited_slots", 512)   # far too small: every query freezes its LDS table and spills to HBM
+        gpu.set_option("force_general_path", 0)
+        gpu.set_option("lds_visited_slots", 512)   # far too small: every query freezes its LDS table and spills to HBM
         _assert_same(gpu.search_batch(q, 10, 100), want, "two-level visited set (LDS + HBM spill)")
-        b.set_option("spill_slots", 512)         # spill tables too small as well -> flagged -> HBM-scratch path
+        gpu.set_option("spill_slots", 512)         # spill tables too small as well -> flagged -> HBM-scratch path
         _assert_same(gpu.search_batch(q, 10, 100), want, "spill overflow -> big path")
-        b.set_option("spill_slots", 8192)
-        b.set_option("spill_tables", 0)          # no spill pool at all -> escalation / big path
+        gpu.set_option("spill_slots", 8192)
+        gpu.set_option("spill_tables", 0)          # no spill pool at all -> escalation / big path
         _assert_same(gpu.search_batch(q, 10, 100), want, "visited overflow without spill -> big path")
-        b.set_option("spill_tables", 2048)
-        b.set_option("force_general_path", 1)
+        gpu.set_option("spill_tables", 2048)
+        gpu.set_option("force_general_path", 1)
         _assert_same(gpu.search_batch(q, 10, 100), want, "two-queue form with spill")
-        b.set_option("force_general_path", 0)
-        b.set_option("lds_visited_slots", 0)
-        b.set_option("lds_candidates", 100)      # candidate array too small
+        gpu.set_option("force_general_path", 0)
+        gpu.set_option("lds_visited_slots", 0)
+        gpu.set_option("lds_candidates", 100)      # candidate array too small
         _assert_same(gpu.search_batch(q, 10, 100), want, "candidate overflow -> big path")
     finally:
-        b.set_option("force_big_path", 0)
-        b.set_option("force_general_path", 0)
-        b.set_option("lds_visited_slots", 0)
-        b.set_option("lds_candidates", 0)
-        b.set_option("spill_slots", 8192)
-        b.set_option("spill_tables", 2048)
+        gpu.set_option("force_big_path", 0)
+        gpu.set_option("force_general_path", 0)
+        gpu.set_option("lds_visited_slots", 0)
+        gpu.set_option("lds_candidates", 0)
+        gpu.set_option("spill_slots", 8192)
+        gpu.set_option("spill_tables", 2048)
     gpu.close()
 
 
@@ -208,11 +208,11 @@ def test_threshold_queries_parity(pkg, pyoracle, small_sets):
         stopped_early += int((want.stats[:, 2] < 4000).sum())
     assert stopped_early > 0, "the early-stop tracker never fired: test inputs do not exercise it"
     try:
-        b.set_option("force_big_path", 1)
+        gpu.set_option("force_big_path", 1)
         want = orc.search_batch(q[:8], 10, 50, threshold=0.2)
         _assert_same(gpu.search_batch(q[:8], 10, 50, threshold=0.2), want, "threshold on the HBM-scratch path")
     finally:
-        b.set_option("force_big_path", 0)
+        gpu.set_option("force_big_path", 0)
     gpu.close()
 
 
@@ -231,10 +231,10 @@ def test_fused_adc_layout_parity(pkg, pyoracle, small_sets, sim, M, R):
         want = orc.search_batch(q, k, rk)
         _assert_same(gpu.search_batch(q, k, rk), want, f"fused sim={sim} M={M} R={R} k={k} rk={rk}")
         try:
-            b.set_option("no_pqf", 1)   # generic pool kernel on the fused layout (in-loop visited set)
+            gpu.set_option("no_pqf", 1)   # generic pool kernel on the fused layout (in-loop visited set)
             _assert_same(gpu.search_batch(q, k, rk), want, f"fused/no_pqf sim={sim} M={M} R={R} k={k} rk={rk}")
         finally:
-            b.set_option("no_pqf", 0)
+            gpu.set_option("no_pqf", 0)
     gpu.close()
 
 
@@ -380,7 +380,7 @@ def test_combined_single_query_calls_match_oracle(pkg, pyoracle):
             for k, rk, th, fl, acc in params]
     for flags, combine in ((b.DESC_FUSED_ADC, 1), (0, 1), (b.DESC_FUSED_ADC, 0)):
         gpu = b.GpuIndex(ix, flags=flags)
-        b.set_option("combine", combine)
+        gpu.set_option("combine", combine)
         errors = []
 
         def worker(tid):
@@ -404,7 +404,7 @@ def test_combined_single_query_calls_match_oracle(pkg, pyoracle):
         threads = [threading.Thread(target=worker, args=(t,)) for t in range(24)]
         [t.start() for t in threads]
         [t.join() for t in threads]
-        b.set_option("combine", 1)
+        gpu.set_option("combine", 1)
         gpu.close()
         assert not errors, (flags, combine, errors[:5])
 

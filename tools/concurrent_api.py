@@ -27,7 +27,7 @@ want = ix.search_batch(qh, 10, rk).nodes
 for opt in os.environ.get("JV_OPTS", "").split(","):
     if "=" in opt:
         k_, v_ = opt.split("=")
-        b.set_option(k_, int(v_))
+        ix.set_option(k_, int(v_))
 if os.environ.get("BIG_FIRST"):  # diagnostic: a large device-API launch first, like bench.py does
     Bb = int(os.environ["BIG_FIRST"])
     qb = bench.gen_rows_block(torch, Bb, d, 45, 0, zc, Bl, Bg, 0.35, 0.1, 0.005, False, dev)

@@ -24,10 +24,10 @@ ix = b.GpuIndex(desc=desc, keepalive=keep, flags=b.DESC_BORROW)
 o = [torch.empty((B, 10), dtype=torch.int32, device=dev), torch.empty((B, 10), dtype=torch.int32, device=dev),
      torch.empty((B, 10), dtype=torch.float32, device=dev), torch.empty((B,), dtype=torch.int32, device=dev),
      torch.zeros((B, 4), dtype=torch.int32, device=dev), torch.empty((B,), dtype=torch.int32, device=dev)]
-b.set_option("pqf_only", 1)
+ix.set_option("pqf_only", 1)
 ix.search_batch_device(q.data_ptr(), B, 10, rk, *[t.data_ptr() for t in o])
 torch.cuda.synchronize()
-b.set_option("pqf_only", 0)
+ix.set_option("pqf_only", 0)
 fl = o[5].cpu().numpy().astype(np.uint32)
 ov = (fl & 0x80000000) != 0
 why = (fl >> 8) & 0xF
@@ -37,7 +37,7 @@ print("expanded: mean %.1f p99 %.0f max %d; visited: mean %.1f p99 %.0f max %d" 
 
 # cost of the ladder launches when nothing is flagged: PQF only vs full ladder, HIP events
 def timed(only):
-    b.set_option("pqf_only", only)
+    ix.set_option("pqf_only", only)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ts = []
     for it in range(6):
@@ -46,9 +46,9 @@ def timed(only):
         e1.record()
         torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1))
-    b.set_option("pqf_only", 0)
+    ix.set_option("pqf_only", 0)
     return float(np.median(ts[1:]))
 print("PQF only: %.3f ms; PQF + ladder: %.3f ms" % (timed(1), timed(0)))
 for slots in (4096, 16384):
-    b.set_option("no_escalation", 0)
+    ix.set_option("no_escalation", 0)
 print("done")

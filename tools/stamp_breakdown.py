@@ -29,12 +29,12 @@ for fused in (1,):
          torch.empty((B, 4), dtype=torch.int32, device=dev), torch.empty((B,), dtype=torch.int32, device=dev)]
     for it in range(2):
         dbg.zero_()
-        b.set_option("dbg_ptr", dbg.data_ptr())
+        ix.set_option("dbg_ptr", dbg.data_ptr())
         torch.cuda.synchronize(); t = time.time()
         ix.search_batch_device(q.data_ptr(), B, 10, rk, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(),
                                o[4].data_ptr(), o[5].data_ptr())
         torch.cuda.synchronize(); dt = time.time() - t
-    b.set_option("dbg_ptr", 0)
+    ix.set_option("dbg_ptr", 0)
     v = dbg.cpu().numpy().astype(np.float64)
     st = o[4].cpu().numpy().astype(np.float64).mean(0)
     # register-pool kernel (jv_kernels_pqr.hip) stamp slots; JV_OPT no_pqr=1 shows the round-1 LDS-pool kernel's slots instead
