@@ -198,10 +198,9 @@ namespace {
 struct DeviceScratch {
     std::mutex mu;
     hipEvent_t last_use = nullptr;
-    uint32_t* big_visited = nullptr;
-    int64_t* big_cand = nullptr;
-    int blocks = 0, cand_cap = 0;
-    size_t words = 0;
+    uint32_t* big_visited = nullptr;  // every index carves [its blocks][its ceil(n / 32) words] out of this arena
+    int64_t* big_cand = nullptr;      // ... and [its blocks][its candidate slots] out of this one
+    size_t vis_bytes = 0, cand_bytes = 0;
     std::atomic<int64_t> bytes{0};
 };
 DeviceScratch g_scratch[64];
@@ -387,7 +386,7 @@ Geometry plan_geometry(const jv_index* ix, int rk, bool pool_ok, int force_slots
 }
 
 // size / grow the device's shared HBM-scratch (caller holds sc.mu)
-int ensure_big(jv_index* ix, DeviceScratch& sc, int rk) {
+int ensure_big(jv_index* ix, DeviceScratch& sc, int rk, int* cap_out, int* blocks_out) {
     int cap = (int)OPT(ix, OPT_BIG_CAND_CAP);
     int res_cap = ((rk + 1) & ~1);
     if (cap < 4 * rk) cap = 4 * rk;
@@ -406,24 +405,27 @@ int ensure_big(jv_index* ix, DeviceScratch& sc, int rk) {
         const size_t budget = (size_t)std::max<int64_t>(16, OPT(ix, OPT_BIG_BUDGET_MB)) << 20;
         blocks = (int)std::min<size_t>(1024, std::max<size_t>(16, budget / per));
     }
-    if (sc.big_visited && sc.blocks >= blocks && sc.words >= words && sc.cand_cap >= cap) return JV_OK;
+    *cap_out = cap;        // this index's queue capacity and resident blocks (the shared arenas may be larger)
+    *blocks_out = blocks;
+    const size_t need_vis = (size_t)blocks * words * sizeof(uint32_t), need_cand = (size_t)blocks * (size_t)cap * sizeof(int64_t);
+    if (sc.big_visited && sc.big_cand && sc.vis_bytes >= need_vis && sc.cand_bytes >= need_cand) return JV_OK;
     // grow: wait for the launches still using the old buffers
     HIPCHK(hipEventSynchronize(sc.last_use));
-    blocks = std::max(blocks, sc.blocks);
-    words = std::max(words, sc.words);
-    cap = std::max(cap, sc.cand_cap);
-    if (sc.big_visited) HIPCHK(hipFree(sc.big_visited));
-    if (sc.big_cand) HIPCHK(hipFree(sc.big_cand));
-    sc.big_visited = nullptr;
-    sc.big_cand = nullptr;
-    sc.blocks = 0;
-    sc.bytes = 0;
-    HIPCHK(hipMalloc((void**)&sc.big_visited, (size_t)blocks * words * sizeof(uint32_t)));
-    HIPCHK(hipMalloc((void**)&sc.big_cand, (size_t)blocks * (size_t)cap * sizeof(int64_t)));
-    sc.blocks = blocks;
-    sc.words = words;
-    sc.cand_cap = cap;
-    sc.bytes = (int64_t)((size_t)blocks * words * sizeof(uint32_t) + (size_t)blocks * (size_t)cap * sizeof(int64_t));
+    if (sc.vis_bytes < need_vis || !sc.big_visited) {
+        if (sc.big_visited) HIPCHK(hipFree(sc.big_visited));
+        sc.big_visited = nullptr;
+        sc.vis_bytes = 0;
+        HIPCHK(hipMalloc((void**)&sc.big_visited, need_vis));
+        sc.vis_bytes = need_vis;
+    }
+    if (sc.cand_bytes < need_cand || !sc.big_cand) {
+        if (sc.big_cand) HIPCHK(hipFree(sc.big_cand));
+        sc.big_cand = nullptr;
+        sc.cand_bytes = 0;
+        HIPCHK(hipMalloc((void**)&sc.big_cand, need_cand));
+        sc.cand_bytes = need_cand;
+    }
+    sc.bytes = (int64_t)(sc.vis_bytes + sc.cand_bytes);
     return JV_OK;
 }
 
@@ -646,13 +648,15 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
         // last rung: the device's shared HBM scratch; its users are ordered through the scratch event
         DeviceScratch& sc = g_scratch[ix->device & 63];
         std::lock_guard<std::mutex> lk(sc.mu);
-        rc = ensure_big(ix, sc, rk);
+        int my_cap = 0, my_blocks = 0;
+        rc = ensure_big(ix, sc, rk, &my_cap, &my_blocks);
         if (rc != JV_OK) return rc;
-        a.big_visited = sc.big_visited;
+        a.big_visited = sc.big_visited;  // (block b uses [b * words, ...) of the bitsets with words = ceil(n / 32) of THIS index)
         a.big_cand = sc.big_cand;
-        a.big_cand_cap = sc.cand_cap;
+        a.big_cand_cap = my_cap;
+        a.res_cap = (rk + 1) & ~1;  // the rung runs the two-queue form: rerankK results, the rest of my_cap are candidates
         HIPCHK(hipStreamWaitEvent(stream, sc.last_use, 0));
-        HIPCHK(jvk_launch_search_big(&ix->dev, &a, pq ? 1 : 0, sc.blocks, g.lds_big, force_big ? 1 : 0, stream));
+        HIPCHK(jvk_launch_search_big(&ix->dev, &a, pq ? 1 : 0, my_blocks, g.lds_big, force_big ? 1 : 0, stream));
         HIPCHK(hipEventRecord(sc.last_use, stream));
     }
     return JV_OK;

@@ -62,25 +62,25 @@ def test_visit_limit_stops_searches_lucene_would_discard(pkg, pyoracle, small):
             kw = dict(accept=acc, accept_num_docs=(n if acc is not None else 0))
             want = orc.search_batch(q, 10, 60, **kw)
             work = want.stats[:, 0] + want.stats[:, 2]
-            limit = int(np.median(work))
-            res, status, fl, rc = gpu.search_batch_ex(q, 10, 60, visit_limit=limit, **kw)
-            assert rc == b.JV_OK and (status == 0).all()
-            early = (fl & b.QFLAG_EARLY_TERMINATED) != 0
-            assert early.any() and (~early).any()
-            # untouched searches: identical to the oracle; they really were below the limit
-            for i in np.nonzero(~early)[0]:
-                assert np.array_equal(res.nodes[i], want.nodes[i]) and np.array_equal(res.stats[i], want.stats[i])
-                assert np.array_equal(res.scores[i].view(np.uint32), want.scores[i].view(np.uint32))
-            # stopped searches: no results, and the full search would have reached the limit as well
-            assert (res.count[early] == 0).all() and (res.nodes[early] == -1).all()
-            assert (work[early] >= limit).all()
-            # the generic kernels know visited while searching and stop exactly at the limit; the fused-PQ kernels only
-            # count expansions while searching (a later, but still safe, stop)
-            if flags == 0:
-                assert (work[~early] < limit).all()
+            # the generic kernels know `visited` while searching and stop exactly at the limit; the fused-PQ kernels only
+            # count expansions while searching (a later, but still safe, stop): give them a limit expansions alone reach
+            for limit, must_fire in ((int(np.median(work)), flags == 0 and data is ix), (int(np.median(want.stats[:, 2])), True)):
+                res, status, fl, rc = gpu.search_batch_ex(q, 10, 60, visit_limit=limit, **kw)
+                assert rc == b.JV_OK and (status == 0).all()
+                early = (fl & b.QFLAG_EARLY_TERMINATED) != 0
+                if must_fire:
+                    assert early.any(), (limit, int(early.sum()))
+                # untouched searches: identical to the oracle
+                for i in np.nonzero(~early)[0]:
+                    assert np.array_equal(res.nodes[i], want.nodes[i]) and np.array_equal(res.stats[i], want.stats[i])
+                    assert np.array_equal(res.scores[i].view(np.uint32), want.scores[i].view(np.uint32))
+                # stopped searches: no results, the full search would have reached the limit as well, and the reported
+                # counters already reach it (so Lucene's collector is earlyTerminated())
+                assert (res.count[early] == 0).all() and (res.nodes[early] == -1).all()
+                assert (work[early] >= limit).all()
                 assert (res.stats[early, 0] + res.stats[early, 2] >= limit).all()
-            one, f1 = gpu.search_ex(q[0], 10, 60, visit_limit=limit, **kw)
-            assert bool(f1 & b.QFLAG_EARLY_TERMINATED) == bool(early[0])
+                one, f1 = gpu.search_ex(q[0], 10, 60, visit_limit=limit, **kw)
+                assert bool(f1 & b.QFLAG_EARLY_TERMINATED) == bool(early[0])
         gpu.close()
 
 
@@ -94,22 +94,26 @@ def test_per_query_status_one_bad_query_does_not_fail_its_batch(pkg, pyoracle, s
     gpu = b.GpuIndex(ix)
     orc = pyoracle.Oracle(b, ix)
     gpu.set_option("force_big_path", 1)
-    gpu.set_option("big_cand_cap", 8)       # the HBM candidate queue holds 4 * rerankK entries at least: far too few for some
-    want = orc.search_batch(q, 10, 40)
-    res, status, fl, rc = gpu.search_batch_ex(q, 10, 40)
-    bad = status != 0
-    assert rc == b.JV_ENOMEM and bad.any() and (~bad).any(), (rc, int(bad.sum()))
+    rk = 40
+    for cap in range(200, 1600, 20):   # find a queue size that part of the batch overflows and part does not
+        gpu.set_option("big_cand_cap", cap)
+        res, status, fl, rc = gpu.search_batch_ex(q, 10, rk)
+        bad = status != 0
+        if bad.any() and (~bad).any():
+            break
+    want = orc.search_batch(q, 10, rk)
+    assert rc == b.JV_ENOMEM and bad.any() and (~bad).any(), (rc, rk, int(bad.sum()))
     assert (status[bad] == b.JV_ENOMEM).all()
     for i in np.nonzero(~bad)[0]:
         assert np.array_equal(res.nodes[i], want.nodes[i]) and np.array_equal(res.stats[i], want.stats[i])
     with pytest.raises(b.JvError):
-        gpu.search_batch(q, 10, 40)          # the plain call still reports the failure
+        gpu.search_batch(q, 10, rk)          # the plain call still reports the failure
     # combined single-query calls: only the callers of the bad queries see an error
     outcome = {}
 
     def worker(i):
         try:
-            r = gpu.search(q[i], 10, 40)
+            r = gpu.search(q[i], 10, rk)
             outcome[i] = np.array_equal(r.nodes[0], want.nodes[i])
         except b.JvError as e:
             outcome[i] = e.code
