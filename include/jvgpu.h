@@ -98,6 +98,17 @@ typedef struct jv_index_desc {
     const int32_t* ord2doc;       /* [n] or NULL => identity                               */
     int32_t max_doc;              /* doc-id space size (for accept bitsets)                */
     int32_t reserved;
+    /* NVQ-inline vectors (quantType 2, J/JVectorReader.java:357-358; decode = J/JVectorIndexQuantization.java:306-361):
+     * when nvq_M > 0 every "exact" score (the rerank, the exact provider of an NVQ-only field, jv_score_ordinals) is
+     * taken against the DEQUANTISED vector
+     *     x[i] = logitNQT(fma(byte[i], logisticScale_s, logisticBias_s), 1 / scaledGrowthRate_s, scaledMidpoint_s) + globalMean[i]
+     * of the node's 8-bit NVQ record instead of a full-precision row, and `vectors` may be NULL (4x fewer rerank bytes). */
+    int32_t nvq_M;                /* NVQ subvectors per vector (0 => no NVQ)                                  */
+    int32_t reserved2;
+    const int32_t* nvq_sub_sizes; /* [nvq_M] or NULL => jvector's even split (d/M, first d%M get +1)          */
+    const float* nvq_params;      /* [n][nvq_M][4]: growthRate, midpoint, minValue, maxValue per subvector    */
+    const uint8_t* nvq_bytes;     /* [n][d] quantised components                                              */
+    const float* nvq_global_mean; /* [d] subtracted before encoding, added back after decoding                */
 } jv_index_desc;
 
 typedef struct jv_index jv_index; /* opaque handle */

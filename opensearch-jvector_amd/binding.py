@@ -51,6 +51,8 @@ class JvIndexDesc(C.Structure):
         ("pq_M", C.c_int32), ("pq_K", C.c_int32), ("pq_sub_sizes", C.c_void_p), ("pq_codebooks", C.c_void_p),
         ("pq_centroid", C.c_void_p), ("pq_codes", C.c_void_p),
         ("ord2doc", C.c_void_p), ("max_doc", C.c_int32), ("reserved", C.c_int32),
+        ("nvq_M", C.c_int32), ("reserved2", C.c_int32), ("nvq_sub_sizes", C.c_void_p), ("nvq_params", C.c_void_p),
+        ("nvq_bytes", C.c_void_p), ("nvq_global_mean", C.c_void_p),
     ]
 
 
@@ -88,6 +90,11 @@ class IndexData:
     pq_K: int = 0
     ord2doc: Optional[np.ndarray] = None        # [n] int32
     max_doc: int = 0
+    # NVQ-inline vectors (quantType 2): exact scores are taken against the dequantised record
+    nvq_M: int = 0
+    nvq_params: Optional[np.ndarray] = None     # [n][nvq_M][4] float32: growthRate, midpoint, minValue, maxValue
+    nvq_bytes: Optional[np.ndarray] = None      # [n][d] uint8
+    nvq_global_mean: Optional[np.ndarray] = None  # [d] float32
 
     @property
     def n(self) -> int:
@@ -150,6 +157,11 @@ def make_desc(ix: IndexData, device: int = 0, flags: int = 0):
     desc.pq_codes = _ptr(own(ix.pq_codes, np.uint8))
     desc.ord2doc = _ptr(own(ix.ord2doc, np.int32))
     desc.max_doc = ix.max_doc if ix.max_doc else ix.n
+    desc.nvq_M = ix.nvq_M
+    if ix.nvq_M:
+        desc.nvq_params = _ptr(own(ix.nvq_params, np.float32))
+        desc.nvq_bytes = _ptr(own(ix.nvq_bytes, np.uint8))
+        desc.nvq_global_mean = _ptr(own(ix.nvq_global_mean, np.float32))
     return desc, keep
 
 

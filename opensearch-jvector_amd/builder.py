@@ -110,3 +110,44 @@ def build_index_cpu(vectors: np.ndarray, similarity: int = SIM_EUCLIDEAN, R: int
         cb, cen, codes, K = pq_train_encode_cpu(vectors, pq_M, similarity, threads=threads)
         ix.pq_codebooks, ix.pq_centroid, ix.pq_codes, ix.pq_M, ix.pq_K = cb, cen, codes, pq_M, K
     return ix
+
+
+def nvq_encode(base: np.ndarray, M: int = 2, growth: float = 1.0, midpoint: float = 0.0):
+    """8-bit NVQ records for test / benchmark inputs (write side; NOT jvector's trained encoder: the parameter fit of
+    NVQuantization lives in the library).  Per vector: subtract the global mean, then per subvector keep (growthRate,
+    midpoint, minValue, maxValue) and quantise every component through the same logistic map the reference's decoder
+    inverts (J/JVectorIndexQuantization.java:319-361).  Returns (params [n][M][4] f32, bytes [n][d] u8, mean [d] f32)."""
+    x = np.asarray(base, dtype=np.float32)
+    n, d = x.shape
+    mean = x.mean(axis=0).astype(np.float32)
+    c = (x - mean).astype(np.float64)
+    sizes = [d // M + (1 if m < d % M else 0) for m in range(M)]
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(int)
+    params = np.zeros((n, M, 4), dtype=np.float32)
+    codes = np.zeros((n, d), dtype=np.uint8)
+    for m in range(M):
+        seg = c[:, offs[m]:offs[m + 1]]
+        mn = seg.min(axis=1)
+        mx = seg.max(axis=1)
+        mx = np.where(mx - mn < 1e-6, mn + 1e-6, mx)
+        delta = mx - mn
+        sg = growth / delta
+        sm = midpoint * delta
+
+        def logistic(v):
+            # logisticNQT (J/JVectorIndexQuantization.java:344-350): 2^t with a piecewise-linear mantissa, so that the
+            # reference's logitNQT decoder inverts it up to the 8-bit step
+            t = (v * sg[:, None] - sg[:, None] * sm[:, None]).astype(np.float32)
+            p = np.floor(t + np.float32(1.0)).astype(np.int32)
+            f = ((t - p.astype(np.float32)) * np.float32(0.5) + np.float32(1.0)).astype(np.float32)
+            z = (f.view(np.int32) + (p << 23)).view(np.float32).astype(np.float64)
+            return z / (z + 1.0)
+        lo = logistic(mn[:, None])
+        hi = logistic(mx[:, None])
+        q = np.rint((logistic(seg) - lo) / np.maximum(hi - lo, 1e-12) * 255.0)
+        codes[:, offs[m]:offs[m + 1]] = np.clip(q, 0, 255).astype(np.uint8)
+        params[:, m, 0] = growth
+        params[:, m, 1] = midpoint
+        params[:, m, 2] = mn.astype(np.float32)
+        params[:, m, 3] = mx.astype(np.float32)
+    return params, codes, mean

@@ -718,7 +718,10 @@ int jv_index_create(const jv_index_desc* desc, jv_index** out) {
     if (n < 0 || d <= 0 || R <= 0) return fail(JV_EINVAL, "bad shape n=%d d=%d R=%d", n, d, R);
     // VectorSimilarityMapper.ordToDistFunc throws IllegalArgumentException on unknown ordinals (J/JVectorReader.java:407-413)
     if (desc->similarity < 0 || desc->similarity > 2) return fail(JV_EINVAL, "invalid similarity ordinal %d", desc->similarity);
-    if (n > 0 && (!desc->vectors || !desc->adj)) return fail(JV_EINVAL, "vectors/adj is NULL");
+    const int NM = desc->nvq_M;
+    if (NM < 0 || NM > JV_NVQ_MAX_M || NM > d) return fail(JV_EUNSUPPORTED, "nvq_M %d not in [0,%d]", NM, JV_NVQ_MAX_M);
+    if (NM > 0 && (!desc->nvq_global_mean || (n > 0 && (!desc->nvq_params || !desc->nvq_bytes)))) return fail(JV_EINVAL, "nvq arrays are NULL");
+    if (n > 0 && ((!desc->vectors && NM == 0) || !desc->adj)) return fail(JV_EINVAL, "vectors/adj is NULL");
     if (desc->entry_node >= n) return fail(JV_EINVAL, "entry_node %d out of range", desc->entry_node);
     if (desc->num_upper_layers < 0 || desc->num_upper_layers > JV_MAX_UPPER_LAYERS)
         return fail(JV_EUNSUPPORTED, "num_upper_layers %d not in [0,%d]", desc->num_upper_layers, JV_MAX_UPPER_LAYERS);
@@ -773,7 +776,9 @@ int jv_index_create(const jv_index_desc* desc, jv_index** out) {
     } while (0)
     {
         if (n > 0) {
-            if (borrow && D.stride == d) {
+            if (!desc->vectors) {
+                D.vectors = nullptr;  // NVQ-only field: every exact score is taken against the dequantised record
+            } else if (borrow && D.stride == d) {
                 D.vectors = desc->vectors;
             } else {
                 float* v = nullptr;
@@ -896,6 +901,48 @@ int jv_index_create(const jv_index_desc* desc, jv_index** out) {
                     }
                     D.pq_codes = codes;
                 }
+            }
+        }
+        if (NM > 0) {
+            D.nvq_M = NM;
+            D.nvq_stride = (d + 3) & ~3;
+            std::vector<int32_t> noff((size_t)NM + 1, 0);
+            for (int m2 = 0; m2 < NM; m2++) {
+                const int sz = desc->nvq_sub_sizes ? desc->nvq_sub_sizes[m2] : d / NM + (m2 < d % NM ? 1 : 0);
+                if (sz <= 0) {
+                    rc = fail(JV_EINVAL, "nvq_sub_sizes[%d] = %d", m2, sz);
+                    goto error;
+                }
+                noff[(size_t)m2 + 1] = noff[(size_t)m2] + sz;
+            }
+            if (noff[(size_t)NM] != d) {
+                rc = fail(JV_EINVAL, "nvq subvector sizes sum to %d, expected d=%d", noff[(size_t)NM], d);
+                goto error;
+            }
+            int32_t* dno = nullptr;
+            TRY(dev_alloc(ix, &dno, (size_t)NM + 1));
+            TRYHIP(hipMemcpy(dno, noff.data(), ((size_t)NM + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+            D.nvq_sub_off = dno;
+            std::vector<float> mean((size_t)D.nch * 64, 0.0f);
+            memcpy(mean.data(), desc->nvq_global_mean, (size_t)d * sizeof(float));
+            float* dmean = nullptr;
+            TRY(dev_alloc(ix, &dmean, mean.size()));
+            TRYHIP(hipMemcpy(dmean, mean.data(), mean.size() * sizeof(float), hipMemcpyHostToDevice));
+            D.nvq_mean = dmean;
+            if (n > 0) {
+                float* dpr = nullptr;
+                TRY(dev_alloc(ix, &dpr, (size_t)n * NM * 4));
+                TRYHIP(hipMemcpy(dpr, desc->nvq_params, (size_t)n * NM * 4 * sizeof(float), kind));
+                D.nvq_params = dpr;
+                uint8_t* db = nullptr;
+                TRY(dev_alloc(ix, &db, (size_t)n * D.nvq_stride));
+                if (D.nvq_stride == d) {
+                    TRYHIP(hipMemcpy(db, desc->nvq_bytes, (size_t)n * d, kind));
+                } else {
+                    TRYHIP(hipMemset(db, 0, (size_t)n * D.nvq_stride));
+                    TRYHIP(hipMemcpy2D(db, (size_t)D.nvq_stride, desc->nvq_bytes, (size_t)d, (size_t)d, (size_t)n, kind));
+                }
+                D.nvq_bytes = db;
             }
         }
         if (M > 0 && n > 0 && (desc->flags & JV_DESC_FUSED_ADC)) {

@@ -265,6 +265,104 @@ __device__ __forceinline__ void score_rows_fixed(const JvIndexDev& ix, const flo
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// NVQ-inline vectors: the same canonical accumulation over the DEQUANTISED record (nvqDequantize,
+// J/JVectorIndexQuantization.java:319-361; identical arithmetic to oracle/jv_oracle.c jvo_nvq_dequantize).
+// A 16-lane group scores one row: lane t owns elements 64 j + 4 t .. + 3 (one dword of bytes per chunk).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int java_round_f(float x) {  // Math.round(float): closest int, ties towards +infinity
+    const float r = floorf(x);
+    return (int)r + ((x - r) >= 0.5f ? 1 : 0);
+}
+__device__ __forceinline__ float nvq_logistic(float value, float alpha, float x0) {
+    float temp = fmaf(value, alpha, -alpha * x0);
+    const int p = java_round_f(temp + 0.5f);
+    const float f = fmaf(temp - (float)p, 0.5f, 1.0f);
+    temp = __int_as_float((int)((uint32_t)__float_as_int(f) + ((uint32_t)p << 23)));
+    return temp / (temp + 1.0f);
+}
+__device__ __forceinline__ float nvq_logit(float scaled, float inverse_alpha, float x0) {
+    const float z = scaled / (1.0f - scaled);
+    const int temp = __float_as_int(z);
+    const int e = temp & 0x7f800000;
+    const float p = (float)((e >> 23) - 128);
+    const float m = __int_as_float((temp & 0x007fffff) + 0x3f800000);
+    return (m + p) * inverse_alpha + x0;
+}
+template <int SIM>
+__device__ __forceinline__ void score_rows_nvq_t(const JvIndexDev& ix, const float* q_lds, const int32_t* todo, int m,
+                                                 float* todo_score, float qnorm2, float scale, int lane) {
+    const int g = lane >> 4, t = lane & 15;
+    const int nch = ix.nch, NM = ix.nvq_M;
+    for (int base = 0; base < m; base += 4) {
+        const int r = base + g;
+        const bool val = r < m;
+        const int node = todo[val ? r : 0];
+        // per-subvector decode constants of this row
+        float sc_[JV_NVQ_MAX_M], bias_[JV_NVQ_MAX_M], inv_[JV_NVQ_MAX_M], x0_[JV_NVQ_MAX_M];
+#pragma unroll
+        for (int s = 0; s < JV_NVQ_MAX_M; s++) {
+            sc_[s] = bias_[s] = inv_[s] = x0_[s] = 0.0f;
+            if (s < NM) {
+                const float* pr = ix.nvq_params + ((size_t)node * NM + s) * 4;
+                const float growth = pr[0], midpoint = pr[1], minv = pr[2], maxv = pr[3];
+                const float delta = maxv - minv;
+                const float sg = growth / delta;
+                const float sm = midpoint * delta;
+                bias_[s] = nvq_logistic(minv, sg, sm);
+                sc_[s] = (nvq_logistic(maxv, sg, sm) - bias_[s]) / 255.0f;
+                inv_[s] = 1.0f / sg;
+                x0_[s] = sm;
+            }
+        }
+        float acc[4] = {0.f, 0.f, 0.f, 0.f}, nrm[4] = {0.f, 0.f, 0.f, 0.f};
+        const uint8_t* rowp = ix.nvq_bytes + (size_t)node * ix.nvq_stride;
+        for (int j = 0; j < nch; j++) {
+            const int i0 = j * 64 + 4 * t;
+            if (i0 < ix.stride) {
+                const uint32_t w = *(const uint32_t*)(rowp + i0);
+                const f32x4 qv = *(const f32x4*)(q_lds + i0);
+                const f32x4 mean = *(const f32x4*)(ix.nvq_mean + i0);
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int i = i0 + e;
+                    float v = 0.0f;
+                    if (i < ix.d) {
+                        int s = 0;
+#pragma unroll
+                        for (int s2 = 1; s2 < JV_NVQ_MAX_M; s2++) s += (s2 < NM && i >= ix.nvq_sub_off[s2]) ? 1 : 0;
+                        float scs = sc_[0], bs = bias_[0], ivs = inv_[0], x0s = x0_[0];
+#pragma unroll
+                        for (int s2 = 1; s2 < JV_NVQ_MAX_M; s2++)
+                            if (s == s2) scs = sc_[s2], bs = bias_[s2], ivs = inv_[s2], x0s = x0_[s2];
+                        const float b = (float)((w >> (8 * e)) & 0xFFu);
+                        v = nvq_logit(fmaf(b, scs, bs), ivs, x0s) + mean[e];
+                    }
+                    if (SIM == 0) {
+                        const float df = qv[e] - v;
+                        acc[e] = fmaf(df, df, acc[e]);
+                    } else {
+                        acc[e] = fmaf(qv[e], v, acc[e]);
+                        if (SIM == 2) nrm[e] = fmaf(v, v, nrm[e]);
+                    }
+                }
+            }
+        }
+        float s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        s = row16_tree_sum(s);
+        float score;
+        if (SIM == 2) {
+            float nv = (nrm[0] + nrm[1]) + (nrm[2] + nrm[3]);
+            nv = row16_tree_sum(nv);
+            score = map_score(2, s / sqrtf(qnorm2 * nv));
+        } else {
+            score = map_score(SIM, s);
+        }
+        if (scale != 1.0f) score = score * scale;
+        if (t == 0 && val) todo_score[r] = score;
+    }
+}
+
 // NCHT = number of 64-float chunks per row known at compile time (kernel template parameter; 0 = any d)
 template <int NCHT>
 struct RowsInFlight { static constexpr int U = NCHT <= 6 ? 4 : (NCHT <= 12 ? 2 : 1); };
@@ -272,6 +370,12 @@ struct RowsInFlight { static constexpr int U = NCHT <= 6 ? 4 : (NCHT <= 12 ? 2 :
 template <int NCHT, int UMUL = 1>
 __device__ __forceinline__ void score_rows(const JvIndexDev& ix, const float* q_lds, const int32_t* todo, int m,
                                            float* todo_score, float qnorm2, float scale, int lane) {
+    if (ix.nvq_M > 0) {  // NVQ-inline field: exact scores against the dequantised records
+        if (ix.sim == 0) score_rows_nvq_t<0>(ix, q_lds, todo, m, todo_score, qnorm2, scale, lane);
+        else if (ix.sim == 1) score_rows_nvq_t<1>(ix, q_lds, todo, m, todo_score, qnorm2, scale, lane);
+        else score_rows_nvq_t<2>(ix, q_lds, todo, m, todo_score, qnorm2, scale, lane);
+        return;
+    }
     if (NCHT == 0) {
         if (ix.sim == 0) score_rows_t<0>(ix, q_lds, todo, m, todo_score, qnorm2, scale, lane);
         else if (ix.sim == 1) score_rows_t<1>(ix, q_lds, todo, m, todo_score, qnorm2, scale, lane);

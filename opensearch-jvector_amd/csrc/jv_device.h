@@ -38,7 +38,15 @@ struct JvIndexDev {
     const uint8_t* pq_codes;    // [n][M]
     const float* pq_norm_lut;   // [M][256] |centroid|^2 (cosine) or nullptr
     const uint8_t* pq_fused;    // fused layout: [n][R][M] neighbours' codes next to the adjacency order, or nullptr
+    // NVQ-inline vectors (exact scores against the dequantised record; `vectors` may be nullptr then)
+    int32_t nvq_M;
+    int32_t nvq_stride;         // bytes per row = roundup(d, 4)
+    const int32_t* nvq_sub_off; // [nvq_M + 1]
+    const float* nvq_params;    // [n][nvq_M][4]: growthRate, midpoint, minValue, maxValue
+    const uint8_t* nvq_bytes;   // [n][nvq_stride], zero padded
+    const float* nvq_mean;      // [nch * 64] global mean, zero padded
 };
+#define JV_NVQ_MAX_M 8
 
 struct JvSearchArgs {
     const float* queries;  // [nq][d]

@@ -102,6 +102,75 @@ static inline float map_score(int sim, float raw) {
 
 static inline float cosine_from(float dot, float na, float nb) { return dot / sqrtf(na * nb); }
 
+/* ------------------------------------------------------------------------------------------ */
+/* NVQ-inline vectors: dequantisation (J/JVectorIndexQuantization.java:319-361, restated)        */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Java Math.round(float): closest int, ties towards positive infinity */
+static inline int java_round(float x) {
+    float r = floorf(x);
+    return (int)r + ((x - r) >= 0.5f ? 1 : 0);
+}
+/* logisticNQT (:344-350) */
+static inline float nvq_logistic(float value, float alpha, float x0) {
+    float temp = fmaf(value, alpha, -alpha * x0);
+    int p = java_round(temp + 0.5f);
+    float f = fmaf(temp - (float)p, 0.5f, 1.0f);
+    int32_t m;
+    memcpy(&m, &f, 4);
+    m = (int32_t)((uint32_t)m + ((uint32_t)p << 23));
+    memcpy(&temp, &m, 4);
+    return temp / (temp + 1.0f);
+}
+/* logitNQT (:353-360) */
+static inline float nvq_logit(float scaled, float inverse_alpha, float x0) {
+    float z = scaled / (1.0f - scaled);
+    int32_t temp;
+    memcpy(&temp, &z, 4);
+    int32_t e = temp & 0x7f800000;
+    float p = (float)((e >> 23) - 128);
+    int32_t mb = (temp & 0x007fffff) + 0x3f800000;
+    float m;
+    memcpy(&m, &mb, 4);
+    return (m + p) * inverse_alpha + x0;
+}
+/* nvqDequantize (:319-341) of node's record into out[d] */
+void jvo_nvq_dequantize(const jv_index_desc* ix, int node, float* out) {
+    int d = ix->d, M = ix->nvq_M, off = 0;
+    const uint8_t* bytes = ix->nvq_bytes + (size_t)node * d;
+    for (int s = 0; s < M; s++) {
+        int size = ix->nvq_sub_sizes ? ix->nvq_sub_sizes[s] : d / M + (s < d % M ? 1 : 0);
+        const float* pr = ix->nvq_params + ((size_t)node * M + s) * 4;
+        float growth = pr[0], midpoint = pr[1], minv = pr[2], maxv = pr[3];
+        float delta = maxv - minv;
+        float scaled_growth = growth / delta;
+        float scaled_mid = midpoint * delta;
+        float bias = nvq_logistic(minv, scaled_growth, scaled_mid);
+        float scale = (nvq_logistic(maxv, scaled_growth, scaled_mid) - bias) / 255.0f;
+        float inv = 1.0f / scaled_growth;
+        for (int i = 0; i < size; i++) {
+            float sv = fmaf((float)bytes[off + i], scale, bias);
+            out[off + i] = nvq_logit(sv, inv, scaled_mid);
+        }
+        off += size;
+    }
+    for (int i = 0; i < d; i++) out[i] = out[i] + ix->nvq_global_mean[i];
+}
+
+static _Thread_local float* tls_nvq_row;
+static _Thread_local int tls_nvq_cap;
+/* the row every "exact" score is taken against: the full-precision vector, or the dequantised NVQ record */
+static const float* exact_row(const jv_index_desc* ix, int node) {
+    if (ix->nvq_M <= 0) return ix->vectors + (size_t)node * ix->d;
+    if (tls_nvq_cap < ix->d) {
+        free(tls_nvq_row);
+        tls_nvq_row = (float*)malloc(sizeof(float) * (size_t)ix->d);
+        tls_nvq_cap = ix->d;
+    }
+    jvo_nvq_dequantize(ix, node, tls_nvq_row);
+    return tls_nvq_row;
+}
+
 static float exact_unscaled(int sim, const float* q, const float* v, int d, float qnorm2) {
     if (sim == JV_SIM_EUCLIDEAN) return map_score(sim, jvo_raw_l2(q, v, d));
     if (sim == JV_SIM_DOT_PRODUCT) return map_score(sim, jvo_raw_dot(q, v, d));
@@ -368,14 +437,14 @@ typedef struct {
 static inline float score_fn(searcher* s, int node) {
     const jv_index_desc* ix = s->ix;
     if (s->lut) return jvo_pq_score(ix, s->lut, s->norm_lut, s->qnorm2, node);
-    float v = exact_unscaled(ix->similarity, s->q, ix->vectors + (size_t)node * ix->d, ix->d, s->qnorm2);
+    float v = exact_unscaled(ix->similarity, s->q, exact_row(ix, node), ix->d, s->qnorm2);
     /* wrapExactScoreFunction: x2 for Lucene MIP, exact-provider path only (J/JVectorReader.java:220-239,359-364) */
     return ix->score_scale != 1.0f ? v * ix->score_scale : v;
 }
 /* view.rerankerFor(q, sim): NOT wrapped (J/JVectorReader.java:355) */
 static inline float rerank_fn(searcher* s, int node) {
     const jv_index_desc* ix = s->ix;
-    return exact_unscaled(ix->similarity, s->q, ix->vectors + (size_t)node * ix->d, ix->d, s->qnorm2);
+    return exact_unscaled(ix->similarity, s->q, exact_row(ix, node), ix->d, s->qnorm2);
 }
 
 /* J/JVectorReader.java:157-163 */
@@ -692,7 +761,7 @@ void jvo_score_ordinals(const jv_index_desc* ix, const float* query, const int32
             out_scores[i] = 0.0f;
             continue;
         }
-        float s = exact_unscaled(ix->similarity, query, ix->vectors + (size_t)o * ix->d, ix->d, qn);
+        float s = exact_unscaled(ix->similarity, query, exact_row(ix, o), ix->d, qn);
         out_scores[i] = ix->score_scale != 1.0f ? s * ix->score_scale : s;
     }
 }
@@ -714,7 +783,7 @@ void jvo_brute_force(const jv_index_desc* ix, const float* queries, int32_t nq, 
                 int doc = ix->ord2doc ? ix->ord2doc[o] : o;
                 if (doc < 0 || !((accept_doc_words[doc >> 6] >> (doc & 63)) & 1)) continue;
             }
-            float s = exact_unscaled(ix->similarity, q, ix->vectors + (size_t)o * ix->d, ix->d, qn);
+            float s = exact_unscaled(ix->similarity, q, exact_row(ix, o), ix->d, qn);
             if (ix->score_scale != 1.0f) s = s * ix->score_scale;
             lh_push_bounded(&h, jvo_encode_key(o, s), k);
         }

@@ -43,6 +43,9 @@ void jvo_pq_build_norm_lut(const jv_index_desc* ix, float* norm_lut);
 float jvo_pq_raw(const float* lut, const uint8_t* code, int M);
 float jvo_pq_score(const jv_index_desc* ix, const float* lut, const float* norm_lut, float qnorm2, int node);
 
+/* --- NVQ-inline vectors: nvqDequantize restated (J/JVectorIndexQuantization.java:319-361); out has d floats --- */
+void jvo_nvq_dequantize(const jv_index_desc* ix, int node, float* out);
+
 /* --- the search (GraphSearcher.search; call site J/JVectorReader.java:165-173) ---
  * Same contract as jv_search in include/jvgpu.h. Returns JV_OK / JV_EINVAL. */
 int jvo_search(const jv_index_desc* ix, const float* query, int32_t topK, int32_t rerankK,

@@ -48,6 +48,8 @@ def load(desc_type):
         lib.jvo_float_to_sortable_int.restype = i32
         lib.jvo_pq_build_lut.argtypes = [P, vp, vp]
         lib.jvo_pq_build_lut.restype = None
+        lib.jvo_nvq_dequantize.argtypes = [P, i32, vp]
+        lib.jvo_nvq_dequantize.restype = None
         _lib = lib
     return _lib
 
@@ -93,6 +95,11 @@ class Oracle:
         o = np.ascontiguousarray(ordinals, dtype=np.int32)
         out = np.zeros(o.shape[0], dtype=np.float32)
         self.lib.jvo_score_ordinals(C.byref(self.desc), q.ctypes.data, o.ctypes.data, o.shape[0], out.ctypes.data)
+        return out
+
+    def nvq_dequantize(self, node):
+        out = np.zeros(self.d, dtype=np.float32)
+        self.lib.jvo_nvq_dequantize(C.byref(self.desc), int(node), out.ctypes.data)
         return out
 
     def brute_force(self, queries, k, accept=None, threads=0):

@@ -24,9 +24,10 @@ def test_library_exports_every_declared_symbol(pkg):
 
 def test_desc_struct_layout_matches_header(pkg):
     # 64-bit layout of jv_index_desc: 10 x 4 B + pad, pointers 8-aligned
-    assert ctypes.sizeof(pkg.binding.JvIndexDesc) == 120
+    assert ctypes.sizeof(pkg.binding.JvIndexDesc) == 160
     assert pkg.binding.JvIndexDesc.vectors.offset == 48
     assert pkg.binding.JvIndexDesc.ord2doc.offset == 104
+    assert pkg.binding.JvIndexDesc.nvq_M.offset == 120 and pkg.binding.JvIndexDesc.nvq_global_mean.offset == 152
 
 
 @pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="GPU present")
