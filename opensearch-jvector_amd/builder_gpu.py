@@ -43,6 +43,9 @@ def _prune_lib():
         vp = C.c_void_p
         lib.jvb_robust_prune_device.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp, vp]
         lib.jvb_robust_prune_device.restype = C.c_int
+        lib.jvb_pq_encode_device.argtypes = [vp, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int,
+                                             C.c_int, vp]
+        lib.jvb_pq_encode_device.restype = C.c_int
         _PRUNE_LIB = lib
     return _PRUNE_LIB
 
@@ -274,6 +277,28 @@ def _add_backlinks(torch, base, adj, deg, u, sel, R, Rcap, alpha, sim):
         deg[o] = nsel2
 
 
+def pq_encode_gpu(torch, base, M, K, codebooks_t, centroid_t):
+    """PQ codes of every row of `base` on the GPU (csrc/jv_build_kernels.hip jvb_pq_encode_kernel): nearest centroid per
+    subspace under the canonical fmaf-chain distance, ties -> lowest index; bit-identical to jvb_pq_encode_cpu.
+    codebooks_t: flat float32 tensor (concat over m of [K][ds_m]); centroid_t: [d] tensor or None.  Returns uint8 [n][M]."""
+    n, d = base.shape
+    dev = base.device
+    sizes = [d // M + (1 if m < d % M else 0) for m in range(M)]
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    cb_off = np.concatenate([[0], np.cumsum([K * s_ for s_ in sizes])[:-1]]).astype(np.int64)
+    t_off = torch.from_numpy(offs).to(dev)
+    t_cb = torch.from_numpy(cb_off).to(dev)
+    codes = torch.empty((n, M), dtype=torch.uint8, device=dev)
+    cbt = codebooks_t.to(dev, torch.float32).contiguous()
+    cen = None if centroid_t is None else centroid_t.to(dev, torch.float32).contiguous()
+    rc = _prune_lib().jvb_pq_encode_device(base.data_ptr(), n, d, base.stride(0), M, K, t_off.data_ptr(), cbt.data_ptr(),
+                                           t_cb.data_ptr(), (cen.data_ptr() if cen is not None else None), codes.data_ptr(), M,
+                                           int(max(sizes)), torch.cuda.current_stream(dev).cuda_stream)
+    if rc != 0:
+        raise RuntimeError(f"jvb_pq_encode_device failed: {rc}")
+    return codes
+
+
 def pq_train_encode_gpu(torch, base, M, sim, K=256, iters=8, max_train=128000, seed=1):
     """ProductQuantization.compute analogue: K = min(256, n) clusters per subspace, global centring iff
     EUCLIDEAN (J/JVectorIndexQuantization.java:122-131).  Returns dict(codebooks (np), centroid (np|None),
@@ -305,21 +330,15 @@ def pq_train_encode_gpu(torch, base, M, sim, K=256, iters=8, max_train=128000, s
         for _ in range(iters):
             dist = (xm * xm).sum(1, keepdim=True) - 2 * xm @ cb.T + (cb * cb).sum(1)[None, :]
             asg = dist.argmin(1)
-            sums = torch.zeros_like(cb).index_add_(0, asg, xm)
-            cnt = torch.zeros((K,), device=dev).index_add_(0, asg, torch.ones((nt,), device=dev))
+            # cluster sums through a one-hot GEMM (no float atomics: two builds of the same data give the same codebooks)
+            onehot = torch.zeros((K, nt), device=dev, dtype=torch.float32)
+            onehot[asg, torch.arange(nt, device=dev)] = 1.0
+            sums = onehot @ xm
+            cnt = torch.bincount(asg, minlength=K).to(torch.float32)
             nz = cnt > 0
             cb[nz] = sums[nz] / cnt[nz, None]
         books.append(cb)
-    codes = torch.empty((n, M), dtype=torch.uint8, device=dev)
-    ch = 1 << 18
-    for s in range(0, n, ch):
-        xb = base[s:s + ch]
-        if center:
-            xb = xb - centroid
-        for m in range(M):
-            xm = xb[:, offs[m]:offs[m + 1]]
-            cb = books[m]
-            dist = (xm * xm).sum(1, keepdim=True) - 2 * xm @ cb.T + (cb * cb).sum(1)[None, :]
-            codes[s:s + ch, m] = dist.argmin(1).to(torch.uint8)
+    codebooks_t = torch.cat([b_.reshape(-1) for b_ in books]).contiguous()
+    codes = pq_encode_gpu(torch, base, M, K, codebooks_t, centroid)
     codebooks = np.concatenate([b.cpu().numpy().reshape(-1) for b in books]).astype(np.float32)
     return dict(codebooks=codebooks, centroid=(centroid.cpu().numpy() if center else None), codes=codes, K=K)

@@ -484,7 +484,15 @@ extern "C" int jvb_pq_encode_cpu(const float* vectors, int32_t n, int32_t d, int
             float bd = std::numeric_limits<float>::max();
             int bc = 0;
             for (int c = 0; c < K; c++) {
-                float dd = l2f(&tmp[offs[m]], cb + (size_t)c * sizes[m], sizes[m]);
+                // the canonical PQ distance: the sequential fmaf chain over the subspace's dimensions that the search
+                // kernels use for a look-up table entry (so encode(x) == argmin of x's own LUT row), ties -> lowest c
+                const float* xs = &tmp[offs[m]];
+                const float* cv = cb + (size_t)c * sizes[m];
+                float dd = 0.0f;
+                for (int j = 0; j < sizes[m]; j++) {
+                    const float df = xs[j] - cv[j];
+                    dd = std::fmaf(df, df, dd);
+                }
                 if (dd < bd) {
                     bd = dd;
                     bc = c;

@@ -75,3 +75,65 @@ extern "C" int jvb_robust_prune_device(const float* scc, const float* sc, const 
     jvb_robust_prune_kernel<<<S, WAVE, lds, (hipStream_t)stream>>>(scc, sc, cd, valid, S, Lc, R, alpha, sel, nsel);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// PQ encoding (J/JVectorIndexQuantization.java:114-140, merge re-encode J/JVectorWriter.java:1117-1124):
+// code[i][m] = argmin_c sum_j (x'[i][off_m + j] - codebook[m][c][j])^2 with x' = x - globalCentroid, the sum being
+// the SAME sequential fmaf chain over the subspace's dimensions that the search kernels use for a query's look-up
+// table (jv_dev_common.h build_lut), ties -> lowest centroid index.  So encode(x) == argmin of x's own LUT row:
+// the write side and the read side share one arithmetic, and the CPU encoder (jv_build_cpu.cpp) is bit-identical.
+// One lane = one vector; the centroid components are wave-uniform (scalar loads); subspace of up to 64 dims.
+// ---------------------------------------------------------------------------------------------------------------
+#define PQE_MAX_DS 64
+__global__ __launch_bounds__(256) void jvb_pq_encode_kernel(const float* __restrict__ vectors, long long n, int d, int stride,
+                                                            int M, int K, const int32_t* __restrict__ sub_off,
+                                                            const float* __restrict__ codebooks,      // concat over m of [K][ds_m]
+                                                            const long long* __restrict__ cb_off,     // [M] float offset of subspace m
+                                                            const float* __restrict__ centroid,       // [d] or nullptr
+                                                            uint8_t* __restrict__ codes, int code_stride) {
+    const int m = blockIdx.y;
+    const int d0 = sub_off[m], ds = sub_off[m + 1] - d0;
+    const float* cb = codebooks + cb_off[m];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float x[PQE_MAX_DS];
+        const float* row = vectors + (size_t)i * (size_t)stride + d0;
+#pragma unroll
+        for (int j = 0; j < PQE_MAX_DS; j++) {
+            x[j] = 0.0f;
+            if (j < ds) x[j] = centroid ? row[j] - centroid[d0 + j] : row[j];
+        }
+        float best = 3.4028234663852886e38f;
+        int bc = 0;
+        for (int c = 0; c < K; c++) {
+            const float* cv = cb + (size_t)c * ds;  // wave-uniform address
+            float acc = 0.0f;
+#pragma unroll
+            for (int j = 0; j < PQE_MAX_DS; j++) {
+                if (j < ds) {
+                    const float df = x[j] - cv[j];
+                    acc = fmaf(df, df, acc);
+                }
+            }
+            if (acc < best) {
+                best = acc;
+                bc = c;
+            }
+        }
+        codes[(size_t)i * (size_t)code_stride + m] = (uint8_t)bc;
+    }
+}
+
+// device pointers everywhere; sub_off [M + 1] int32, cb_off [M] int64
+extern "C" int jvb_pq_encode_device(const float* vectors, long long n, int d, int stride, int M, int K, const int32_t* sub_off,
+                                    const float* codebooks, const long long* cb_off, const float* centroid, uint8_t* codes,
+                                    int code_stride, int max_ds, void* stream) {
+    if (n <= 0) return 0;
+    if (max_ds > PQE_MAX_DS || M <= 0 || K <= 0 || K > 256) return -4;
+    long long bx = (n + 255) / 256;
+    if (bx > 8192) bx = 8192;
+    dim3 grid((unsigned)bx, (unsigned)M);
+    jvb_pq_encode_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(vectors, n, d, stride, M, K, sub_off, codebooks, cb_off, centroid, codes,
+                                                                code_stride);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
