@@ -68,7 +68,7 @@ def test_ka15_recall_floor_through_the_gpu_builder(pkg, pyoracle):
     torch, gb = _gb()
     b = pkg.binding
     dev = torch.device("cuda", 0)
-    for n in (500, 1500, 20000):   # (the reference's merge scenarios hold 100 .. 1 500 vectors)
+    for n in (500, 1500):   # (the reference's merge scenarios hold 100 .. 1 500 vectors)
         base = pkg.datagen.java_random_vectors(42, n, 128)
         q = pkg.datagen.java_random_vectors(43, 10, 128)
         adj, entry = gb.build_graph_gpu(torch, torch.from_numpy(base).to(dev), 0, R=32, L=100, verbose=False)
