@@ -46,6 +46,8 @@ def load_library(path: str = LIB_PATH):
         lib.jvh_similarity_ord_to_dist_func.argtypes = [i32, vp]
         lib.jvh_similarity_dist_func_to_ord.argtypes = [i32]
         lib.jvh_concurrent_search_bench.argtypes = [vp, vp, i32, i32, i32, i32, i32, C.c_double, vp, vp]
+        lib.jvh_meta_write.argtypes = [vp, C.c_char_p, i32, vp, i32, vp, C.c_int64, vp]
+        lib.jvh_meta_read.argtypes = [vp, C.c_int64, vp, C.c_char_p, vp, i32, vp, vp, vp, C.c_int64]
         _lib = lib
     return _lib
 
@@ -157,3 +159,52 @@ def concurrent_search_bench(index: "binding.GpuIndex", queries: np.ndarray, topK
                                                 float(seconds), None if chk is None else chk.ctypes.data, out.ctypes.data))
     return {"threads": threads, "qps": float(out[0]), "p50_ms": float(out[1]), "p99_ms": float(out[2]),
             "completed": int(out[3]), "mismatches": int(out[4])}
+
+
+class MetaField(C.Structure):
+    """One VectorIndexFieldMetadata record of a .meta-jvector file (J/JVectorWriter.java:512-563)."""
+    _fields_ = [("fieldNumber", C.c_int32), ("vectorEncoding", C.c_int32), ("similarityOrd", C.c_int32),
+                ("vectorDimension", C.c_int32), ("vectorIndexOffset", C.c_int64), ("vectorIndexLength", C.c_int64),
+                ("compressedVectorsOffset", C.c_int64), ("compressedVectorsLength", C.c_int64),
+                ("quantizationType", C.c_int32), ("degreeOverflow", C.c_float), ("mapSize", C.c_int32),
+                ("mapMaxDoc", C.c_int32), ("ord2doc", C.c_void_p)]
+
+
+def meta_write(segment_id: bytes, suffix: str, version: int, fields) -> bytes:
+    """fields: list of dicts with the MetaField members + 'ord2doc' (int32 array).  Returns the file's bytes."""
+    lib = load_library()
+    arr = (MetaField * len(fields))()
+    keep = []
+    for i, f in enumerate(fields):
+        o2d = np.ascontiguousarray(f["ord2doc"], dtype=np.int32)
+        keep.append(o2d)
+        for k in ("fieldNumber", "vectorEncoding", "similarityOrd", "vectorDimension", "vectorIndexOffset", "vectorIndexLength",
+                  "compressedVectorsOffset", "compressedVectorsLength", "quantizationType", "degreeOverflow"):
+            setattr(arr[i], k, f[k])
+        arr[i].mapSize = o2d.shape[0]
+        arr[i].mapMaxDoc = f["mapMaxDoc"]
+        arr[i].ord2doc = o2d.ctypes.data
+    cap = 1 << 20
+    out = (C.c_uint8 * cap)()
+    n = C.c_int64()
+    sid = (C.c_uint8 * 16)(*segment_id)
+    _check(lib, lib.jvh_meta_write(sid, suffix.encode(), version, arr, len(fields), out, cap, C.byref(n)))
+    return bytes(out[:n.value])
+
+
+def meta_read(data: bytes, segment_id: bytes, suffix: str):
+    """Returns (version, [dict per field]) or raises HostError (-3: corrupt / truncated / mismatching file)."""
+    lib = load_library()
+    buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+    arr = (MetaField * 64)()
+    nf, ver = C.c_int(), C.c_int()
+    ords = np.zeros(1 << 20, dtype=np.int32)
+    sid = (C.c_uint8 * 16)(*segment_id)
+    _check(lib, lib.jvh_meta_read(buf, len(data), sid, suffix.encode(), arr, 64, C.byref(nf), C.byref(ver), ords.ctypes.data, ords.shape[0]))
+    fields, used = [], 0
+    for i in range(nf.value):
+        f = {k: getattr(arr[i], k) for k, _ in MetaField._fields_ if k != "ord2doc"}
+        f["ord2doc"] = ords[used:used + arr[i].mapSize].copy()
+        used += arr[i].mapSize
+        fields.append(f)
+    return ver.value, fields

@@ -178,6 +178,164 @@ void GraphNodeIdToDocMap::update(const std::vector<int>& oldToNew) {
     graphNodeIdsToDocIds_.swap(newOrd2Doc);
 }
 
+// ---- .meta-jvector ----
+namespace {
+struct ByteWriter {
+    std::vector<uint8_t> b;
+    void u8(uint8_t v) { b.push_back(v); }
+    void beInt(uint32_t v) { for (int i = 3; i >= 0; i--) b.push_back((uint8_t)(v >> (8 * i))); }
+    void beLong(uint64_t v) { for (int i = 7; i >= 0; i--) b.push_back((uint8_t)(v >> (8 * i))); }
+    void leInt(uint32_t v) { for (int i = 0; i < 4; i++) b.push_back((uint8_t)(v >> (8 * i))); }   // DataOutput.writeInt, Lucene >= 9
+    void vInt(int32_t v) { writeVInt(b, v); }
+    void vLong(int64_t v) {  // DataOutput.writeVLong (non-negative)
+        uint64_t i = (uint64_t)v;
+        while ((i & ~0x7Full) != 0) {
+            b.push_back((uint8_t)((i & 0x7F) | 0x80));
+            i >>= 7;
+        }
+        b.push_back((uint8_t)i);
+    }
+    void str(const std::string& s) {
+        vInt((int32_t)s.size());
+        b.insert(b.end(), s.begin(), s.end());
+    }
+};
+struct ByteReader {
+    const std::vector<uint8_t>& in;
+    size_t pos = 0;
+    uint8_t u8() {
+        if (pos >= in.size()) throw IOException("read past EOF");
+        return in[pos++];
+    }
+    uint32_t beInt() { uint32_t v = 0; for (int i = 0; i < 4; i++) v = (v << 8) | u8(); return v; }
+    uint64_t beLong() { uint64_t v = 0; for (int i = 0; i < 8; i++) v = (v << 8) | u8(); return v; }
+    uint32_t leInt() { uint32_t v = 0; for (int i = 0; i < 4; i++) v |= (uint32_t)u8() << (8 * i); return v; }
+    int32_t vInt() { return readVInt(in, pos); }
+    int64_t vLong() {
+        uint64_t v = 0;
+        for (int shift = 0; shift < 63; shift += 7) {
+            uint8_t b = u8();
+            v |= (uint64_t)(b & 0x7F) << shift;
+            if (!(b & 0x80)) return (int64_t)v;
+        }
+        throw IOException("Invalid vLong detected (negative values disallowed)");
+    }
+};
+uint32_t crc32(const uint8_t* p, size_t n) {  // java.util.zip.CRC32 (reflected 0xEDB88320), as BufferedChecksum uses
+    static uint32_t table[256];
+    static bool init = false;
+    if (!init) {
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            table[i] = c;
+        }
+        init = true;
+    }
+    uint32_t c = 0xFFFFFFFFu;
+    for (size_t i = 0; i < n; i++) c = table[(c ^ p[i]) & 0xFF] ^ (c >> 8);
+    return c ^ 0xFFFFFFFFu;
+}
+constexpr uint32_t CODEC_MAGIC = 0x3fd76c17u, FOOTER_MAGIC = ~CODEC_MAGIC;
+}  // namespace
+
+std::vector<uint8_t> JVectorMeta::write(const uint8_t segmentId[16], const std::string& segmentSuffix, int version,
+                                        const std::vector<VectorIndexFieldMetadata>& fields) {
+    if (version < VERSION_START || version > VERSION_CURRENT) throw IllegalArgumentException("unsupported meta version " + std::to_string(version));
+    if (segmentSuffix.size() > 255) throw IllegalArgumentException("suffix too long");
+    ByteWriter w;
+    // CodecUtil.writeIndexHeader
+    w.beInt(CODEC_MAGIC);
+    w.str(META_CODEC_NAME);
+    w.beInt((uint32_t)version);
+    for (int i = 0; i < 16; i++) w.u8(segmentId[i]);
+    w.u8((uint8_t)segmentSuffix.size());
+    w.b.insert(w.b.end(), segmentSuffix.begin(), segmentSuffix.end());
+    for (const VectorIndexFieldMetadata& f : fields) {
+        w.leInt((uint32_t)f.fieldNumber);  // J/JVectorWriter.java:299 (consumed by readFields' loop header)
+        // VectorIndexFieldMetadata.toOutput (:528-540)
+        w.leInt((uint32_t)f.fieldNumber);
+        w.leInt((uint32_t)f.vectorEncoding);
+        w.leInt((uint32_t)f.similarityOrd);
+        w.vInt(f.vectorDimension);
+        w.vLong(f.vectorIndexOffset);
+        w.vLong(f.vectorIndexLength);
+        w.vLong(f.compressedVectorsOffset);
+        w.vLong(f.compressedVectorsLength);
+        if (version >= VERSION_WITH_QUANTIZATION_TYPE) w.u8((uint8_t)f.quantizationType);
+        uint32_t bits;
+        memcpy(&bits, &f.degreeOverflow, 4);
+        w.leInt(bits);
+        const std::vector<uint8_t> m = f.graphNodeIdToDocMap.toOutput();
+        w.b.insert(w.b.end(), m.begin(), m.end());
+    }
+    w.leInt(0xFFFFFFFFu);  // end-of-fields marker (:575)
+    // CodecUtil.writeFooter
+    w.beInt(FOOTER_MAGIC);
+    w.beInt(0);
+    w.beLong((uint64_t)crc32(w.b.data(), w.b.size()));
+    return w.b;
+}
+
+std::vector<VectorIndexFieldMetadata> JVectorMeta::read(const std::vector<uint8_t>& file, const uint8_t expectedSegmentId[16],
+                                                        const std::string& expectedSuffix, int* versionOut) {
+    ByteReader r{file};
+    // CodecUtil.checkIndexHeader
+    if (r.beInt() != CODEC_MAGIC) throw IOException("codec header mismatch: bad magic");
+    const int32_t nameLen = r.vInt();
+    std::string name;
+    for (int i = 0; i < nameLen; i++) name.push_back((char)r.u8());
+    if (name != META_CODEC_NAME) throw IOException("codec mismatch: actual codec=" + name + " vs expected codec=" + META_CODEC_NAME);
+    const int version = (int)r.beInt();
+    if (version < VERSION_START) throw IOException("Format version is not supported (too old): " + std::to_string(version));
+    if (version > VERSION_CURRENT) throw IOException("Format version is not supported (too new): " + std::to_string(version));
+    for (int i = 0; i < 16; i++)
+        if (r.u8() != expectedSegmentId[i]) throw IOException("file mismatch, expected id differs");
+    const int suffixLen = r.u8();
+    std::string suffix;
+    for (int i = 0; i < suffixLen; i++) suffix.push_back((char)r.u8());
+    if (suffix != expectedSuffix) throw IOException("file mismatch, expected suffix=" + expectedSuffix + ", got=" + suffix);
+    std::vector<VectorIndexFieldMetadata> fields;
+    // readFields (J/JVectorReader.java:255-262)
+    for (int32_t fieldNumber = (int32_t)r.leInt(); fieldNumber != -1; fieldNumber = (int32_t)r.leInt()) {
+        VectorIndexFieldMetadata f;
+        f.fieldNumber = (int32_t)r.leInt();
+        if (f.fieldNumber != fieldNumber) throw IOException("field number mismatch in meta record");
+        f.vectorEncoding = (int32_t)r.leInt();
+        if (f.vectorEncoding < 0 || f.vectorEncoding > 1) throw IOException("Invalid vector encoding id: " + std::to_string(f.vectorEncoding));
+        f.similarityOrd = (int32_t)r.leInt();
+        if (f.similarityOrd < 0 || f.similarityOrd > 2) throw IllegalArgumentException("Invalid ordinal: " + std::to_string(f.similarityOrd));
+        f.vectorDimension = r.vInt();
+        f.vectorIndexOffset = r.vLong();
+        f.vectorIndexLength = r.vLong();
+        f.compressedVectorsOffset = r.vLong();
+        f.compressedVectorsLength = r.vLong();
+        if (version >= VERSION_WITH_QUANTIZATION_TYPE) f.quantizationType = (int8_t)r.u8();
+        else f.quantizationType = f.compressedVectorsLength > 0 ? 1 : 0;  // v0: PQ iff compressed vectors are present
+        const uint32_t bits = r.leInt();
+        memcpy(&f.degreeOverflow, &bits, 4);
+        // GraphNodeIdToDocMap(IndexInput): parse in place to learn its length
+        const size_t start = r.pos;
+        const int32_t mapVersion = (int32_t)r.leInt();
+        if (mapVersion != 1) throw IOException("Unsupported version: " + std::to_string(mapVersion));
+        const int32_t size = r.vInt();
+        (void)r.vInt();
+        for (int i = 0; i < size; i++) (void)r.vInt();
+        f.graphNodeIdToDocMap = GraphNodeIdToDocMap::fromBytes(std::vector<uint8_t>(file.begin() + (long)start, file.begin() + (long)r.pos));
+        fields.push_back(std::move(f));
+    }
+    // CodecUtil.checkFooter
+    const size_t footerStart = r.pos;
+    if (file.size() - footerStart != 16) throw IOException("misplaced codec footer (file truncated or extended?)");
+    if (r.beInt() != FOOTER_MAGIC) throw IOException("codec footer mismatch (file truncated?)");
+    if (r.beInt() != 0) throw IOException("codec footer mismatch: unknown algorithmID");
+    const uint64_t stored = r.beLong();
+    const uint32_t actual = crc32(file.data(), footerStart + 8);
+    if ((stored & 0xFFFFFFFF00000000ull) != 0 || (uint32_t)stored != actual) throw IOException("checksum failed (hardware problem?)");
+    if (versionOut) *versionOut = version;
+    return fields;
+}
+
 // ---- JVectorReader ----
 JVectorReader::FieldEntry::~FieldEntry() { jv_index_destroy(index); }
 

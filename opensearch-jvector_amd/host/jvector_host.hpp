@@ -159,6 +159,32 @@ private:
     std::vector<int> graphNodeIdsToDocIds_, docIdsToGraphNodeIds_;
 };
 
+// ---- the plugin-owned segment metadata file "<segment>_<suffix>.meta-jvector"  ----
+// J/JVectorWriter.java:512-563 (VectorIndexFieldMetadata.toOutput / the IndexInput constructor), :299 (field number written
+// in front of every record), :573-577 (end marker -1 + footer); J/JVectorReader.java:52-81,255-262 (checkIndexHeader /
+// readFields / checkFooter); J/JVectorFormat.java:23,31-33 (codec name, versions 0 and 1).
+struct VectorIndexFieldMetadata {
+    int32_t fieldNumber = 0;
+    int32_t vectorEncoding = 1;            // Lucene VectorEncoding ordinal: 0 BYTE, 1 FLOAT32
+    int32_t similarityOrd = 0;             // VectorSimilarityMapper.distFuncToOrd: 0 L2, 1 DOT (also MIP), 2 COSINE
+    int32_t vectorDimension = 0;
+    int64_t vectorIndexOffset = 0, vectorIndexLength = 0, compressedVectorsOffset = 0, compressedVectorsLength = 0;
+    int8_t quantizationType = 0;           // 0 none, 1 PQ, 2 NVQ-inline (absent in version 0: inferred from the PQ length)
+    float degreeOverflow = 0.0f;
+    GraphNodeIdToDocMap graphNodeIdToDocMap;
+};
+namespace JVectorMeta {
+constexpr const char* META_CODEC_NAME = "JVectorVectorsFormatMeta";
+constexpr int VERSION_START = 0, VERSION_WITH_QUANTIZATION_TYPE = 1, VERSION_CURRENT = 1;
+// the whole file: CodecUtil index header (big-endian magic / version, codec name, 16-byte segment id, suffix), the
+// records (little-endian ints, vints), the end marker and the CodecUtil footer (magic, algorithm 0, CRC32 of all before it)
+std::vector<uint8_t> write(const uint8_t segmentId[16], const std::string& segmentSuffix, int version,
+                           const std::vector<VectorIndexFieldMetadata>& fields);
+// throws IOException for a truncated / corrupt file (bad magic, codec, version range, segment id, suffix, checksum)
+std::vector<VectorIndexFieldMetadata> read(const std::vector<uint8_t>& file, const uint8_t expectedSegmentId[16],
+                                           const std::string& expectedSuffix, int* versionOut);
+}  // namespace JVectorMeta
+
 // J/JVectorReader.java — the codec reader; one FieldEntry per (segment, field) owns one HBM index
 class JVectorReader {
 public:

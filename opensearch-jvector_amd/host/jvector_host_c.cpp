@@ -207,4 +207,74 @@ int jvh_concurrent_search_bench(jv_index* index, const float* queries, int nq, i
     return 0;
 }
 
-}  // extern "C"
+
+// ---- .meta-jvector (host/jvector_host.hpp JVectorMeta): flat view for the byte-level round-trip test ----
+struct jvh_meta_field {
+    int32_t fieldNumber, vectorEncoding, similarityOrd, vectorDimension;
+    int64_t vectorIndexOffset, vectorIndexLength, compressedVectorsOffset, compressedVectorsLength;
+    int32_t quantizationType;
+    float degreeOverflow;
+    int32_t mapSize, mapMaxDoc;       // GraphNodeIdToDocMap: ordinals, doc-id space (maxDoc = highest doc id + 1)
+    const int32_t* ord2doc;           // write: [mapSize]; read: filled into the caller's buffer
+};
+
+int jvh_meta_write(const uint8_t* segment_id, const char* suffix, int version, const jvh_meta_field* fields, int nfields,
+                   uint8_t* out, int64_t cap, int64_t* out_len) {
+    return guard([&] {
+        std::vector<VectorIndexFieldMetadata> fs;
+        for (int i = 0; i < nfields; i++) {
+            VectorIndexFieldMetadata f;
+            f.fieldNumber = fields[i].fieldNumber;
+            f.vectorEncoding = fields[i].vectorEncoding;
+            f.similarityOrd = fields[i].similarityOrd;
+            f.vectorDimension = fields[i].vectorDimension;
+            f.vectorIndexOffset = fields[i].vectorIndexOffset;
+            f.vectorIndexLength = fields[i].vectorIndexLength;
+            f.compressedVectorsOffset = fields[i].compressedVectorsOffset;
+            f.compressedVectorsLength = fields[i].compressedVectorsLength;
+            f.quantizationType = (int8_t)fields[i].quantizationType;
+            f.degreeOverflow = fields[i].degreeOverflow;
+            std::vector<int> o2d(fields[i].ord2doc, fields[i].ord2doc + fields[i].mapSize);
+            f.graphNodeIdToDocMap = GraphNodeIdToDocMap(o2d, fields[i].mapMaxDoc - 1);
+            fs.push_back(std::move(f));
+        }
+        std::vector<uint8_t> b = JVectorMeta::write(segment_id, suffix ? suffix : "", version, fs);
+        *out_len = (int64_t)b.size();
+        if ((int64_t)b.size() > cap) throw IOException("output buffer too small");
+        memcpy(out, b.data(), b.size());
+    });
+}
+
+int jvh_meta_read(const uint8_t* file, int64_t len, const uint8_t* segment_id, const char* suffix, jvh_meta_field* fields,
+                  int max_fields, int* nfields, int* version, int32_t* ord2doc_buf, int64_t ord_cap) {
+    return guard([&] {
+        std::vector<uint8_t> in(file, file + len);
+        std::vector<VectorIndexFieldMetadata> fs = JVectorMeta::read(in, segment_id, suffix ? suffix : "", version);
+        *nfields = (int)fs.size();
+        if ((int)fs.size() > max_fields) throw IOException("too many fields for the caller's buffer");
+        int64_t used = 0;
+        for (size_t i = 0; i < fs.size(); i++) {
+            const VectorIndexFieldMetadata& f = fs[i];
+            jvh_meta_field& o = fields[i];
+            o.fieldNumber = f.fieldNumber;
+            o.vectorEncoding = f.vectorEncoding;
+            o.similarityOrd = f.similarityOrd;
+            o.vectorDimension = f.vectorDimension;
+            o.vectorIndexOffset = f.vectorIndexOffset;
+            o.vectorIndexLength = f.vectorIndexLength;
+            o.compressedVectorsOffset = f.compressedVectorsOffset;
+            o.compressedVectorsLength = f.compressedVectorsLength;
+            o.quantizationType = f.quantizationType;
+            o.degreeOverflow = f.degreeOverflow;
+            o.mapSize = f.graphNodeIdToDocMap.size();
+            o.mapMaxDoc = f.graphNodeIdToDocMap.maxDoc();
+            if (used + o.mapSize > ord_cap) throw IOException("ord2doc buffer too small");
+            for (int k = 0; k < o.mapSize; k++) ord2doc_buf[used + k] = f.graphNodeIdToDocMap.ordToDoc()[(size_t)k];
+            o.ord2doc = ord2doc_buf + used;
+            used += o.mapSize;
+        }
+    });
+}
+
+}
+
