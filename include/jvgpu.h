@@ -235,7 +235,7 @@ int jv_index_get_info(const jv_index* index, jv_index_info* out);
  * created afterwards start from (nothing process-wide is read at call time).  Names: "lds_visited_slots",
  * "lds_candidates", "force_big_path", "force_general_path", "big_blocks", "big_cand_cap", "big_budget_mb",
  * "spill_tables", "spill_slots", "combine", "combine_leaders", "combine_max_batch", "max_contexts", "filter_cache"
- * (+ diagnostics: "no_escalation", "no_pqf", "no_pqp", "no_pqr", "no_lutr", "pqf_only", "dbg_ptr").
+ * (+ diagnostics: "no_escalation", "no_pqf", "no_pqp", "no_lutr", "lutr_min_queries", "pqf_only", "dbg_ptr").
  * JV_EINVAL for unknown names. */
 int jv_set_option(const char* name, int64_t value);
 int jv_index_set_option(jv_index* index, const char* name, int64_t value);

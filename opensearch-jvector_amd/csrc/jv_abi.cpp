@@ -38,11 +38,6 @@ hipError_t jvk_launch_merge_topk(const int32_t* d_docs, const float* d_scores, i
 hipError_t jvk_launch_merge_topk_strided(const int32_t* d_pairs, const float* unused, int nq, int lists, int k,
                                          int32_t* d_out_docs, float* d_out_scores, hipStream_t s);
 hipError_t jvk_launch_pack_pairs(const int32_t* d_docs, const float* d_scores, int32_t* d_pairs, long long n, hipStream_t s);
-// register-pool kernel (jv_kernels_pqr.hip)
-hipError_t jvk_pqr_set_max_lds(int bytes);
-int jvk_pqr_capacity(void);
-int jvk_pqr_blocks_per_cu(const JvIndexDev* ix, int lds_bytes);
-hipError_t jvk_launch_search_pqr(const JvIndexDev* ix, const JvSearchArgs* a, int lds_bytes, int blocks, hipStream_t s);
 // LDS-pool persistent kernel (jv_kernels_pqp.hip): the headline path
 hipError_t jvk_pqp_set_max_lds(int bytes);
 int jvk_pqp_max_entries(void);
@@ -78,14 +73,15 @@ int fail(int code, const char* fmt, ...) {
 // Tunables.  Every index carries its own set (jv_index_set_option); jv_set_option only changes the DEFAULTS that
 // indexes created afterwards start from — nothing process-wide is read at call time.
 //   lds_visited_slots / lds_candidates   on-chip scratch geometry of the generic kernels (0 = auto)
-//   force_big_path / force_general_path / no_escalation / no_pqf / no_pqr / no_pqp / no_lutr / pqf_only   rung selection (diagnostics)
+//   force_big_path / force_general_path / no_escalation / no_pqf / no_pqp / no_lutr / pqf_only   rung selection (diagnostics)
 //   spill_tables x spill_slots           per-context pool of visited-set spill tables (512 x 8192 x 4 B = 16 MB, allocated on first use)
 //   big_blocks / big_cand_cap / big_budget_mb   HBM-scratch rung: resident blocks (0 = as many as fit the budget), candidate slots
 //   combine / combine_leaders / combine_max_batch   group commit of concurrent jv_search calls
 //   max_contexts                         cap of per-index launch contexts (callers beyond it wait)
 //   filter_cache                         device-resident doc-filter bitsets kept per index (0 = off)
+//   lutr_min_queries                     launches with more queries keep the PQ look-up table in registers (-1 = 4 per CU)
 //   dbg_ptr                              diagnostic build only
-enum OptId { OPT_LDS_VISITED_SLOTS, OPT_LDS_CANDIDATES, OPT_FORCE_BIG, OPT_FORCE_GENERAL, OPT_NO_ESCALATION, OPT_DBG_PTR, OPT_NO_PQF, OPT_NO_PQR, OPT_NO_PQP, OPT_NO_LUTR, OPT_PQF_ONLY, OPT_SPILL_TABLES, OPT_SPILL_SLOTS, OPT_BIG_BLOCKS, OPT_BIG_CAND_CAP, OPT_BIG_BUDGET_MB, OPT_COMBINE, OPT_COMBINE_LEADERS, OPT_COMBINE_MAX_BATCH, OPT_MAX_CONTEXTS, OPT_FILTER_CACHE, OPT_COUNT };
+enum OptId { OPT_LDS_VISITED_SLOTS, OPT_LDS_CANDIDATES, OPT_FORCE_BIG, OPT_FORCE_GENERAL, OPT_NO_ESCALATION, OPT_DBG_PTR, OPT_NO_PQF, OPT_NO_PQP, OPT_NO_LUTR, OPT_LUTR_MIN_QUERIES, OPT_PQF_ONLY, OPT_SPILL_TABLES, OPT_SPILL_SLOTS, OPT_BIG_BLOCKS, OPT_BIG_CAND_CAP, OPT_BIG_BUDGET_MB, OPT_COMBINE, OPT_COMBINE_LEADERS, OPT_COMBINE_MAX_BATCH, OPT_MAX_CONTEXTS, OPT_FILTER_CACHE, OPT_COUNT };
 struct OptName { const char* name; int64_t def; };
 const OptName kOptNames[OPT_COUNT] = {
     {"lds_visited_slots", 0},
@@ -95,9 +91,9 @@ const OptName kOptNames[OPT_COUNT] = {
     {"no_escalation", 0},
     {"dbg_ptr", 0},
     {"no_pqf", 0},
-    {"no_pqr", 1},
     {"no_pqp", 0},
     {"no_lutr", 0},
+    {"lutr_min_queries", -1},
     {"pqf_only", 0},
     {"spill_tables", 512},
     {"spill_slots", 8192},
@@ -155,8 +151,8 @@ struct Ctx {
     uint32_t* spill = nullptr;
     int spill_tables = 0, spill_slots = 0;
     // register-pool kernel: per-resident-workgroup expansion logs
-    int32_t* pqr_log = nullptr;
-    size_t pqr_log_ints = 0;
+    int32_t* pqp_log = nullptr;
+    size_t pqp_log_ints = 0;
 };
 
 // One caller's jv_search waiting to be served.  Lives on the caller's stack.
@@ -292,7 +288,7 @@ void ctx_destroy(Ctx* c) {
     if (c->h_query) hipHostFree(c->h_query);
     hipFree(c->work_counter);
     hipFree(c->spill);
-    hipFree(c->pqr_log);
+    hipFree(c->pqp_log);
     if (c->last_use) hipEventDestroy(c->last_use);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -504,7 +500,7 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
         const int lut_b = ix->dev.pq_M * 256 * 4;
         const int qc_b = ix->dev.nch * 64 * 4;
         ap.cand_cap = rk + 64 + ix->dev.R;
-        ap.pqr_log_cap = (3 * rk + 64 + 3) & ~3;
+        ap.pqp_log_cap = (3 * rk + 64 + 3) & ~3;
         bool alias = qc_b <= lut_b;
         const int off_f = ix->dev.pq_M * 256 - ix->dev.nch * 64;
         for (int m = 0; alias && m + 1 < ix->dev.pq_M; m++)
@@ -512,76 +508,39 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
         const int rerank_b = qc_b + JV_TODO * 8 + ((rk + 1) & ~1) * 8;   // after the search, in front of the pool
         // Table in registers (8 resident queries per CU, +34 % throughput at rerankK = 1 200, but 1.7x the latency of
         // one query): only when the launch has more queries than the LDS-table variant could keep resident anyway
-        const int lutr = (OPT(ix, OPT_NO_LUTR) == 0 && jvk_pqp_lutr_ok(&ix->dev, ap.cand_cap) && nq > 4 * ix->cu_count) ? 1 : 0;
+        const int64_t lutr_min = OPT(ix, OPT_LUTR_MIN_QUERIES) >= 0 ? OPT(ix, OPT_LUTR_MIN_QUERIES) : 4 * (int64_t)ix->cu_count;
+        const int lutr = (OPT(ix, OPT_NO_LUTR) == 0 && jvk_pqp_lutr_ok(&ix->dev, ap.cand_cap) && nq > lutr_min) ? 1 : 0;
         int lds;
         if (lutr) {
             // table in registers: LDS = the pool while searching, one hash set afterwards (>= 4 096 slots), then the
             // rerank scratch with the pool written back behind the query and todo lists
             const int pool_b = (ap.cand_cap + 1) * 8;
-            ap.pqr_pool_off = 0;
-            ap.pqr_qc_off = 0;
+            ap.pqp_pool_off = 0;
+            ap.pqp_qc_off = 0;
             lds = std::max(std::max(pool_b, qc_b), std::max(16384, qc_b + JV_TODO * 8 + pool_b));
         } else {
-            ap.pqr_pool_off = (std::max(lut_b, rerank_b) + 15) & ~15;
-            lds = ap.pqr_pool_off + (ap.cand_cap + 1) * 8;
-            ap.pqr_qc_off = alias ? lut_b - qc_b : ((lds + 15) & ~15);
-            if (!alias) lds = ap.pqr_qc_off + qc_b;
+            ap.pqp_pool_off = (std::max(lut_b, rerank_b) + 15) & ~15;
+            lds = ap.pqp_pool_off + (ap.cand_cap + 1) * 8;
+            ap.pqp_qc_off = alias ? lut_b - qc_b : ((lds + 15) & ~15);
+            if (!alias) lds = ap.pqp_qc_off + qc_b;
         }
         lds = (lds + 15) & ~15;
-        ap.pqr_lds_bytes = lds;
+        ap.pqp_lds_bytes = lds;
         if (lds <= kMaxLds) {
             const int per_cu = jvk_pqp_blocks_per_cu(&ix->dev, ap.cand_cap, lds, lutr);
             int blocks = ix->cu_count * per_cu;
             if (blocks > nq) blocks = nq;
-            const size_t need = (size_t)blocks * (size_t)ap.pqr_log_cap;
-            if (need > c->pqr_log_ints) {
-                if (c->pqr_log) HIPCHK(hipFree(c->pqr_log));
-                c->pqr_log = nullptr;
-                c->pqr_log_ints = 0;
-                HIPCHK(hipMalloc((void**)&c->pqr_log, need * sizeof(int32_t)));
-                c->pqr_log_ints = need;
+            const size_t need = (size_t)blocks * (size_t)ap.pqp_log_cap;
+            if (need > c->pqp_log_ints) {
+                if (c->pqp_log) HIPCHK(hipFree(c->pqp_log));
+                c->pqp_log = nullptr;
+                c->pqp_log_ints = 0;
+                HIPCHK(hipMalloc((void**)&c->pqp_log, need * sizeof(int32_t)));
+                c->pqp_log_ints = need;
             }
-            ap.pqr_log = c->pqr_log;
-            ap.pqr_counter = c->work_counter + 6;
+            ap.pqp_log = c->pqp_log;
+            ap.pqp_counter = c->work_counter + 6;
             HIPCHK(jvk_launch_search_pqp(&ix->dev, &ap, lds, blocks, lutr, stream));
-            pqf = true;
-        }
-    }
-    // (comparison only, option no_pqr = 0) the register-pool kernel (jv_kernels_pqr.hip): no filter, threshold <= 0, pool of rk + 64 boundary
-    // ties + one expansion's R new keys in at most 2 048 register slots; LDS = the look-up table only
-    if (!pqf && !force_big && !filtered && g.pool && pqf_index && rk + 64 + ix->dev.R <= jvk_pqr_capacity() && OPT(ix, OPT_NO_PQF) == 0 &&
-        OPT(ix, OPT_NO_PQR) == 0) {
-        JvSearchArgs ap = a;
-        const int lut_b = ix->dev.pq_M * 256 * 4;
-        const int qc_b = ix->dev.nch * 64 * 4;
-        ap.cand_cap = rk + 64 + ix->dev.R;
-        ap.pqr_log_cap = (3 * rk + 64 + 3) & ~3;
-        // the centred query is only needed while the table is built: it may sit in the table's own tail when no row
-        // is written over dimensions a later row still reads (row m covers floats [256 m, 256 m + 256) of the table)
-        bool alias = qc_b <= lut_b;
-        const int off_f = ix->dev.pq_M * 256 - ix->dev.nch * 64;
-        for (int m = 0; alias && m + 1 < ix->dev.pq_M; m++)
-            if ((m + 1) * 256 - off_f > ix->pq_sub_off[(size_t)m + 1]) alias = false;
-        ap.pqr_qc_off = alias ? lut_b - qc_b : lut_b;
-        int lds = alias ? lut_b : lut_b + qc_b;
-        const int rerank_b = qc_b + JV_TODO * 8 + ((rk + 1) & ~1) * 8 + rk * 4;
-        if (lds < rerank_b) lds = rerank_b;
-        lds = (lds + 15) & ~15;
-        if (lds <= kMaxLds) {
-            const int per_cu = jvk_pqr_blocks_per_cu(&ix->dev, lds);
-            int blocks = ix->cu_count * per_cu;
-            if (blocks > nq) blocks = nq;
-            const size_t need = (size_t)blocks * (size_t)ap.pqr_log_cap;
-            if (need > c->pqr_log_ints) {
-                if (c->pqr_log) HIPCHK(hipFree(c->pqr_log));
-                c->pqr_log = nullptr;
-                c->pqr_log_ints = 0;
-                HIPCHK(hipMalloc((void**)&c->pqr_log, need * sizeof(int32_t)));
-                c->pqr_log_ints = need;
-            }
-            ap.pqr_log = c->pqr_log;
-            ap.pqr_counter = c->work_counter + 6;
-            HIPCHK(jvk_launch_search_pqr(&ix->dev, &ap, lds, blocks, stream));
             pqf = true;
         }
     }
@@ -955,7 +914,6 @@ int jv_index_create(const jv_index_desc* desc, jv_index** out) {
             ix->info.fused_adc = 1;
         }
         TRYHIP(jvk_set_max_lds(kMaxLds));
-        TRYHIP(jvk_pqr_set_max_lds(kMaxLds));
         TRYHIP(jvk_pqp_set_max_lds(kMaxLds));
         {
             hipDeviceProp_t prop;
@@ -989,7 +947,7 @@ int jv_index_get_info(const jv_index* index, jv_index_info* out) {
     {
         std::lock_guard<std::mutex> lk(ix->mu);
         for (const Ctx* c : ix->all_ctx)
-            scratch += (int64_t)(c->queries_cap * 4 + c->nq_cap * 4 + c->accept_cap * 8 + c->arena_cap + c->pqr_log_ints * 4 +
+            scratch += (int64_t)(c->queries_cap * 4 + c->nq_cap * 4 + c->accept_cap * 8 + c->arena_cap + c->pqp_log_ints * 4 +
                                  (size_t)c->spill_tables * (size_t)c->spill_slots * 4 + 32);
     }
     {

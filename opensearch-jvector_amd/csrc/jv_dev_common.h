@@ -1,4 +1,4 @@
-// jv_dev_common.h — device helpers shared by the kernel translation units (jv_kernels.hip, jv_kernels_pqr.hip):
+// jv_dev_common.h — device helpers shared by the kernel translation units (jv_kernels.hip, jv_kernels_pqp.hip):
 // NodeQueue keys, cross-lane helpers, the canonical exact / PQ scoring, visited sets, the threshold tracker.
 // gfx950 only.  Compile with -ffp-contract=off: every fused multiply-add is an explicit fmaf().
 #pragma once

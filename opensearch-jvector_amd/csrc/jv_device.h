@@ -82,12 +82,12 @@ struct JvSearchArgs {
     int32_t* spill_counter;  // zeroed per call
     int64_t* dbg;            // diagnostic build (-DJV_STAMPS) only: 8 cycle accumulators; nullptr in the product
     // register-pool kernel (jv_kernels_pqr.hip): persistent grid
-    int32_t* pqr_log;        // [blocks][pqr_log_cap] expansion log scratch
-    int32_t pqr_log_cap;
-    int32_t pqr_qc_off;      // LDS byte offset of the centred query during the LUT build
-    int32_t pqr_pool_off;    // LDS byte offset of the pool (jv_kernels_pqp.hip)
-    int32_t pqr_lds_bytes;   // dynamic LDS bytes of the launch (register-LUT variant: the visited-count hash set uses all of it)
-    int32_t* pqr_counter;    // query dequeue counter (zeroed per call)
+    int32_t* pqp_log;        // [blocks][pqp_log_cap] expansion log scratch
+    int32_t pqp_log_cap;
+    int32_t pqp_qc_off;      // LDS byte offset of the centred query during the LUT build
+    int32_t pqp_pool_off;    // LDS byte offset of the pool (jv_kernels_pqp.hip)
+    int32_t pqp_lds_bytes;   // dynamic LDS bytes of the launch (register-LUT variant: the visited-count hash set uses all of it)
+    int32_t* pqp_counter;    // query dequeue counter (zeroed per call)
 };
 
 #define JV_FLAG_OVERFLOW 0x80000000u /* on-chip scratch overflow: query must be re-run on the big path */

@@ -55,8 +55,8 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
     const int M = ix.pq_M, R = ix.R, lpn = ix.pq_lanes, cs = ix.pq_code_stride;
     float* lut = (float*)smem;  // [M][256]; later: visited-count hash, then rerank scratch
     const int lut_bytes = M * 256 * (int)sizeof(float);
-    float* qc_lds = (float*)(smem + a.pqr_qc_off);  // centred query, only during the LUT build (may alias the LUT's tail)
-    const int log_cap = a.pqr_log_cap;
+    float* qc_lds = (float*)(smem + a.pqp_qc_off);  // centred query, only during the LUT build (may alias the LUT's tail)
+    const int log_cap = a.pqp_log_cap;
 
     int32_t* o_nodes = a.out_nodes + (size_t)qi * topK;
     int32_t* o_docs = a.out_docs ? a.out_docs + (size_t)qi * topK : nullptr;
@@ -160,7 +160,7 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
 
     // ---- the pool: sorted descending; bit 0 of a key = "not expanded yet"; slots [np, cap] hold the minimum key ----
     const int cap = a.cand_cap;                   // entries; slot `cap` is a permanent sentinel
-    int64_t* pool = (int64_t*)(smem + a.pqr_pool_off);
+    int64_t* pool = (int64_t*)(smem + a.pqp_pool_off);
     for (int i = lane; i <= cap; i += JV_WAVE) pool[i] = KEY_MIN;
     int np = 0, nexp = 0, expanded = 0, lo_un = 0;
     int why = 0;
@@ -433,7 +433,7 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
         // lives where the LUT was; node ids are split into `parts` hash classes counted one after the other when one
         // table cannot hold them all (adjacency rows are re-read once per class). ----
         uint32_t* vh = (uint32_t*)smem;
-        const int hash_bytes = LUTR ? a.pqr_lds_bytes : lut_bytes;
+        const int hash_bytes = LUTR ? a.pqp_lds_bytes : lut_bytes;
         int vslots = 1;
         while (vslots * 2 * 4 <= hash_bytes) vslots <<= 1;
         const uint32_t vmask = (uint32_t)vslots - 1u;
@@ -665,10 +665,10 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
 template <int NCHT, int NP, bool FAST, int CAPK, bool LUTR = false>
 __global__ __launch_bounds__(JV_WAVE, LUTR ? 2 : 1) void jv_search_pqp_kernel(const JvIndexDev ix, const JvSearchArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int32_t* explog = a.pqr_log + (size_t)blockIdx.x * (size_t)a.pqr_log_cap;
+    int32_t* explog = a.pqp_log + (size_t)blockIdx.x * (size_t)a.pqp_log_cap;
     for (;;) {
         int qi = 0;
-        if (threadIdx.x == 0) qi = atomicAdd(a.pqr_counter, 1);
+        if (threadIdx.x == 0) qi = atomicAdd(a.pqp_counter, 1);
         qi = __builtin_amdgcn_readfirstlane(qi);
         if (qi >= a.nq) break;
         search_one_pqp<NCHT, NP, FAST, CAPK, LUTR>(ix, a, qi, smem, explog);

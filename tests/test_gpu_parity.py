@@ -235,6 +235,15 @@ def test_fused_adc_layout_parity(pkg, pyoracle, small_sets, sim, M, R):
             _assert_same(gpu.search_batch(q, k, rk), want, f"fused/no_pqf sim={sim} M={M} R={R} k={k} rk={rk}")
         finally:
             gpu.set_option("no_pqf", 0)
+        if M == 32 and R == 32 and sim != 2:
+            # the large-launch variant of the headline kernel (look-up table in registers) on this small batch, and the
+            # round-1 LDS-pool kernel: both must give the same bits
+            for opt, val, back in (("lutr_min_queries", 0, -1), ("no_pqp", 1, 0)):
+                try:
+                    gpu.set_option(opt, val)
+                    _assert_same(gpu.search_batch(q, k, rk), want, f"fused/{opt} sim={sim} M={M} R={R} k={k} rk={rk}")
+                finally:
+                    gpu.set_option(opt, back)
     gpu.close()
 
 
