@@ -350,8 +350,9 @@ class Engine:
             raise SystemExit(f"bench: {bad} of {nq} queries were flagged FAILED/OVERFLOW by the engine (results invalid)")
         return int((fl & np.uint32(1)).sum())
 
-    def timed(self, rk, steps, warmup, barrier):
-        torch, dist, world, B, k = self.torch, self.dist, self.world, self.B, self.k
+    def timed(self, rk, steps, warmup, barrier, batch=None):
+        torch, dist, world, k = self.torch, self.dist, self.world, self.k
+        B = self.B if batch is None else min(batch, self.B)
         nq_pool = self.queries.shape[0]
         batches = [self.queries[i * B:(i + 1) * B] for i in range(nq_pool // B)]
         for w in range(warmup):
@@ -620,14 +621,16 @@ def main():
             try:
                 e2 = make_engine(other)
                 gt2 = e2.ground_truth()
-                rk2, rec2, slog2 = e2.sweep(gt2, SWEEP)
+                # bounded: the sweep stops at rerankK = 900 and the rate is taken on 2 steps of <= 65 536 queries (a
+                # distribution 32-byte codes cannot rank would otherwise spend minutes in its slowest configuration)
+                rk2, rec2, slog2 = e2.sweep(gt2, [r for r in SWEEP if r <= 900])
                 log(f"[{other}] recall sweep: {slog2}")
-                t2 = e2.timed(rk2, min(args.steps, 5), 1, barrier)
-                by2 = algorithmic_bytes(t2["visited"], t2["reranked"], t2["expanded"], t2["total_queries"], min(args.steps, 5), pq_M, d, R, fused)
+                t2 = e2.timed(rk2, 2, 1, barrier, batch=65536)
+                by2 = algorithmic_bytes(t2["visited"], t2["reranked"], t2["expanded"], t2["total_queries"], 2, pq_M, d, R, fused)
                 rows.append({"distribution": other, "rerankK": rk2, "recall_at_10": round(rec2, 4),
                              "recall_target_met": bool(rec2 >= 0.95), "qps": round(t2["qps"], 1),
-                             "roofline_frac": round(by2 / min(args.steps, 5) / (t2["kernel_avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                             "recall_sweep_tail": slog2[-3:]})
+                             "roofline_frac": round(by2 / 2 / (t2["kernel_avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             "queries_per_step": min(65536, B), "recall_sweep_tail": slog2[-3:]})
                 e2.close()
                 del e2, gt2
                 torch.cuda.empty_cache()

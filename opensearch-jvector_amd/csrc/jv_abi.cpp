@@ -494,8 +494,10 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
                            (ix->dev.R * ix->dev.pq_lanes + JV_WAVE - 1) / JV_WAVE <= ix->dev.pq_lanes;
     // headline path: the persistent LDS-pool kernel (jv_kernels_pqp.hip): no filter, threshold <= 0; LDS = look-up table +
     // pool of rk + 64 boundary ties + one expansion's R new keys (+ 1 sentinel slot); the expansion log lives in HBM
+    // (pools of <= 256 entries stay on the round-1 kernel below: its 256-entry variant keeps masks and pivots in scalar
+    //  registers and measured 1.5-3 % faster there; its cost grows with the pool, this kernel's does not)
     if (!force_big && !filtered && g.pool && pqf_index && rk + 64 + ix->dev.R <= jvk_pqp_max_entries() && OPT(ix, OPT_NO_PQF) == 0 &&
-        OPT(ix, OPT_NO_PQP) == 0) {
+        OPT(ix, OPT_NO_PQP) == 0 && (rk + 64 + ix->dev.R > 256 || OPT(ix, OPT_LUTR_MIN_QUERIES) == 0)) {
         JvSearchArgs ap = a;
         const int lut_b = ix->dev.pq_M * 256 * 4;
         const int qc_b = ix->dev.nch * 64 * 4;
@@ -509,7 +511,11 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
         // Table in registers (8 resident queries per CU, +34 % throughput at rerankK = 1 200, but 1.7x the latency of
         // one query): only when the launch has more queries than the LDS-table variant could keep resident anyway
         const int64_t lutr_min = OPT(ix, OPT_LUTR_MIN_QUERIES) >= 0 ? OPT(ix, OPT_LUTR_MIN_QUERIES) : 4 * (int64_t)ix->cu_count;
-        const int lutr = (OPT(ix, OPT_NO_LUTR) == 0 && jvk_pqp_lutr_ok(&ix->dev, ap.cand_cap) && nq > lutr_min) ? 1 : 0;
+        // ... and only where the LDS-table variant drops below 4 resident queries per CU (measured: at 4 per CU it is the
+        // faster one, at 3 per CU the register variant wins by a third)
+        const int lds_table_variant = ((std::max(lut_b, rerank_b) + 15) & ~15) + (ap.cand_cap + 1) * 8;
+        const bool crowded = kMaxLds / std::max(1, lds_table_variant) < 4 || OPT(ix, OPT_LUTR_MIN_QUERIES) == 0;
+        const int lutr = (OPT(ix, OPT_NO_LUTR) == 0 && jvk_pqp_lutr_ok(&ix->dev, ap.cand_cap) && nq > lutr_min && crowded) ? 1 : 0;
         int lds;
         if (lutr) {
             // table in registers: LDS = the pool while searching, one hash set afterwards (>= 4 096 slots), then the
