@@ -81,7 +81,7 @@ int fail(int code, const char* fmt, ...) {
 //   filter_cache                         device-resident doc-filter bitsets kept per index (0 = off)
 //   lutr_min_queries                     launches with more queries keep the PQ look-up table in registers (-1 = 4 per CU)
 //   dbg_ptr                              diagnostic build only
-enum OptId { OPT_LDS_VISITED_SLOTS, OPT_LDS_CANDIDATES, OPT_FORCE_BIG, OPT_FORCE_GENERAL, OPT_NO_ESCALATION, OPT_DBG_PTR, OPT_NO_PQF, OPT_NO_PQP, OPT_NO_LUTR, OPT_LUTR_MIN_QUERIES, OPT_PQF_ONLY, OPT_SPILL_TABLES, OPT_SPILL_SLOTS, OPT_BIG_BLOCKS, OPT_BIG_CAND_CAP, OPT_BIG_BUDGET_MB, OPT_COMBINE, OPT_COMBINE_LEADERS, OPT_COMBINE_MAX_BATCH, OPT_MAX_CONTEXTS, OPT_FILTER_CACHE, OPT_COUNT };
+enum OptId { OPT_LDS_VISITED_SLOTS, OPT_LDS_CANDIDATES, OPT_FORCE_BIG, OPT_FORCE_GENERAL, OPT_NO_ESCALATION, OPT_DBG_PTR, OPT_NO_PQF, OPT_NO_PQP, OPT_NO_LUTR, OPT_LUTR_MIN_QUERIES, OPT_PQP_BLOCKS_PER_CU, OPT_PQF_ONLY, OPT_SPILL_TABLES, OPT_SPILL_SLOTS, OPT_BIG_BLOCKS, OPT_BIG_CAND_CAP, OPT_BIG_BUDGET_MB, OPT_COMBINE, OPT_COMBINE_LEADERS, OPT_COMBINE_MAX_BATCH, OPT_MAX_CONTEXTS, OPT_FILTER_CACHE, OPT_COUNT };
 struct OptName { const char* name; int64_t def; };
 const OptName kOptNames[OPT_COUNT] = {
     {"lds_visited_slots", 0},
@@ -94,6 +94,7 @@ const OptName kOptNames[OPT_COUNT] = {
     {"no_pqp", 0},
     {"no_lutr", 0},
     {"lutr_min_queries", -1},
+    {"pqp_blocks_per_cu", 0},
     {"pqf_only", 0},
     {"spill_tables", 512},
     {"spill_slots", 8192},
@@ -513,7 +514,7 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
         const int64_t lutr_min = OPT(ix, OPT_LUTR_MIN_QUERIES) >= 0 ? OPT(ix, OPT_LUTR_MIN_QUERIES) : 4 * (int64_t)ix->cu_count;
         // ... and only where the LDS-table variant drops below 4 resident queries per CU (measured: at 4 per CU it is the
         // faster one, at 3 per CU the register variant wins by a third)
-        const int lds_table_variant = ((std::max(lut_b, rerank_b) + 15) & ~15) + (ap.cand_cap + 1) * 8;
+        const int lds_table_variant = ((std::max(lut_b, rerank_b) + 15) & ~15) + (ap.cand_cap + 1) * 8 + 784;
         const bool crowded = kMaxLds / std::max(1, lds_table_variant) < 4 || OPT(ix, OPT_LUTR_MIN_QUERIES) == 0;
         const int lutr = (OPT(ix, OPT_NO_LUTR) == 0 && jvk_pqp_lutr_ok(&ix->dev, ap.cand_cap) && nq > lutr_min && crowded) ? 1 : 0;
         int lds;
@@ -523,17 +524,20 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
             const int pool_b = (ap.cand_cap + 1) * 8;
             ap.pqp_pool_off = 0;
             ap.pqp_qc_off = 0;
-            lds = std::max(std::max(pool_b, qc_b), std::max(16384, qc_b + JV_TODO * 8 + pool_b));
+            ap.pqp_scratch_off = (pool_b + 15) & ~15;
+            lds = std::max(std::max(ap.pqp_scratch_off + 768, qc_b), std::max(16384, qc_b + JV_TODO * 8 + pool_b));
         } else {
             ap.pqp_pool_off = (std::max(lut_b, rerank_b) + 15) & ~15;
-            lds = ap.pqp_pool_off + (ap.cand_cap + 1) * 8;
+            ap.pqp_scratch_off = (ap.pqp_pool_off + (ap.cand_cap + 1) * 8 + 15) & ~15;
+            lds = ap.pqp_scratch_off + 768;
             ap.pqp_qc_off = alias ? lut_b - qc_b : ((lds + 15) & ~15);
             if (!alias) lds = ap.pqp_qc_off + qc_b;
         }
         lds = (lds + 15) & ~15;
         ap.pqp_lds_bytes = lds;
         if (lds <= kMaxLds) {
-            const int per_cu = jvk_pqp_blocks_per_cu(&ix->dev, ap.cand_cap, lds, lutr);
+            int per_cu = jvk_pqp_blocks_per_cu(&ix->dev, ap.cand_cap, lds, lutr);
+            if (OPT(ix, OPT_PQP_BLOCKS_PER_CU) > 0) per_cu = (int)std::min<int64_t>(per_cu, OPT(ix, OPT_PQP_BLOCKS_PER_CU));  // diagnostics
             int blocks = ix->cu_count * per_cu;
             if (blocks > nq) blocks = nq;
             const size_t need = (size_t)blocks * (size_t)ap.pqp_log_cap;

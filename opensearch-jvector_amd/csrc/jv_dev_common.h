@@ -20,10 +20,10 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define STAMP_DIRECT(i) { unsigned long long t_ = clock64(); if (a.dbg && lane == 0) atomicAdd((unsigned long long*)a.dbg + (i), t_ - st_last); st_last = t_; }
 #else
 #define STAMP_DECL
-#define STAMP(i)
-#define STAMP_FLUSH
-#define STAMP_COUNT(i, v)
-#define STAMP_DIRECT(i)
+#define STAMP(i) {}
+#define STAMP_FLUSH {}
+#define STAMP_COUNT(i, v) {}
+#define STAMP_DIRECT(i) {}
 #endif
 
 #define KEY_MIN ((int64_t)0x8000000000000000ll)

@@ -86,6 +86,7 @@ struct JvSearchArgs {
     int32_t pqp_log_cap;
     int32_t pqp_qc_off;      // LDS byte offset of the centred query during the LUT build
     int32_t pqp_pool_off;    // LDS byte offset of the pool (jv_kernels_pqp.hip)
+    int32_t pqp_scratch_off; // LDS byte offset of the 768-byte merge scratch (kept keys + ranks of one expansion)
     int32_t pqp_lds_bytes;   // dynamic LDS bytes of the launch (register-LUT variant: the visited-count hash set uses all of it)
     int32_t* pqp_counter;    // query dequeue counter (zeroed per call)
 };

@@ -123,21 +123,36 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
     const bool full16 = (M & 15) == 0;
     auto adc_regs = [&](const u32x4 cw) -> float {  // this lane's 16 subspaces (chunk my_c), summed left to right like adc_chunk
         float sum = 0.0f;
+        // four look-ups (32 ds_bpermute) are issued back to back before the first result is consumed: one LDS round trip
+        // per group instead of one per register (the scheduler otherwise serialises them to save registers)
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const int w = (int)cw[i >> 2];
-            const int sh = (i & 3) * 8;
-            const int addr = (int)(((uint32_t)w >> sh) & 0xFFu);       // ds_bpermute reads lane (addr >> 2) & 63 = code >> 2
-            const int m0 = __builtin_amdgcn_sbfe(w, sh, 1), m1 = __builtin_amdgcn_sbfe(w, sh + 1, 1);  // -1 / 0: code bits 0, 1
-            int x[4];
+        for (int g4 = 0; g4 < 16; g4 += 4) {
+            int t0[4][4], t1[4][4];
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int t0 = __builtin_amdgcn_ds_bpermute(addr, __float_as_int(lutr[LUTR ? i : 0][e]));
-                const int t1 = __builtin_amdgcn_ds_bpermute(addr, __float_as_int(lutr[LUTR ? 16 + i : 0][e]));
-                x[e] = my_c ? t1 : t0;
+            for (int ii = 0; ii < 4; ii++) {
+                const int i = g4 + ii;
+                const int w = (int)cw[i >> 2];
+                const int addr = (int)(((uint32_t)w >> ((i & 3) * 8)) & 0xFFu);  // ds_bpermute reads lane (addr >> 2) & 63 = code >> 2
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    t0[ii][e] = __builtin_amdgcn_ds_bpermute(addr, __float_as_int(lutr[LUTR ? i : 0][e]));
+                    t1[ii][e] = __builtin_amdgcn_ds_bpermute(addr, __float_as_int(lutr[LUTR ? 16 + i : 0][e]));
+                }
             }
-            const int s01 = (m0 & x[1]) | (~m0 & x[0]), s23 = (m0 & x[3]) | (~m0 & x[2]);
-            sum = sum + __int_as_float((m1 & s23) | (~m1 & s01));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ii = 0; ii < 4; ii++) {
+                const int i = g4 + ii;
+                const int w = (int)cw[i >> 2];
+                const int sh = (i & 3) * 8;
+                const int m0 = __builtin_amdgcn_sbfe(w, sh, 1), m1 = __builtin_amdgcn_sbfe(w, sh + 1, 1);  // -1 / 0: code bits 0, 1
+                int x[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) x[e] = my_c ? t1[ii][e] : t0[ii][e];
+                const int s01 = (m0 & x[1]) | (~m0 & x[0]), s23 = (m0 & x[3]) | (~m0 & x[2]);
+                sum = sum + __int_as_float((m1 & s23) | (~m1 & s01));
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         return sum;
     };
@@ -331,6 +346,8 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
         int nk = __popcll(km);
         STAMP_COUNT(8, __popcll(km))
         STAMP(3)  // boundary test + rank search + duplicate test
+        if (nk == 0) { STAMP_COUNT(9, 1) }
+        if (nk == 1) { STAMP_COUNT(10, 1) }
         if (nk > 0) {
             int rnew = 0, r_min, r_max;
             if (nk == 1) {
@@ -342,18 +359,30 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
                     if (pos < np && pos >= r_min) pool[pos + 1] = e;
                 }
             } else {
-                // rank among the kept new keys; the same neighbour twice in one adjacency row (malformed graph): keep one
-                const int vlo = (int)(uint32_t)(v & 0xFFFFFFFFll), vhi = (int)(v >> 32);
+                // Bursts of ~8 new keys are the norm when there are several.  The kept keys (and their ranks among the old
+                // entries) are compacted into a small LDS scratch, and every lane reads them back with wave-uniform
+                // (broadcast) reads: rank among the new keys, twins (the same neighbour twice in one adjacency row of a
+                // malformed graph: keep the first), and later the per-position shift counts — no scalar lane-by-lane loops.
+                int64_t* const sk = (int64_t*)(smem + a.pqp_scratch_off);  // [64] kept keys (R <= 64), lane order
+                int32_t* const sr = (int32_t*)(sk + 64);                    // [64] their ranks among the old entries
                 for (int attempt = 0; attempt < 2; attempt++) {
+                    const int my = __popcll(km & ((1ull << lane) - 1ull));
+                    if (keep) {
+                        sk[my] = v;
+                        sr[my] = rold;
+                    }
                     rnew = 0;
                     bool twin = false;
-                    for (unsigned long long m = km; m;) {
-                        const int j = __ffsll((long long)m) - 1;
-                        m &= m - 1ull;
-                        const int64_t kj = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(vhi, j) << 32) |
-                                                     (uint64_t)(uint32_t)__builtin_amdgcn_readlane(vlo, j));
-                        rnew += kj > v ? 1 : 0;
-                        twin |= kj == v && j < lane;
+                    for (int j0 = 0; j0 < nk; j0 += 8) {
+                        int64_t kj[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) kj[u] = sk[min(j0 + u, 63)];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) {
+                            const bool in = j0 + u < nk;
+                            rnew += (in && kj[u] > v) ? 1 : 0;
+                            twin |= in && kj[u] == v && j0 + u < my;
+                        }
                     }
                     const unsigned long long km2 = __ballot(keep && !twin);
                     if (km2 == km) break;
@@ -365,6 +394,7 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
                 const int lane_last = __ffsll((long long)__ballot(keep && rnew == nk - 1)) - 1;  // smallest new key
                 r_min = __builtin_amdgcn_readlane(rold, lane_first);
                 r_max = __builtin_amdgcn_readlane(rold, lane_last);
+                STAMP(14)  // (diagnostic) ranks among the new keys
                 // in-place shift, from the last occupied chunk down to the chunk of the first insertion point: an old
                 // entry at position p moves up by the number of new keys that rank ahead of it
                 const int t_mixed = r_max >> 6;  // chunks above it shift uniformly by nk
@@ -374,10 +404,12 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
                     int cnt = nk;
                     if (t <= t_mixed) {
                         cnt = 0;
-                        for (unsigned long long m = km; m;) {
-                            const int j = __ffsll((long long)m) - 1;
-                            m &= m - 1ull;
-                            cnt += pos >= __builtin_amdgcn_readlane(rold, j) ? 1 : 0;
+                        for (int j0 = 0; j0 < nk; j0 += 8) {
+                            int rj[8];
+#pragma unroll
+                            for (int u = 0; u < 8; u++) rj[u] = sr[min(j0 + u, 63)];
+#pragma unroll
+                            for (int u = 0; u < 8; u++) cnt += (j0 + u < nk && pos >= rj[u]) ? 1 : 0;
                         }
                     }
                     if (pos < np && cnt > 0) pool[pos + cnt] = e;
@@ -439,8 +471,9 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
         const uint32_t vmask = (uint32_t)vslots - 1u;
         const int vshift = 32 - (31 - __clz(vslots));
         const int vlimit = (vslots / 16) * 13;
+        // ~3.1 distinct neighbours per expansion are typical; a class that overflows its table doubles `parts` and starts over
         int parts = 1;
-        while (parts < 64 && (long long)nexp * 6 > (long long)vlimit * parts) parts <<= 1;
+        while (parts < 64 && (long long)nexp * 7 > (long long)vlimit * parts * 2) parts <<= 1;
         // the log was written by lane 0 and is read back by every lane: drain the stores, read with L1-bypassing loads
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_waitcnt(0);

@@ -23,6 +23,9 @@ for fused in (1,):
                                     pq_codebooks=pq["codebooks"], pq_centroid=pq["centroid"], pq_codes_ptr=pq["codes"].data_ptr(),
                                     borrow=True, extra_flags=(b.DESC_FUSED_ADC if fused else 0))
     ix = b.GpuIndex(desc=desc, keepalive=keep, flags=b.DESC_BORROW)
+    for key, val in os.environ.items():   # JV_OPT_<name>=<int> -> per-index option
+        if key.startswith("JV_OPT_"):
+            ix.set_option(key[len("JV_OPT_"):].lower(), int(val))
     dbg = torch.zeros(16, dtype=torch.int64, device=dev)
     o = [torch.empty((B, 10), dtype=torch.int32, device=dev), torch.empty((B, 10), dtype=torch.int32, device=dev),
          torch.empty((B, 10), dtype=torch.float32, device=dev), torch.empty((B,), dtype=torch.int32, device=dev),
@@ -45,6 +48,7 @@ for fused in (1,):
     print(f"fused={fused} rk={rk}: {B / dt:.0f} QPS (stamped build), expansions/query {st[2]:.1f}, visited/query {st[0]:.1f}")
     for i, nme in enumerate(names):
         print(f"   {nme:36s} {100 * cyc[i] / cyc.sum():5.1f} %   {cyc[i] / ne:8.0f} cycles/expansion")
+    print(f"   nk == 0: {v[9] / ne:.3f}, nk == 1: {v[10] / ne:.3f} of the expansions; ranks-among-new-keys part of the insert phase: {v[14] / ne:.0f} cycles/expansion")
     print(f"   per expansion: candidates past the boundary {v[8] / ne:.2f}, already-in-pool (chunk-first) {v[9] / ne:.2f}, already-in-pool {v[10] / ne:.2f}, "
           f"inserts {v[11] / ne:.2f}, whole chunks shifted per insert {v[12] / max(v[11], 1):.2f}")
     ix.close()
