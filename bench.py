@@ -550,7 +550,9 @@ def main():
         except Exception as e:  # pragma: no cover - reported, never fatal for the headline number
             caller_rows = f"unavailable: {e!r}"
 
-    main_kernel = "jv_search_pqf_kernel" if fused else "jv_search_lds_kernel"
+    # the kernel that carries the step: pools of <= 256 entries run on jv_search_pqf_kernel, larger ones on the persistent
+    # jv_search_pqp_kernel (csrc/jv_abi.cpp enqueue_batch), exact indexes on jv_search_lds_kernel
+    main_kernel = ("jv_search_pqp_kernel" if rk + 64 + R > 256 else "jv_search_pqf_kernel") if fused else "jv_search_lds_kernel"
     recall_txt = "nan" if chosen_recall != chosen_recall else f"{chosen_recall:.4f}"
     metric = "queries/sec at recall@10>=0.95" if target_met in (True, None) else \
         f"queries/sec at recall@10={recall_txt} (target 0.95 NOT reached by any rerankK of the sweep)"

@@ -30,7 +30,7 @@ hipError_t jvk_build_fused(const uint8_t* codes, const int32_t* adj, uint8_t* fu
 hipError_t jvk_launch_search_lds(const JvIndexDev* ix, const JvSearchArgs* a, int pq, int pool, int tag, int lds_bytes, hipStream_t s);
 hipError_t jvk_launch_search_pqf(const JvIndexDev* ix, const JvSearchArgs* a, int lds_bytes, hipStream_t s);
 hipError_t jvk_launch_search_big(const JvIndexDev* ix, const JvSearchArgs* a, int pq, int blocks, int lds_bytes,
-                                 int force_all, hipStream_t s);
+                                 int force_all, int qlds, hipStream_t s);
 hipError_t jvk_launch_score_ordinals(const JvIndexDev* ix, const float* d_query, const int32_t* d_ordinals,
                                      int count, float* d_out, hipStream_t s);
 hipError_t jvk_launch_merge_topk(const int32_t* d_docs, const float* d_scores, int nq, int lists, int k,
@@ -625,7 +625,19 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
         a.big_cand_cap = my_cap;
         a.res_cap = (rk + 1) & ~1;  // the rung runs the two-queue form: rerankK results, the rest of my_cap are candidates
         HIPCHK(hipStreamWaitEvent(stream, sc.last_use, 0));
-        HIPCHK(jvk_launch_search_big(&ix->dev, &a, pq ? 1 : 0, my_blocks, g.lds_big, force_big ? 1 : 0, stream));
+        // first with both queues in LDS (every slot the workgroup's LDS has left; the visited set is the HBM bitset) ...
+        const int fixed_lds = (g.lds_big + 15) & ~15;
+        const int qslots = (kMaxLds - fixed_lds) / 8;
+        if (qslots >= a.res_cap + 4 * rk + 256 && OPT(ix, OPT_NO_ESCALATION) == 0) {
+            JvSearchArgs aq = a;
+            aq.cand_cap = qslots - aq.res_cap;
+            aq.work_counter = c->work_counter + 7;
+            HIPCHK(jvk_launch_search_big(&ix->dev, &aq, pq ? 1 : 0, my_blocks, kMaxLds, force_big ? 1 : 0, 1, stream));
+            // ... then, for what outgrew them (and for the rerankFloor corner that needs the admission log), in HBM
+            HIPCHK(jvk_launch_search_big(&ix->dev, &a, pq ? 1 : 0, my_blocks, g.lds_big, 0, 0, stream));
+        } else {
+            HIPCHK(jvk_launch_search_big(&ix->dev, &a, pq ? 1 : 0, my_blocks, g.lds_big, force_big ? 1 : 0, 0, stream));
+        }
         HIPCHK(hipEventRecord(sc.last_use, stream));
     }
     return JV_OK;

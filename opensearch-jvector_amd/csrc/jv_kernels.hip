@@ -25,7 +25,10 @@
 
 // POOL: level 0 runs on one sorted pool (exact when there is no filter and threshold <= 0, ties included:
 // DESIGN.md "Single-pool search"); otherwise the two-queue form of jvector is executed literally.
-template <bool PQ, bool BIG, bool POOL, int NCHT>
+// BIG: visited set = bitset in HBM scratch (exact whatever the search touches).  QLDS (with BIG): both queues still live
+// in LDS (as many candidate slots as the workgroup's LDS holds) — a pop is an arg-max scan over the queue, so on-chip
+// queues are ~20x faster than the HBM ones; only a query that outgrows them as well takes the HBM-queue form.
+template <bool PQ, bool BIG, bool POOL, int NCHT, bool QLDS = false>
 __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, unsigned char* smem,
                            int64_t* big_cand, uint32_t* big_bits) {
     const int lane = threadIdx.x;
@@ -63,7 +66,7 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
     int64_t* cand;
     uint32_t* hash = nullptr;
     int cand_cap;
-    if (BIG) {
+    if (BIG && !QLDS) {
         res = big_cand;
         cand = big_cand + a.res_cap;
         cand_cap = a.big_cand_cap - a.res_cap;
@@ -218,7 +221,7 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
             }
             // addTopCandidate: a full queue only admits a STRICTLY better score
             if (acc && sc >= thr) {
-                if (BIG && PQ && lvl == 0) {  // call log for replay_first_best (top of the candidate area, like the hand-back list)
+                if (BIG && !QLDS && PQ && lvl == 0) {  // call log for replay_first_best (top of the candidate area, like the hand-back list)
                     if (st.ncand + st.nhand + 1 > cand_cap) {
                         st.overflow = true;
                         break;
@@ -582,8 +585,8 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
             }
             if (ties > 1) {
                 // several results share the best approximate score: jvector's pick is the first in its heap array
-                if (!BIG) {
-                    st.overflow = true;  // -> the HBM-scratch rung replays the heap
+                if (!BIG || QLDS) {
+                    st.overflow = true;  // -> the HBM-queue rung replays the heap
                 } else if (st.nhand + rk + 2 > cand_cap) {
                     st.overflow = true;
                 } else {
@@ -609,7 +612,7 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
                 s[2] = st.expanded;
                 s[3] = st.expanded_base;
             } else {
-                a.out_flags[qi] = BIG ? (int32_t)(JV_FLAG_FAILED | JV_FLAG_BIG) : (int32_t)JV_FLAG_OVERFLOW;
+                a.out_flags[qi] = (BIG && !QLDS) ? (int32_t)(JV_FLAG_FAILED | JV_FLAG_BIG) : (int32_t)JV_FLAG_OVERFLOW;
             }
             a.out_count[qi] = 0;
         }
@@ -1453,7 +1456,7 @@ __global__ __launch_bounds__(JV_WAVE) void jv_build_search_kernel(const JvIndexD
 
 // Big path: queues and visited bitset in HBM scratch; each resident workgroup dequeues the queries the
 // fast path flagged as overflowed.  Exact in all cases the fast path cannot hold on chip.
-template <bool PQ, int NCHT>
+template <bool PQ, int NCHT, bool QLDS = false>
 __global__ __launch_bounds__(JV_WAVE) void jv_search_big_kernel(const JvIndexDev ix, const JvSearchArgs a,
                                                                  const int force_all) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1472,7 +1475,7 @@ __global__ __launch_bounds__(JV_WAVE) void jv_search_big_kernel(const JvIndexDev
         while (m) {
             const int j = __ffsll((long long)m) - 1;
             m &= m - 1ull;
-            search_one<PQ, true, false, NCHT>(ix, a, base + j, smem, my_cand, my_bits);
+            search_one<PQ, true, false, NCHT, QLDS>(ix, a, base + j, smem, my_cand, my_bits);
             __syncthreads();
         }
     }
@@ -1609,6 +1612,8 @@ static const lds_kernel_t g_pqf_kernels[3][3][4] = {{JV_PQF_ROW(4, 1, false), JV
 // [FAST][pool size][nch slot]
 static const lds_kernel_t g_pqff_kernels[2][2][4] = {{JV_PQFF_ROW(8, false), JV_PQFF_ROW(16, false)}, {JV_PQFF_ROW(8, true), JV_PQFF_ROW(16, true)}};
 static const big_kernel_t g_big_kernels[2][4] = {JV_ROW(jv_search_big_kernel, false), JV_ROW(jv_search_big_kernel, true)};
+#define JV_BIGQ_ROW(PQ) { jv_search_big_kernel<PQ, 0, true>, jv_search_big_kernel<PQ, 2, true>, jv_search_big_kernel<PQ, 12, true>, jv_search_big_kernel<PQ, 24, true> }
+static const big_kernel_t g_bigq_kernels[2][4] = {JV_BIGQ_ROW(false), JV_BIGQ_ROW(true)};  // queues in LDS, visited bitset in HBM
 
 static int nch_slot(const JvIndexDev* ix) {
     if (ix->stride != ix->nch * 64) return 0;
@@ -1635,6 +1640,8 @@ extern "C" hipError_t jvk_set_max_lds(int bytes) {
                     e = hipFuncSetAttribute((const void*)g_pqff_kernels[v >> 1][v & 1][s], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             if (e == hipSuccess)
                 e = hipFuncSetAttribute((const void*)g_big_kernels[a][s], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute((const void*)g_bigq_kernels[a][s], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             if (e != hipSuccess) return e;
         }
     }
@@ -1675,10 +1682,11 @@ extern "C" hipError_t jvk_launch_search_lds(const JvIndexDev* ix, const JvSearch
     return hipGetLastError();
 }
 
+// qlds: 1 = queues in LDS (a->res_cap / a->cand_cap entries after the fixed part), visited bitset in HBM
 extern "C" hipError_t jvk_launch_search_big(const JvIndexDev* ix, const JvSearchArgs* a, int pq, int blocks,
-                                            int lds_bytes, int force_all, hipStream_t stream) {
+                                            int lds_bytes, int force_all, int qlds, hipStream_t stream) {
     if (a->nq <= 0) return hipSuccess;
-    g_big_kernels[pq ? 1 : 0][nch_slot(ix)]<<<blocks, JV_WAVE, lds_bytes, stream>>>(*ix, *a, force_all);
+    (qlds ? g_bigq_kernels : g_big_kernels)[pq ? 1 : 0][nch_slot(ix)]<<<blocks, JV_WAVE, lds_bytes, stream>>>(*ix, *a, force_all);
     return hipGetLastError();
 }
 

@@ -94,6 +94,7 @@ def test_per_query_status_one_bad_query_does_not_fail_its_batch(pkg, pyoracle, s
     gpu = b.GpuIndex(ix)
     orc = pyoracle.Oracle(b, ix)
     gpu.set_option("force_big_path", 1)
+    gpu.set_option("no_escalation", 1)      # straight to the HBM-queue form (the LDS-queue rung would hold these queries)
     rk = 40
     for cap in range(200, 1600, 20):   # find a queue size that part of the batch overflows and part does not
         gpu.set_option("big_cand_cap", cap)

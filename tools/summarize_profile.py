@@ -22,7 +22,7 @@ def main(src, name):
             shutil.copy(os.path.join(src, f), os.path.join(dst, f))
     bench = json.loads(open(os.path.join(src, "bench_under_trace.json")).read().strip().splitlines()[-1])
     steps, warm, B = bench["steps"], bench["warmup"], bench["config"]["queries_per_step"]
-    grid = str(B * 64)
+    grid = str(B * 64)   # one workgroup per query (jv_search_lds / pqf); the persistent pqp kernel launches a resident grid instead
     lines = [f"# rocprofv3 summary — {name}", "",
              f"command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --profile-mode "
              f"--workload {bench['config']['workload'].split(':')[0]} --steps {steps} --warmup {warm} --rerankk {bench['config']['rerankK']}`",
@@ -49,7 +49,7 @@ def main(src, name):
         if not os.path.exists(p):
             continue
         vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(p))
-                if main_kernel in r["Kernel_Name"] and r["Grid_Size"] == grid]
+                if main_kernel in r["Kernel_Name"] and (r["Grid_Size"] == grid or "pqp" in main_kernel)]
         vals = vals[-steps:]
         if vals:
             traffic[cname] = sum(vals) / len(vals)
