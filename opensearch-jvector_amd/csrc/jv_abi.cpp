@@ -498,7 +498,7 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
     // (pools of <= 256 entries stay on the round-1 kernel below: its 256-entry variant keeps masks and pivots in scalar
     //  registers and measured 1.5-3 % faster there; its cost grows with the pool, this kernel's does not)
     if (!force_big && !filtered && g.pool && pqf_index && rk + 64 + ix->dev.R <= jvk_pqp_max_entries() && OPT(ix, OPT_NO_PQF) == 0 &&
-        OPT(ix, OPT_NO_PQP) == 0 && (rk + 64 + ix->dev.R > 256 || OPT(ix, OPT_LUTR_MIN_QUERIES) == 0)) {
+        OPT(ix, OPT_NO_PQP) == 0 && (rk + 64 + ix->dev.R > 256 || OPT(ix, OPT_LUTR_MIN_QUERIES) == 0) && ix->dev.n < (1 << 30)) {
         JvSearchArgs ap = a;
         const int lut_b = ix->dev.pq_M * 256 * 4;
         const int qc_b = ix->dev.nch * 64 * 4;
@@ -517,30 +517,46 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
         const int lds_table_variant = ((std::max(lut_b, rerank_b) + 15) & ~15) + (ap.cand_cap + 1) * 8 + 784;
         const bool crowded = kMaxLds / std::max(1, lds_table_variant) < 4 || OPT(ix, OPT_LUTR_MIN_QUERIES) == 0;
         const int lutr = (OPT(ix, OPT_NO_LUTR) == 0 && jvk_pqp_lutr_ok(&ix->dev, ap.cand_cap) && nq > lutr_min && crowded) ? 1 : 0;
-        int lds;
-        if (lutr) {
-            // table in registers: LDS = the pool while searching, one hash set afterwards (>= 4 096 slots), then the
-            // rerank scratch with the pool written back behind the query and todo lists
-            const int pool_b = (ap.cand_cap + 1) * 8;
-            ap.pqp_pool_off = 0;
-            ap.pqp_qc_off = 0;
-            ap.pqp_scratch_off = (pool_b + 15) & ~15;
-            lds = std::max(std::max(ap.pqp_scratch_off + 768, qc_b), std::max(16384, qc_b + JV_TODO * 8 + pool_b));
-        } else {
-            ap.pqp_pool_off = (std::max(lut_b, rerank_b) + 15) & ~15;
-            ap.pqp_scratch_off = (ap.pqp_pool_off + (ap.cand_cap + 1) * 8 + 15) & ~15;
-            lds = ap.pqp_scratch_off + 768;
-            ap.pqp_qc_off = alias ? lut_b - qc_b : ((lds + 15) & ~15);
-            if (!alias) lds = ap.pqp_qc_off + qc_b;
-        }
-        lds = (lds + 15) & ~15;
-        ap.pqp_lds_bytes = lds;
+        // LDS plan of one launch: offsets into the workgroup's LDS for a pool of x.cand_cap entries
+        auto plan = [&](JvSearchArgs& x, bool regs) {
+            int lds;
+            const int pool_b = (x.cand_cap + 1) * 8;
+            if (regs) {
+                // table in registers: LDS = the pool while searching, one hash set afterwards (>= 4 096 slots), then the
+                // rerank scratch with the pool written back behind the query and todo lists
+                x.pqp_pool_off = 0;
+                x.pqp_qc_off = 0;
+                x.pqp_scratch_off = (pool_b + 15) & ~15;
+                lds = std::max(std::max(x.pqp_scratch_off + 768, qc_b), std::max(16384, qc_b + JV_TODO * 8 + pool_b));
+            } else {
+                x.pqp_pool_off = (std::max(lut_b, rerank_b) + 15) & ~15;
+                x.pqp_scratch_off = (x.pqp_pool_off + pool_b + 15) & ~15;
+                lds = x.pqp_scratch_off + 768;
+                x.pqp_qc_off = alias ? lut_b - qc_b : ((lds + 15) & ~15);
+                if (!alias) lds = x.pqp_qc_off + qc_b;
+            }
+            lds = (lds + 15) & ~15;
+            x.pqp_lds_bytes = lds;
+            return lds;
+        };
+        const int lds = plan(ap, lutr != 0);
+        // second launch for what outgrows the first (more than 63 ties at the rerankK boundary, a longer expansion log):
+        // table in LDS, as many tie slots as the largest pool class allows, 4x the log; walks the flag array
+        JvSearchArgs ap2 = ap;
+        ap2.cand_cap = std::min(jvk_pqp_max_entries(), std::max(2 * ap.cand_cap, rk + ix->dev.R + 1024));
+        ap2.pqp_log_cap = (12 * rk + 1024 + 3) & ~3;
+        ap2.retry_only = 1;
+        ap2.retry_counter = c->work_counter + 5;
+        const int lds2 = plan(ap2, false);
+        const bool second = lds2 <= kMaxLds && ap2.cand_cap > ap.cand_cap && OPT(ix, OPT_PQF_ONLY) == 0;
         if (lds <= kMaxLds) {
             int per_cu = jvk_pqp_blocks_per_cu(&ix->dev, ap.cand_cap, lds, lutr);
             if (OPT(ix, OPT_PQP_BLOCKS_PER_CU) > 0) per_cu = (int)std::min<int64_t>(per_cu, OPT(ix, OPT_PQP_BLOCKS_PER_CU));  // diagnostics
             int blocks = ix->cu_count * per_cu;
             if (blocks > nq) blocks = nq;
-            const size_t need = (size_t)blocks * (size_t)ap.pqp_log_cap;
+            const int blocks2 = std::min(ix->cu_count, (nq + 7) / 8);
+            size_t need = (size_t)blocks * (size_t)ap.pqp_log_cap;
+            if (second) need = std::max(need, (size_t)blocks2 * (size_t)ap2.pqp_log_cap);
             if (need > c->pqp_log_ints) {
                 if (c->pqp_log) HIPCHK(hipFree(c->pqp_log));
                 c->pqp_log = nullptr;
@@ -551,6 +567,10 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
             ap.pqp_log = c->pqp_log;
             ap.pqp_counter = c->work_counter + 6;
             HIPCHK(jvk_launch_search_pqp(&ix->dev, &ap, lds, blocks, lutr, stream));
+            if (second) {
+                ap2.pqp_log = c->pqp_log;
+                HIPCHK(jvk_launch_search_pqp(&ix->dev, &ap2, lds2, blocks2, 0, stream));
+            }
             pqf = true;
         }
     }

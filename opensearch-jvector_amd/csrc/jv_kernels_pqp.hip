@@ -25,7 +25,20 @@
 typedef int i32x32 __attribute__((ext_vector_type(32)));
 
 __device__ __forceinline__ float hi_score(int hi) { return __int_as_float(hi ^ ((hi >> 31) & 0x7fffffff)); }
-__device__ __forceinline__ int lo_node(int lo) { return (int)((~((uint32_t)lo >> 1)) & 0x7FFFFFFFu); }
+// pool keys of this kernel (n < 2^30): [63:32] sortable score | [31:2] ~node | bit 1 "not rejected" | bit 0 "not expanded yet".
+// (A fresh key has both low bits set, so whatever entry the same node already has in the pool ranks at or behind the fresh
+// key: the duplicate test finds it inside the window the rank search ends on.)
+// The order between two different nodes is NodeQueue's (score desc, ordinal asc); the two low bits belong to the entry.
+// "rejected" = jvector's strict admission (GraphSearcher.addTopCandidate): a popped candidate whose score merely EQUALS the
+// worst result of a full result queue is expanded but not admitted.  Such an entry stays in the pool (re-encounters must
+// still recognise the node) but is taken out before the results are read.  All rejected entries tie with the boundary
+// score, so they neither move the boundary nor survive its next rise.
+__device__ __forceinline__ int64_t pqp_key(float score, int node) {
+    int32_t b = __float_as_int(score);
+    int32_t s = b ^ ((b >> 31) & 0x7fffffff);
+    return (int64_t)(((uint64_t)(uint32_t)s << 32) | ((uint64_t)((uint32_t)(~node) & 0x3FFFFFFFu) << 2) | 3ull);
+}
+__device__ __forceinline__ int lo_node(int lo) { return (int)((~((uint32_t)lo >> 2)) & 0x3FFFFFFFu); }
 
 // one level of the per-lane rank search: FAN - 1 pivots at lo + k * BLK + BLK - 1; entries are sorted descending and
 // slots beyond the pool hold the minimum key, so "pivot > v" is monotone and needs no bound check
@@ -179,6 +192,7 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
     for (int i = lane; i <= cap; i += JV_WAVE) pool[i] = KEY_MIN;
     int np = 0, nexp = 0, expanded = 0, lo_un = 0;
     int why = 0;
+    int nrej = 0;         // rejected entries in the pool (all at the boundary score)
     float bscore = 0.0f;  // score of the rk-th best entry once np >= rk
     {
         const int ep = ix.entry;
@@ -186,7 +200,7 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
         if (lane < lpn && my_chunk) cw = *(const u32x4*)(ix.pq_codes + (size_t)ep * cs + my_c * 16);
         float s = adc_score(cw, lane < lpn && my_chunk);
         s = __shfl(s, 0, JV_WAVE);
-        if (lane == 0) pool[0] = make_pool_key(s, ep);
+        if (lane == 0) pool[0] = pqp_key(s, ep);
         np = 1;
         if (rk <= 1) bscore = s;
     }
@@ -229,9 +243,12 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
             why = 1;
             break;
         }
-        // strict-admission tie (DESIGN.md "Single-pool search"): the expanded entries scoring >= the candidate already
-        // fill the result queue and the candidate ranks inside the top rerankK -> the two-queue form decides
-        if (expanded >= rk && idx < rk) {
+        // strict admission (DESIGN.md "Single-pool search"): when the ADMITTED entries scoring >= the candidate already fill
+        // the result queue (the worst result ties with the candidate), jvector expands the candidate without admitting
+        // it.  Admitted entries scoring >= sc = everything ahead of the candidate (all expanded) + the expanded entries of
+        // its equal-score run behind it, minus the rejected ones (all of which tie with the boundary = sc here).
+        bool reject = false;
+        if (expanded >= rk && idx < rk + nrej) {
             int ge = idx;
             int64_t ee = e1;
             for (int tt = t1;;) {
@@ -243,10 +260,8 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
                 if (!(eq >> 63) || (tt << 6) >= np) break;  // the equal-score run ends inside this chunk
                 ee = pool[min((tt << 6) + lane, cap)];
             }
-            if (ge >= rk) {
-                why = 5;
-                break;
-            }
+            if (np >= rk && sc == bscore) ge -= nrej;
+            reject = ge >= rk;
         }
         const int c = lo_node(pk_lo);
         int nnp[NP];
@@ -291,7 +306,8 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
             break;
         }
         // mark the entry expanded; log the node
-        if (lane == b1) ((int*)pool)[2 * idx] = pk_lo & ~1;
+        if (lane == b1) ((int*)pool)[2 * idx] = pk_lo & (reject ? ~3 : ~1);
+        nrej += reject ? 1 : 0;
         if (lane == 0) explog[nexp] = c;
         nexp++;
         lo_un = idx + 1;
@@ -318,7 +334,7 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
         STAMP(2)  // ADC + prefetch issue
         bool keep = nn >= 0 && my_c < npass;
         if (np >= rk && score < bscore) keep = false;  // below the boundary for good
-        const int64_t v = make_pool_key(score, nn);
+        const int64_t v = pqp_key(score, nn);
         // ---- rank of every neighbour's key in the pool, all lanes at once; "same node" = equal up to bit 0 ----
         int rold;
         {
@@ -337,7 +353,7 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
 #pragma unroll
             for (int k2 = 0; k2 < 9; k2++) {
                 if (k2 < 8) c3 += p3[k2] > v ? 1 : 0;
-                dup |= (p3[k2] | 1ll) == v;
+                dup |= (p3[k2] | 3ll) == v;  // same node (whatever its expanded / rejected bits)
             }
             rold = lo + c3;
             if (dup) keep = false;
@@ -424,13 +440,26 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
             np = ntot;
             if (ntot >= rk) {
                 const int bhi = (int)(pool[rk - 1] >> 32);
-                bscore = hi_score(bhi);
+                const float nb = hi_score(bhi);
+                if (nb != bscore) nrej = 0;  // the boundary rose: every rejected entry (they tied with the old one) falls off below
+                bscore = nb;
                 if (ntot > rk) {
-                    const int64_t eb = pool[min(rk + lane, cap)];
-                    const unsigned long long mt = __ballot((int)(eb >> 32) == bhi);  // (a sentinel never matches)
-                    const int run = ~mt ? __ffsll((long long)~mt) - 1 : 64;           // ties directly behind the boundary
-                    if (run >= 64) {
-                        why = 3;  // more boundary ties than this kernel tracks
+                    // ties directly behind the boundary stay; the pool has room for cap - rk - R of them (64 on the first
+                    // launch: one chunk), the same query with more is redone by the wider second launch
+                    const int slack = cap - rk - R;
+                    int run = 0;
+                    for (int p0 = rk;; p0 += JV_WAVE) {
+                        const int64_t eb = pool[min(p0 + lane, cap)];
+                        const unsigned long long mt = __ballot((int)(eb >> 32) == bhi);  // (a sentinel never matches)
+                        if (~mt) {
+                            run += __ffsll((long long)~mt) - 1;
+                            break;
+                        }
+                        run += JV_WAVE;
+                        if (run >= slack) break;
+                    }
+                    if (run >= slack) {
+                        why = 3;  // more boundary ties than this launch tracks
                         break;
                     }
                     np = rk + run;
@@ -443,6 +472,23 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
         }
     }
     STAMP(5)
+    if (why == 0 && nrej > 0) {
+        // take the rejected entries out: what remains in front is jvector's result queue (ascending pass, every entry moves
+        // down by the number of rejected entries ahead of it; a chunk is read completely before it is written)
+        int carry = 0;
+        for (int t = 0; (t << 6) < np; t++) {
+            const int pos = (t << 6) + lane;
+            const int64_t e = pool[min(pos, cap)];
+            const bool rej = pos < np && !(e & 2ll);
+            const unsigned long long rm = __ballot(rej);
+            const int shift = carry + __popcll(rm & ((1ull << lane) - 1ull));
+            if (pos < np && !rej && shift > 0) pool[pos - shift] = e;
+            carry += __popcll(rm);
+        }
+        for (int p0 = np - carry; p0 < np; p0 += JV_WAVE)
+            if (p0 + lane < np) pool[p0 + lane] = KEY_MIN;
+        np -= carry;
+    }
 
     // LUTR: the pool moves to registers so that the whole LDS allocation can serve as the visited-count hash set
     i32x32 PL, PH;
@@ -646,7 +692,7 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
         int node = 0;
         if (i < nres) {
             const int64_t k = rpool[i];
-            node = pool_node(k);
+            node = lo_node((int)(uint32_t)(k & 0xFFFFFFFFll));
             take = above > 0 ? key_score(k) >= a.rerank_floor : i == 0;  // position 0 is the best approximate entry
         }
         const unsigned long long tm = __ballot(take);
@@ -699,11 +745,26 @@ template <int NCHT, int NP, bool FAST, int CAPK, bool LUTR = false>
 __global__ __launch_bounds__(JV_WAVE, LUTR ? 2 : 1) void jv_search_pqp_kernel(const JvIndexDev ix, const JvSearchArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int32_t* explog = a.pqp_log + (size_t)blockIdx.x * (size_t)a.pqp_log_cap;
+    // second launch (a.retry_only: wider pool, longer log): only the queries the first one flagged, found 8 flags at a time
+    int base = 0;
+    unsigned long long todo = 0ull;
     for (;;) {
         int qi = 0;
-        if (threadIdx.x == 0) qi = atomicAdd(a.pqp_counter, 1);
-        qi = __builtin_amdgcn_readfirstlane(qi);
-        if (qi >= a.nq) break;
+        if (a.retry_only) {
+            while (!todo) {
+                if (threadIdx.x == 0) base = atomicAdd(a.retry_counter, 8);  // (small chunks: two flagged queries rarely share one)
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= a.nq) return;
+                const int qf = (threadIdx.x < 8 && base + (int)threadIdx.x < a.nq) ? a.out_flags[base + threadIdx.x] : 0;
+                todo = __ballot(((uint32_t)qf & JV_FLAG_OVERFLOW) != 0);
+            }
+            qi = base + __ffsll((long long)todo) - 1;
+            todo &= todo - 1ull;
+        } else {
+            if (threadIdx.x == 0) qi = atomicAdd(a.pqp_counter, 1);
+            qi = __builtin_amdgcn_readfirstlane(qi);
+            if (qi >= a.nq) break;
+        }
         search_one_pqp<NCHT, NP, FAST, CAPK, LUTR>(ix, a, qi, smem, explog);
         __syncthreads();
     }

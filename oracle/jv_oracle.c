@@ -568,8 +568,6 @@ typedef struct {
     size_t lut_floats;
     float* norm_lut;
     size_t norm_floats;
-    const float* norm_for_codebooks; /* norm_lut is a function of the index only: cached per (codebooks, M, K) */
-    int norm_M, norm_K;
     int32_t* sizes;
     int sizes_cap;
     float* qc;
@@ -625,14 +623,10 @@ int jvo_search(const jv_index_desc* ix, const float* query, int32_t topK, int32_
                 free(sc->norm_lut);
                 sc->norm_lut = (float*)malloc(sizeof(float) * lf);
                 sc->norm_floats = lf;
-                sc->norm_for_codebooks = NULL;
             }
-            if (sc->norm_for_codebooks != ix->pq_codebooks || sc->norm_M != ix->pq_M || sc->norm_K != ix->pq_K) {
-                jvo_pq_build_norm_lut(ix, sc->norm_lut);
-                sc->norm_for_codebooks = ix->pq_codebooks;
-                sc->norm_M = ix->pq_M;
-                sc->norm_K = ix->pq_K;
-            }
+            /* rebuilt per query (the cost of one LUT): a cache keyed by the codebook ADDRESS went stale when a later
+             * index's arrays were allocated where an earlier one's had been */
+            jvo_pq_build_norm_lut(ix, sc->norm_lut);
             s.norm_lut = sc->norm_lut;
         }
     }

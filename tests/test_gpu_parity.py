@@ -361,8 +361,11 @@ def test_score_tie_storm_parity(pkg, pyoracle, seed):
         cb, cen, codes, K = bl.pq_train_encode_cpu(base, 2, sim)
         ixq = b.IndexData(vectors=base, adj=adj, entry_node=ix.entry_node, similarity=sim, pq_codebooks=cb, pq_centroid=cen,
                           pq_codes=codes, pq_M=2, pq_K=K)
-        for data, flags, name in ((ix, 0, "exact"), (ixq, 0, "pq"), (ixq, b.DESC_FUSED_ADC, "pq-fused")):
+        for data, flags, name in ((ix, 0, "exact"), (ixq, 0, "pq"), (ixq, b.DESC_FUSED_ADC, "pq-fused"), (ixq, b.DESC_FUSED_ADC, "pq-fused-pqp")):
             gpu = b.GpuIndex(data, flags=flags)
+            if name == "pq-fused-pqp":
+                gpu.set_option("lutr_min_queries", 0)   # the persistent headline kernel also for these small pools: it
+                                                         # handles strict-admission ties itself ("rejected" entries)
             orc = pyoracle.Oracle(b, data)
             for k, rk in ((1, 1), (2, 2), (3, 4), (5, 8), (10, 16), (10, 40), (20, 100)):
                 _assert_same(gpu.search_batch(q, k, rk), orc.search_batch(q, k, rk), f"{name} sim={sim} seed={seed} k={k} rk={rk}")

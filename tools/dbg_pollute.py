@@ -1,0 +1,8 @@
+"""Fills free HBM with NaN patterns, releases it, then runs the given pytest selection in the same process: reads past
+the end of an allocation that are 'harmless' on zeroed memory show up as parity failures."""
+import sys, torch, pytest
+x = [torch.full((1 << 28,), float("nan"), device="cuda") for _ in range(int(sys.argv[1]))]   # 1 GiB each
+torch.cuda.synchronize()
+del x
+torch.cuda.empty_cache()
+sys.exit(pytest.main(sys.argv[2:]))
