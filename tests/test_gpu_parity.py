@@ -345,6 +345,34 @@ def test_malformed_random_graphs_parity(pkg, pyoracle, seed):
             gpu.close()
 
 
+@pytest.mark.parametrize("seed", [21, 22])
+def test_score_tie_storm_register_table_kernel(pkg, pyoracle, seed):
+    """The same storm through the PQ-32 register-table variant of the persistent kernel (the C3 headline kernel): 32-d
+    vectors that differ in four coordinates only, so whole groups of nodes share one PQ code and every approximate score
+    ties.  Rejected entries (strict admission), tie runs longer than one chunk (second launch) and the rerank over tied
+    pools all have to agree with the two-queue oracle, counters included."""
+    b, bl = pkg.binding, pkg.builder
+    rng = np.random.default_rng(seed)
+    n, d, R = 600, 32, 16
+    base = np.zeros((n, d), dtype=np.float32)
+    base[:, :4] = rng.integers(0, 3, size=(n, 4))
+    adj = np.stack([rng.permutation(n)[:R] for _ in range(n)]).astype(np.int32)
+    q = np.zeros((64, d), dtype=np.float32)
+    q[:, :4] = rng.integers(0, 3, size=(64, 4)) + np.float32(0.5) * (rng.random((64, 4)) < 0.3)
+    for sim in (0, 1):
+        cb, cen, codes, K = bl.pq_train_encode_cpu(base, 32, sim)
+        ixq = b.IndexData(vectors=base, adj=adj, entry_node=int(rng.integers(0, n)), similarity=sim, pq_codebooks=cb, pq_centroid=cen,
+                          pq_codes=codes, pq_M=32, pq_K=K)
+        orc = pyoracle.Oracle(b, ixq)
+        for lutr in (1, 0):
+            gpu = b.GpuIndex(ixq, flags=b.DESC_FUSED_ADC)
+            gpu.set_option("lutr_min_queries", 0)
+            gpu.set_option("no_lutr", 1 - lutr)
+            for k, rk in ((1, 1), (3, 4), (10, 16), (10, 40), (20, 100), (50, 300)):
+                _assert_same(gpu.search_batch(q, k, rk), orc.search_batch(q, k, rk), f"lutr={lutr} sim={sim} seed={seed} k={k} rk={rk}")
+            gpu.close()
+
+
 @pytest.mark.parametrize("seed", [11, 12, 13, 14])
 def test_score_tie_storm_parity(pkg, pyoracle, seed):
     """Vectors on a tiny integer grid (3^4 distinct points for 500 nodes) over a dense random graph: almost every
