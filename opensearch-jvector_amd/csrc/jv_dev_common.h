@@ -370,7 +370,10 @@ struct RowsInFlight { static constexpr int U = NCHT <= 6 ? 4 : (NCHT <= 12 ? 2 :
 template <int NCHT, int UMUL = 1>
 __device__ __forceinline__ void score_rows(const JvIndexDev& ix, const float* q_lds, const int32_t* todo, int m,
                                            float* todo_score, float qnorm2, float scale, int lane) {
-    if (ix.nvq_M > 0) {  // NVQ-inline field: exact scores against the dequantised records
+    // NVQ-inline field: exact scores against the dequantised records.  Only the "any d" instances (NCHT = 0) carry the
+    // decoder — the launchers route NVQ indexes to them — so that the fixed-d kernels keep their register budget
+    // (with the decoder inlined the C2 kernel went from 168 to 248 VGPRs + scratch and lost a third of its throughput).
+    if (NCHT == 0 && ix.nvq_M > 0) {
         if (ix.sim == 0) score_rows_nvq_t<0>(ix, q_lds, todo, m, todo_score, qnorm2, scale, lane);
         else if (ix.sim == 1) score_rows_nvq_t<1>(ix, q_lds, todo, m, todo_score, qnorm2, scale, lane);
         else score_rows_nvq_t<2>(ix, q_lds, todo, m, todo_score, qnorm2, scale, lane);

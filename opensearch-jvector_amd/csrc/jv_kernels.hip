@@ -1616,6 +1616,7 @@ static const big_kernel_t g_big_kernels[2][4] = {JV_ROW(jv_search_big_kernel, fa
 static const big_kernel_t g_bigq_kernels[2][4] = {JV_BIGQ_ROW(false), JV_BIGQ_ROW(true)};  // queues in LDS, visited bitset in HBM
 
 static int nch_slot(const JvIndexDev* ix) {
+    if (ix->nvq_M > 0) return 0;  // the NVQ decoder lives in the "any d" instances only (score_rows)
     if (ix->stride != ix->nch * 64) return 0;
     return ix->nch == 2 ? 1 : ix->nch == 12 ? 2 : ix->nch == 24 ? 3 : 0;
 }

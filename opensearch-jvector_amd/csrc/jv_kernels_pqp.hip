@@ -783,6 +783,7 @@ static const pqp_kernel_t g_pqp_kernels[4][4][4] = {JV_PQP_CAPS(1, false), JV_PQ
 static const pqp_kernel_t g_pqv_kernels[3][4] = {JV_PQV_ROW(0), JV_PQV_ROW(1), JV_PQV_ROW(2)};
 
 static int pqp_nch_slot(const JvIndexDev* ix) {
+    if (ix->nvq_M > 0) return 0;  // the NVQ decoder lives in the "any d" instances only (score_rows)
     if (ix->stride != ix->nch * 64) return 0;
     return ix->nch == 2 ? 1 : ix->nch == 12 ? 2 : ix->nch == 24 ? 3 : 0;
 }

@@ -48,8 +48,13 @@ def main(src, name):
         p = os.path.join(src, f"pmc_{cname}.csv")
         if not os.path.exists(p):
             continue
-        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(p))
-                if main_kernel in r["Kernel_Name"] and (r["Grid_Size"] == grid or "pqp" in main_kernel)]
+        by_name = {}
+        for r in csv.DictReader(open(p)):
+            if main_kernel in r["Kernel_Name"] and (r["Grid_Size"] == grid or "pqp" in main_kernel):
+                by_name.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
+        # (the persistent kernel is launched twice per step: the main launch and the wider second launch over the few
+        #  flagged queries, a different template instance — the main one is the instance that moves the bytes)
+        vals = max(by_name.values(), key=lambda v: sum(v)) if by_name else []
         vals = vals[-steps:]
         if vals:
             traffic[cname] = sum(vals) / len(vals)
