@@ -649,6 +649,28 @@ def main():
         dist.destroy_process_group()
 
 
+def usable_cpus():
+    """(threads to use, CFS quota in CPUs or None).  The GPU boxes run this in a container whose cgroup grants a CPU-time
+    quota well below the hardware thread count (measured: cpu.max = 16 CPUs on a 256-thread host); more runnable threads
+    than the quota get throttled and the oracle's throughput DROPS (tools/cpu_scaling.py: 51 k QPS at 16 threads, 22 k at
+    256 on the same index), so the baseline uses as many threads as the quota allows."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, -(-int(q) // int(p)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = max(1, -(-q // p))
+        except (OSError, ValueError):
+            pass
+    return (min(n, quota) if quota else n), quota
+
+
 def cpu_baseline(torch, binding, eng, rk, budget_s):
     import psutil
     pyoracle = graft.load_oracle()
@@ -657,13 +679,16 @@ def cpu_baseline(torch, binding, eng, rk, budget_s):
     if psutil.virtual_memory().available < need * 1.3:
         raise MemoryError(f"host RAM too small for a {need / 1e9:.1f} GB index copy")
     t0 = time.time()
-    ix = binding.IndexData(vectors=base.cpu().numpy(), adj=adj_t.cpu().numpy(), entry_node=entry, similarity=sim)
+    # host copy first-touched by all threads (pages on every NUMA node; see oracle/jv_oracle.h: jvo_parallel_copy)
+    spread = lambda t: pyoracle.spread_to_host(binding.JvIndexDesc, t.contiguous())
+    ix = binding.IndexData(vectors=spread(base), adj=spread(adj_t), entry_node=entry, similarity=sim)
     if pq:
-        ix.pq_codebooks, ix.pq_centroid, ix.pq_codes = pq["codebooks"], pq["centroid"], pq["codes"].cpu().numpy()
+        ix.pq_codebooks, ix.pq_centroid, ix.pq_codes = pq["codebooks"], pq["centroid"], spread(pq["codes"])
         ix.pq_M, ix.pq_K = ix.pq_codes.shape[1], pq["K"]
     orc = pyoracle.Oracle(binding, ix)
     log(f"cpu_baseline: index copied to host in {time.time() - t0:.1f}s")
-    cores = os.cpu_count() or 1
+    host_threads = os.cpu_count() or 1
+    cores, quota = usable_cpus()
     pool = queries.cpu().numpy()
     orc.search_batch(pool[:min(4 * cores, len(pool))], k, rk, threads=cores)  # warm the thread pool + per-thread scratch
     nsample = min(len(pool), 4096)
@@ -701,7 +726,7 @@ def cpu_baseline(torch, binding, eng, rk, budget_s):
                       f"per-thread reusable searcher scratch ({dt:.1f}s); C restatement of jVector's search (real jVector "
                       f"needs a JVM: not available)",
             "single_thread_qps": round(n1 / dt1, 1), "cpu_model": cpu_model,
-            "host_threads": cores, "gpu_ids_equal_oracle_on_sample": same_ids,
+            "host_threads": host_threads, "cpu_quota_cpus": quota, "gpu_ids_equal_oracle_on_sample": same_ids,
             "gpu_score_bits_equal_oracle_on_sample": same_bits, "gpu_counters_equal_oracle_on_sample": same_stats}
 
 

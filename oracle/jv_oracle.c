@@ -499,6 +499,17 @@ static const int32_t* neighbours(const jv_index_desc* ix, int level, int node, i
     return NULL;
 }
 
+void jvo_parallel_copy(void* dst, const void* src, size_t bytes) {
+    const size_t chunk = (size_t)2 << 20;
+    const long nchunks = (long)((bytes + chunk - 1) / chunk);
+#pragma omp parallel for schedule(static)
+    for (long c = 0; c < nchunks; c++) {
+        size_t o = (size_t)c * chunk;
+        size_t len = bytes - o < chunk ? bytes - o : chunk;
+        memcpy((char*)dst + o, (const char*)src + o, len);
+    }
+}
+
 /* GraphSearcher.addTopCandidate: when full, only a STRICTLY better score replaces the worst
  * result; an equal score is treated as evicted. */
 static void add_top_candidate(searcher* s, int node, float score, int rk) {

@@ -61,6 +61,11 @@ int jvo_search_batch(const jv_index_desc* ix, const float* queries, int32_t nq, 
                      int32_t* out_docs, float* out_scores, int32_t* out_count, int32_t* out_stats,
                      int threads);
 
+/* bytes from src to dst with all OpenMP threads, 2 MiB per chunk: used by bench.py's cpu_baseline so that the host copy
+ * of the index is FIRST TOUCHED by threads on every NUMA node (a single-threaded copy puts the whole index behind one
+ * socket's memory controllers and starves the other socket's searcher threads). */
+void jvo_parallel_copy(void* dst, const void* src, size_t bytes);
+
 /* exact scorer over an ordinal list (JVectorVectorScorer.score, J/JVectorVectorScorer.java:36-53) */
 void jvo_score_ordinals(const jv_index_desc* ix, const float* query, const int32_t* ordinals,
                         int32_t count, float* out_scores);

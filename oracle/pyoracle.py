@@ -50,8 +50,27 @@ def load(desc_type):
         lib.jvo_pq_build_lut.restype = None
         lib.jvo_nvq_dequantize.argtypes = [P, i32, vp]
         lib.jvo_nvq_dequantize.restype = None
+        lib.jvo_parallel_copy.argtypes = [vp, vp, C.c_size_t]
+        lib.jvo_parallel_copy.restype = None
         _lib = lib
     return _lib
+
+
+def spread_to_host(desc_type, device_tensor, slab_bytes=1 << 30):
+    """numpy copy of a (row-major, contiguous) torch device tensor whose pages are first touched by all OpenMP threads
+    (jvo_parallel_copy), slab by slab, so that a multi-socket host serves the index from every NUMA node."""
+    import numpy as np
+    lib = load(desc_type)
+    t = device_tensor
+    out = np.empty(tuple(t.shape), dtype={4: {True: np.float32, False: np.int32}, 1: {False: np.uint8}}[t.element_size()][t.is_floating_point()])
+    if t.numel() == 0:
+        return out
+    row_bytes = out.strides[0]
+    rows = max(1, slab_bytes // max(1, row_bytes))
+    for a in range(0, t.shape[0], rows):
+        part = t[a:a + rows].cpu().numpy()
+        lib.jvo_parallel_copy(out[a:].ctypes.data, part.ctypes.data, part.nbytes)
+    return out
 
 
 class Oracle:
