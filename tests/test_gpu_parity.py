@@ -355,10 +355,10 @@ def test_score_tie_storm_register_table_kernel(pkg, pyoracle, seed):
     rng = np.random.default_rng(seed)
     n, d, R = 600, 32, 16
     base = np.zeros((n, d), dtype=np.float32)
-    base[:, :4] = rng.integers(0, 3, size=(n, 4))
+    base[:, :4] = rng.integers(0, 2, size=(n, 4))      # 16 distinct points: ~37 nodes per point, > 63 per score class
     adj = np.stack([rng.permutation(n)[:R] for _ in range(n)]).astype(np.int32)
     q = np.zeros((64, d), dtype=np.float32)
-    q[:, :4] = rng.integers(0, 3, size=(64, 4)) + np.float32(0.5) * (rng.random((64, 4)) < 0.3)
+    q[:, :4] = rng.integers(0, 2, size=(64, 4)) + np.float32(0.5) * (rng.random((64, 4)) < 0.3)
     for sim in (0, 1):
         cb, cen, codes, K = bl.pq_train_encode_cpu(base, 32, sim)
         ixq = b.IndexData(vectors=base, adj=adj, entry_node=int(rng.integers(0, n)), similarity=sim, pq_codebooks=cb, pq_centroid=cen,
@@ -370,6 +370,15 @@ def test_score_tie_storm_register_table_kernel(pkg, pyoracle, seed):
             gpu.set_option("no_lutr", 1 - lutr)
             for k, rk in ((1, 1), (3, 4), (10, 16), (10, 40), (20, 100), (50, 300)):
                 _assert_same(gpu.search_batch(q, k, rk), orc.search_batch(q, k, rk), f"lutr={lutr} sim={sim} seed={seed} k={k} rk={rk}")
+            # the fixture must reach past the first launch: with the ladder switched off ("pqf_only") some queries stay
+            # unanswered (more boundary ties than the first launch's 64 slots) — in the runs above those were answered by
+            # the wider second launch of the same kernel
+            gpu.set_option("pqf_only", 1)
+            unanswered = 0
+            for k, rk in ((10, 16), (10, 40), (20, 100)):
+                _, status, _, _ = gpu.search_batch_ex(q, k, rk)
+                unanswered += int((status != 0).sum())
+            assert unanswered > 0, "tie fixture no longer exercises the second launch"
             gpu.close()
 
 
