@@ -41,7 +41,7 @@ hipError_t jvk_launch_pack_pairs(const int32_t* d_docs, const float* d_scores, i
 // LDS-pool persistent kernel (jv_kernels_pqp.hip): the headline path
 hipError_t jvk_pqp_set_max_lds(int bytes);
 int jvk_pqp_max_entries(void);
-int jvk_pqp_blocks_per_cu(const JvIndexDev* ix, int cap, int lds_bytes, int lutr);
+int jvk_pqp_blocks_per_cu(const JvIndexDev* ix, int cap, int lds_bytes, int lutr, int filt);
 int jvk_pqp_lutr_ok(const JvIndexDev* ix, int cap);
 hipError_t jvk_launch_search_pqp(const JvIndexDev* ix, const JvSearchArgs* a, int lds_bytes, int blocks, int lutr, hipStream_t s);
 }
@@ -497,13 +497,19 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
     // pool of rk + 64 boundary ties + one expansion's R new keys (+ 1 sentinel slot); the expansion log lives in HBM
     // (pools of <= 256 entries stay on the round-1 kernel below: its 256-entry variant keeps masks and pivots in scalar
     //  registers and measured 1.5-3 % faster there; its cost grows with the pool, this kernel's does not)
-    if (!force_big && !filtered && g.pool && pqf_index && rk + 64 + ix->dev.R <= jvk_pqp_max_entries() && OPT(ix, OPT_NO_PQF) == 0 &&
-        OPT(ix, OPT_NO_PQP) == 0 && (rk + 64 + ix->dev.R > 256 || OPT(ix, OPT_LUTR_MIN_QUERIES) == 0) && ix->dev.n < (1 << 30)) {
+    // With a doc filter the same kernel (instances in jv_kernels_pqpf.hip) holds every scored node scoring >= the rerankK-th
+    // best ACCEPTED one, ~ rerankK / selectivity entries: first launch 1 024..2 048 entries (register table where it
+    // applies), second launch 4 096; each wave estimates its filter's selectivity first and skips a launch it cannot fit.
+    // (Pools of <= 256 entries keep round 1's filtered kernel with its 448 / 960-entry launches.)
+    const bool pqp_plain = !filtered && g.pool && ix->dev.n < (1 << 30) && (rk + 64 + ix->dev.R > 256 || OPT(ix, OPT_LUTR_MIN_QUERIES) == 0);
+    const bool pqp_filt = filtered && pqf_shape && ix->dev.n < (1 << 29) && rk + 64 + ix->dev.R > 256;
+    if (!force_big && (pqp_plain || pqp_filt) && pqf_index && rk + 64 + ix->dev.R <= jvk_pqp_max_entries() && OPT(ix, OPT_NO_PQF) == 0 &&
+        OPT(ix, OPT_NO_PQP) == 0) {
         JvSearchArgs ap = a;
         const int lut_b = ix->dev.pq_M * 256 * 4;
         const int qc_b = ix->dev.nch * 64 * 4;
-        ap.cand_cap = rk + 64 + ix->dev.R;
-        ap.pqp_log_cap = (3 * rk + 64 + 3) & ~3;
+        ap.cand_cap = filtered ? std::min(2048, std::max(1024, 2 * (rk + 64 + ix->dev.R))) : rk + 64 + ix->dev.R;
+        ap.pqp_log_cap = filtered ? 3 * ap.cand_cap : ((3 * rk + 64 + 3) & ~3);
         bool alias = qc_b <= lut_b;
         const int off_f = ix->dev.pq_M * 256 - ix->dev.nch * 64;
         for (int m = 0; alias && m + 1 < ix->dev.pq_M; m++)
@@ -544,17 +550,19 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
         // table in LDS, as many tie slots as the largest pool class allows, 4x the log; walks the flag array
         JvSearchArgs ap2 = ap;
         ap2.cand_cap = std::min(jvk_pqp_max_entries(), std::max(2 * ap.cand_cap, rk + ix->dev.R + 1024));
-        ap2.pqp_log_cap = (12 * rk + 1024 + 3) & ~3;
+        ap2.pqp_log_cap = filtered ? 3 * ap2.cand_cap : ((12 * rk + 1024 + 3) & ~3);
         ap2.retry_only = 1;
         ap2.retry_counter = c->work_counter + 5;
         const int lds2 = plan(ap2, false);
         const bool second = lds2 <= kMaxLds && ap2.cand_cap > ap.cand_cap && OPT(ix, OPT_PQF_ONLY) == 0;
         if (lds <= kMaxLds) {
-            int per_cu = jvk_pqp_blocks_per_cu(&ix->dev, ap.cand_cap, lds, lutr);
+            int per_cu = jvk_pqp_blocks_per_cu(&ix->dev, ap.cand_cap, lds, lutr, filtered ? 1 : 0);
             if (OPT(ix, OPT_PQP_BLOCKS_PER_CU) > 0) per_cu = (int)std::min<int64_t>(per_cu, OPT(ix, OPT_PQP_BLOCKS_PER_CU));  // diagnostics
             int blocks = ix->cu_count * per_cu;
             if (blocks > nq) blocks = nq;
-            const int blocks2 = std::min(ix->cu_count, (nq + 7) / 8);
+            // (unfiltered: a handful of flagged queries; filtered: a selective filter sends the whole batch here)
+            const int per_cu2 = filtered && second ? jvk_pqp_blocks_per_cu(&ix->dev, ap2.cand_cap, lds2, 0, 1) : 1;
+            const int blocks2 = std::min(ix->cu_count * per_cu2, (nq + 7) / 8);
             size_t need = (size_t)blocks * (size_t)ap.pqp_log_cap;
             if (second) need = std::max(need, (size_t)blocks2 * (size_t)ap2.pqp_log_cap);
             if (need > c->pqp_log_ints) {

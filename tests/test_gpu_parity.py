@@ -505,6 +505,43 @@ def test_filtered_fused_pq_parity(pkg, pyoracle, small_sets, sim):
     gpu.close()
 
 
+@pytest.mark.parametrize("sim", [0, 2])
+def test_filtered_persistent_kernel_parity(pkg, pyoracle, small_sets, sim):
+    """Doc filters at beam widths whose pool (~ rerankK / selectivity) outgrows round 1's filtered kernel: the persistent
+    pool kernel's filtered instances (jv_kernels_pqpf.hip: boundary tracked at the rerankK-th best ACCEPTED entry, first
+    launch <= 2 048 entries, second 4 096, then the generic ladder) against the oracle's two-queue search."""
+    b, bl = pkg.binding, pkg.builder
+    base, q = small_sets["base64"][:6000], small_sets["q64"][:40]
+    n = base.shape[0]
+    rng = np.random.default_rng(23 + sim)
+    max_doc = 2 * n
+    ord2doc = rng.permutation(max_doc)[:n].astype(np.int32)
+    ord2doc[rng.random(n) < 0.03] = -1
+    for pq_M, lutr in ((16, 0), (32, 1)):
+        ix = bl.build_index_cpu(base, sim, R=32, L=80, pq_M=pq_M, ord2doc=ord2doc, max_doc=max_doc)
+        gpu = b.GpuIndex(ix, flags=b.DESC_FUSED_ADC)
+        if lutr:
+            gpu.set_option("lutr_min_queries", 0)     # register-table instances (PQ-32, not cosine) even for this small batch
+        orc = pyoracle.Oracle(b, ix)
+        for frac in (0.95, 0.6, 0.3, 0.1):
+            words = b.accept_words(np.nonzero(rng.random(max_doc) < frac)[0], max_doc)
+            for k, rk in ((10, 200), (20, 400), (10, 1000)):
+                want = orc.search_batch(q, k, rk, accept=words, accept_num_docs=max_doc)
+                got = gpu.search_batch(q, k, rk, accept=words, accept_num_docs=max_doc)
+                _assert_same(got, want, f"sim={sim} M={pq_M} frac={frac} k={k} rk={rk}")
+        words = b.accept_words(np.nonzero(rng.random(max_doc) < 0.5)[0], max_doc)
+        want = orc.search_batch(q, 10, 300, rerank_floor=0.6, accept=words, accept_num_docs=max_doc)
+        got = gpu.search_batch(q, 10, 300, rerank_floor=0.6, accept=words, accept_num_docs=max_doc)
+        _assert_same(got, want, f"sim={sim} M={pq_M} filter + rerankFloor")
+        # the answers above must come from the persistent kernel itself, not from the ladder behind it: with the ladder
+        # switched off a mild filter still answers (nearly) every query
+        gpu.set_option("pqf_only", 1)
+        words = b.accept_words(np.nonzero(rng.random(max_doc) < 0.9)[0], max_doc)
+        _, status, _, _ = gpu.search_batch_ex(q, 10, 400, accept=words, accept_num_docs=max_doc)
+        assert int((status == 0).sum()) >= len(q) - 2, status
+        gpu.close()
+
+
 @pytest.mark.parametrize("seed", [21, 22])
 def test_filtered_tie_storm_parity(pkg, pyoracle, seed):
     """Grid-valued vectors (every comparison is a tie) + doc filters on the fused-PQ path: strict admission into a
@@ -523,7 +560,8 @@ def test_filtered_tie_storm_parity(pkg, pyoracle, seed):
         orc = pyoracle.Oracle(b, ixq)
         for frac in (0.8, 0.4):
             words = b.accept_words(np.nonzero(rng.random(n) < frac)[0], n)
-            for k, rk in ((1, 1), (2, 2), (3, 4), (5, 8), (10, 16), (10, 40)):
+            # (rerankK 200 / 300: pools beyond 256 entries run on the persistent kernel's filtered instances)
+            for k, rk in ((1, 1), (2, 2), (3, 4), (5, 8), (10, 16), (10, 40), (10, 200), (20, 300)):
                 _assert_same(gpu.search_batch(q, k, rk, accept=words, accept_num_docs=n),
                              orc.search_batch(q, k, rk, accept=words, accept_num_docs=n), f"sim={sim} seed={seed} frac={frac} k={k} rk={rk}")
         gpu.close()
