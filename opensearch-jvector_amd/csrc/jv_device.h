@@ -81,7 +81,7 @@ struct JvSearchArgs {
     int32_t spill_tables;
     int32_t* spill_counter;  // zeroed per call
     int64_t* dbg;            // diagnostic build (-DJV_STAMPS) only: 8 cycle accumulators; nullptr in the product
-    // register-pool kernel (jv_kernels_pqr.hip): persistent grid
+    // persistent pool kernel (jv_pqp_body.h)
     int32_t* pqp_log;        // [blocks][pqp_log_cap] expansion log scratch
     int32_t pqp_log_cap;
     int32_t pqp_qc_off;      // LDS byte offset of the centred query during the LUT build

@@ -11,7 +11,7 @@
 //   * round 1 (jv_search_pqf_kernel): LDS pool, but every expansion touched the WHOLE pool — masks in scalar registers
 //     over all 64-entry chunks, a full read-shift-write pass, a full pass to rebuild the masks: 5 100 cycles per
 //     expansion at 256 entries, ~20 000 at 1 024 (rerankK = 900);
-//   * pool in registers (jv_kernels_pqr.hip): insertion by DPP wave shifts is cheap, but the kernel keeps no visited
+//   * pool in registers (measured this round, then removed): insertion by DPP wave shifts is cheap, but the kernel keeps no visited
 //     set while searching, so ~20 of the 32 neighbours of an expansion are re-encounters that must be recognised in
 //     the pool — one at a time through scalar compares (registers cannot be indexed per lane): 340 cycles each;
 //   * this kernel: the pool stays in LDS so that all 32 neighbours find their rank (and their duplicates) at once

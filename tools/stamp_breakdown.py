@@ -40,7 +40,7 @@ for fused in (1,):
     ix.set_option("dbg_ptr", 0)
     v = dbg.cpu().numpy().astype(np.float64)
     st = o[4].cpu().numpy().astype(np.float64).mean(0)
-    # register-pool kernel (jv_kernels_pqr.hip) stamp slots; JV_OPT no_pqr=1 shows the round-1 LDS-pool kernel's slots instead
+    # stamp slots of the persistent pool kernel (jv_pqp_body.h); JV_OPT_no_pqp=1 shows the round-1 kernel's slots instead
     names = ["find best/runner-up + block select", "prefetch issue + mark expanded + log", "ADC", "boundary test + rank search + dedupe", "ranks among new + shift + insert",
              "boundary + trim", "visited-count pass", "LUT build + entry point", "rerank + top-K"]
     cyc = np.concatenate([v[:8], v[13:14]])
