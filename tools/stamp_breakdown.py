@@ -13,7 +13,7 @@ b.load_library(b.LIB_PATH)
 gb = importlib.import_module("opensearch_jvector_amd.builder_gpu")
 import bench
 
-n = int(os.environ.get("N", 2_000_000)); d = 768; M = 32; rk = int(os.environ.get("RK", 200)); B = 65536
+n = int(os.environ.get("N", 2_000_000)); d = 768; M = 32; rk = int(os.environ.get("RK", 200)); B = int(os.environ.get("B", 65536))
 dev = torch.device("cuda", 0)
 base, q = bench.make_pq_data(torch, os.environ.get("DIST", "rotated"), n, B, d, M, 0, n, False, dev)
 adj, entry = gb.build_graph_gpu(torch, base, 0, R=32, L=100, verbose=False)
