@@ -454,13 +454,9 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
                 // (broadcast) reads: rank among the new keys, twins (the same neighbour twice in one adjacency row of a
                 // malformed graph: keep the first), and later the per-position shift counts — no scalar lane-by-lane loops.
                 int64_t* const sk = (int64_t*)(smem + a.pqp_scratch_off);  // [64] kept keys (R <= 64), lane order
-                int32_t* const sr = (int32_t*)(sk + 64);                    // [64] their ranks among the old entries
                 for (int attempt = 0; attempt < 2; attempt++) {
                     const int my = __popcll(km & ((1ull << lane) - 1ull));
-                    if (keep) {
-                        sk[my] = v;
-                        sr[my] = rold;
-                    }
+                    if (keep) sk[my] = v;
                     rnew = 0;
                     bool twin = false;
                     for (int j0 = 0; j0 < nk; j0 += 8) {
@@ -493,13 +489,15 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
                     const int64_t e = pool[min(pos, cap)];
                     int cnt = nk;
                     if (t <= t_mixed) {
-                        cnt = 0;
-                        for (int j0 = 0; j0 < nk; j0 += 8) {
-                            int rj[8];
-#pragma unroll
-                            for (int u = 0; u < 8; u++) rj[u] = sr[min(j0 + u, 63)];
-#pragma unroll
-                            for (int u = 0; u < 8; u++) cnt += (j0 + u < nk && pos >= rj[u]) ? 1 : 0;
+                        // new keys ranked at or before the chunk's first position move the whole chunk; the (few) ranked inside
+                        // it move the entries at or behind them — two ballots and a short scalar loop, no LDS round trip
+                        const int cs0 = t << 6;
+                        cnt = __popcll(__ballot(keep && rold <= cs0));
+                        unsigned long long inm = __ballot(keep && rold > cs0 && rold <= cs0 + 63);
+                        while (inm) {
+                            const int j = __ffsll((long long)inm) - 1;
+                            inm &= inm - 1ull;
+                            cnt += pos >= __builtin_amdgcn_readlane(rold, j) ? 1 : 0;
                         }
                     }
                     if (pos < np && cnt > 0) pool[pos + cnt] = e;
