@@ -449,26 +449,21 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
                     if (pos < np && pos >= r_min) pool[pos + 1] = e;
                 }
             } else {
-                // Bursts of ~8 new keys are the norm when there are several.  The kept keys (and their ranks among the old
-                // entries) are compacted into a small LDS scratch, and every lane reads them back with wave-uniform
-                // (broadcast) reads: rank among the new keys, twins (the same neighbour twice in one adjacency row of a
-                // malformed graph: keep the first), and later the per-position shift counts — no scalar lane-by-lane loops.
-                int64_t* const sk = (int64_t*)(smem + a.pqp_scratch_off);  // [64] kept keys (R <= 64), lane order
+                // Bursts of ~6 new keys are the norm when there are several.  Every kept key is read out of its lane into
+                // scalar registers in turn and compared by all lanes at once: rank among the new keys, twins (the same
+                // neighbour twice in one adjacency row of a malformed graph: keep the first) — no LDS round trips.
+                const int vlo = (int)(uint32_t)(v & 0xFFFFFFFFll), vhi = (int)(v >> 32);
                 for (int attempt = 0; attempt < 2; attempt++) {
-                    const int my = __popcll(km & ((1ull << lane) - 1ull));
-                    if (keep) sk[my] = v;
                     rnew = 0;
                     bool twin = false;
-                    for (int j0 = 0; j0 < nk; j0 += 8) {
-                        int64_t kj[8];
-#pragma unroll
-                        for (int u = 0; u < 8; u++) kj[u] = sk[min(j0 + u, 63)];
-#pragma unroll
-                        for (int u = 0; u < 8; u++) {
-                            const bool in = j0 + u < nk;
-                            rnew += (in && kj[u] > v) ? 1 : 0;
-                            twin |= in && kj[u] == v && j0 + u < my;
-                        }
+                    unsigned long long it = km;
+                    while (it) {
+                        const int j = __ffsll((long long)it) - 1;
+                        it &= it - 1ull;
+                        const int64_t kj = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(vhi, j) << 32) |
+                                                     (uint64_t)(uint32_t)__builtin_amdgcn_readlane(vlo, j));
+                        rnew += kj > v ? 1 : 0;
+                        twin |= kj == v && j < lane;
                     }
                     const unsigned long long km2 = __ballot(keep && !twin);
                     if (km2 == km) break;
