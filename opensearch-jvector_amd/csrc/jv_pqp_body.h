@@ -347,8 +347,10 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
                     nnp[ps] = j < R ? pf_nn[ps] : -1;
                     if (j < R && my_chunk) cwp[ps] = pf_cw[ps];
                 } else {
-                    nnp[ps] = j < R ? ix.adj[(size_t)c * R + j] : -1;
-                    if (j < R && my_chunk) cwp[ps] = *(const u32x4*)(ix.pq_fused + ((size_t)c * R + j) * cs + my_c * 16);
+                    const int32_t* const arow = ix.adj + (size_t)c * (size_t)R;
+                    const unsigned char* const blk = ix.pq_fused + (size_t)c * (size_t)R * (size_t)cs;
+                    nnp[ps] = j < R ? arow[j] : -1;
+                    if (j < R && my_chunk) cwp[ps] = *(const u32x4*)(blk + (uint32_t)(j * cs + my_c * 16));
                 }
             }
         }
@@ -362,8 +364,11 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
             for (int ps = 0; ps < NP; ps++) {
                 if (NP == 1 || ps < npass) {
                     const int j = min(ps * jpp + my_slot, R - 1);
-                    pf_nn[ps] = ix.adj[(size_t)c2e * R + j];
-                    pf_cw[ps] = *(const u32x4*)(ix.pq_fused + ((size_t)c2e * R + j) * cs + (my_chunk ? my_c * 16 : 0));
+                    // (uniform block base + a 32-bit lane offset: scalar address arithmetic, saddr + voffset loads)
+                    const int32_t* const arow = ix.adj + (size_t)c2e * (size_t)R;
+                    const unsigned char* const blk = ix.pq_fused + (size_t)c2e * (size_t)R * (size_t)cs;
+                    pf_nn[ps] = arow[j];
+                    pf_cw[ps] = *(const u32x4*)(blk + (uint32_t)(j * cs + (my_chunk ? my_c * 16 : 0)));
                 }
             }
         }
