@@ -550,9 +550,12 @@ def main():
         except Exception as e:  # pragma: no cover - reported, never fatal for the headline number
             caller_rows = f"unavailable: {e!r}"
 
-    # the kernel that carries the step: pools of <= 256 entries run on jv_search_pqf_kernel, larger ones on the persistent
-    # jv_search_pqp_kernel (csrc/jv_abi.cpp enqueue_batch), exact indexes on jv_search_lds_kernel
-    main_kernel = ("jv_search_pqp_kernel" if rk + 64 + R > 256 else "jv_search_pqf_kernel") if fused else "jv_search_lds_kernel"
+    # the kernel that carries the step (csrc/jv_abi.cpp enqueue_batch): the persistent jv_search_pqp_kernel for pools beyond
+    # 256 entries and wherever its register-table variant applies (PQ-32, not cosine, more than 4 x CUs queries per launch),
+    # else round 1's jv_search_pqf_kernel; exact indexes run on jv_search_lds_kernel
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    reg_table = pq_M == 32 and sim != 2 and eng.B > 4 * cus
+    main_kernel = ("jv_search_pqp_kernel" if (rk + 64 + R > 256 or reg_table) else "jv_search_pqf_kernel") if fused else "jv_search_lds_kernel"
     recall_txt = "nan" if chosen_recall != chosen_recall else f"{chosen_recall:.4f}"
     metric = "queries/sec at recall@10>=0.95" if target_met in (True, None) else \
         f"queries/sec at recall@10={recall_txt} (target 0.95 NOT reached by any rerankK of the sweep)"

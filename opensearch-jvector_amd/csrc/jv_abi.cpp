@@ -501,7 +501,12 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
     // best ACCEPTED one, ~ rerankK / selectivity entries: first launch 1 024..2 048 entries (register table where it
     // applies), second launch 4 096; each wave estimates its filter's selectivity first and skips a launch it cannot fit.
     // (Pools of <= 256 entries keep round 1's filtered kernel with its 448 / 960-entry launches.)
-    const bool pqp_plain = !filtered && g.pool && ix->dev.n < (1 << 30) && (rk + 64 + ix->dev.R > 256 || OPT(ix, OPT_LUTR_MIN_QUERIES) == 0);
+    // (pools of <= 256 entries: the register-table variant where it applies — measured 2.10 M vs 1.92 M QPS for round 1's
+    //  kernel at rerankK = 160 —, else round 1's kernel, which is the faster one against the LDS-table variant there)
+    const int64_t lutr_min_q = OPT(ix, OPT_LUTR_MIN_QUERIES) >= 0 ? OPT(ix, OPT_LUTR_MIN_QUERIES) : 4 * (int64_t)ix->cu_count;
+    const bool lutr_applies = OPT(ix, OPT_NO_LUTR) == 0 && jvk_pqp_lutr_ok(&ix->dev, rk + 64 + ix->dev.R) && nq > lutr_min_q;
+    const bool pqp_plain = !filtered && g.pool && ix->dev.n < (1 << 30) &&
+                           (rk + 64 + ix->dev.R > 256 || OPT(ix, OPT_LUTR_MIN_QUERIES) == 0 || lutr_applies);
     const bool pqp_filt = filtered && pqf_shape && ix->dev.n < (1 << 29) && rk + 64 + ix->dev.R > 256;
     if (!force_big && (pqp_plain || pqp_filt) && pqf_index && rk + 64 + ix->dev.R <= jvk_pqp_max_entries() && OPT(ix, OPT_NO_PQF) == 0 &&
         OPT(ix, OPT_NO_PQP) == 0) {
@@ -517,12 +522,7 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
         const int rerank_b = qc_b + JV_TODO * 8 + ((rk + 1) & ~1) * 8;   // after the search, in front of the pool
         // Table in registers (8 resident queries per CU, +34 % throughput at rerankK = 1 200, but 1.7x the latency of
         // one query): only when the launch has more queries than the LDS-table variant could keep resident anyway
-        const int64_t lutr_min = OPT(ix, OPT_LUTR_MIN_QUERIES) >= 0 ? OPT(ix, OPT_LUTR_MIN_QUERIES) : 4 * (int64_t)ix->cu_count;
-        // ... and only where the LDS-table variant drops below 4 resident queries per CU (measured: at 4 per CU it is the
-        // faster one, at 3 per CU the register variant wins by a third)
-        const int lds_table_variant = ((std::max(lut_b, rerank_b) + 15) & ~15) + (ap.cand_cap + 1) * 8 + 784;
-        const bool crowded = kMaxLds / std::max(1, lds_table_variant) < 4 || OPT(ix, OPT_LUTR_MIN_QUERIES) == 0;
-        const int lutr = (OPT(ix, OPT_NO_LUTR) == 0 && jvk_pqp_lutr_ok(&ix->dev, ap.cand_cap) && nq > lutr_min && crowded) ? 1 : 0;
+        const int lutr = (OPT(ix, OPT_NO_LUTR) == 0 && jvk_pqp_lutr_ok(&ix->dev, ap.cand_cap) && nq > lutr_min_q) ? 1 : 0;
         // LDS plan of one launch: offsets into the workgroup's LDS for a pool of x.cand_cap entries
         auto plan = [&](JvSearchArgs& x, bool regs) {
             int lds;

@@ -16,6 +16,9 @@ pq = gb.pq_train_encode_gpu(torch, base, M, 0)
 desc, keep = b.make_desc_device(n, d, 32, base.data_ptr(), adj.data_ptr(), entry, 0, pq_M=M, pq_K=pq["K"], pq_codebooks=pq["codebooks"],
                                 pq_centroid=pq["centroid"], pq_codes_ptr=pq["codes"].data_ptr(), borrow=True, extra_flags=b.DESC_FUSED_ADC)
 ix = b.GpuIndex(desc=desc, keepalive=keep, flags=b.DESC_BORROW)
+for key, val in os.environ.items():   # JV_OPT_<name>=<int> -> per-index option
+    if key.startswith("JV_OPT_"):
+        ix.set_option(key[len("JV_OPT_"):].lower(), int(val))
 o = [torch.empty((B, 10), dtype=torch.int32, device=dev), torch.empty((B, 10), dtype=torch.int32, device=dev),
      torch.empty((B, 10), dtype=torch.float32, device=dev), torch.empty((B,), dtype=torch.int32, device=dev),
      torch.zeros((B, 4), dtype=torch.int32, device=dev), torch.empty((B,), dtype=torch.int32, device=dev)]
