@@ -500,14 +500,18 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
     // With a doc filter the same kernel (instances in jv_kernels_pqpf.hip) holds every scored node scoring >= the rerankK-th
     // best ACCEPTED one, ~ rerankK / selectivity entries: first launch 1 024..2 048 entries (register table where it
     // applies), second launch 4 096; each wave estimates its filter's selectivity first and skips a launch it cannot fit.
-    // (Pools of <= 256 entries keep round 1's filtered kernel with its 448 / 960-entry launches.)
+    // (Pools of <= 256 entries keep round 1's filtered kernel with its 448 / 960-entry launches where the register-table
+    //  variant does not apply.)
     // (pools of <= 256 entries: the register-table variant where it applies — measured 2.10 M vs 1.92 M QPS for round 1's
     //  kernel at rerankK = 160 —, else round 1's kernel, which is the faster one against the LDS-table variant there)
     const int64_t lutr_min_q = OPT(ix, OPT_LUTR_MIN_QUERIES) >= 0 ? OPT(ix, OPT_LUTR_MIN_QUERIES) : 4 * (int64_t)ix->cu_count;
     const bool lutr_applies = OPT(ix, OPT_NO_LUTR) == 0 && jvk_pqp_lutr_ok(&ix->dev, rk + 64 + ix->dev.R) && nq > lutr_min_q;
     const bool pqp_plain = !filtered && g.pool && ix->dev.n < (1 << 30) &&
                            (rk + 64 + ix->dev.R > 256 || OPT(ix, OPT_LUTR_MIN_QUERIES) == 0 || lutr_applies);
-    const bool pqp_filt = filtered && pqf_shape && ix->dev.n < (1 << 29) && rk + 64 + ix->dev.R > 256;
+    // (measured at rerankK = 160, 2M docs, 65 536 queries per launch, selectivity 0.9 / 0.5 / 0.3 / 0.15: round 1's filtered
+    //  kernel 1.33 M / 0.90 M / 0.27 M / 37 k QPS, this kernel's register-table variant 1.64 M / 1.07 M / 0.68 M / 227 k)
+    const bool pqp_filt = filtered && pqf_shape && ix->dev.n < (1 << 29) &&
+                          (rk + 64 + ix->dev.R > 256 || OPT(ix, OPT_LUTR_MIN_QUERIES) == 0 || lutr_applies);
     if (!force_big && (pqp_plain || pqp_filt) && pqf_index && rk + 64 + ix->dev.R <= jvk_pqp_max_entries() && OPT(ix, OPT_NO_PQF) == 0 &&
         OPT(ix, OPT_NO_PQP) == 0) {
         JvSearchArgs ap = a;

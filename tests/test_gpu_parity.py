@@ -520,12 +520,13 @@ def test_filtered_persistent_kernel_parity(pkg, pyoracle, small_sets, sim):
     for pq_M, lutr in ((16, 0), (32, 1)):
         ix = bl.build_index_cpu(base, sim, R=32, L=80, pq_M=pq_M, ord2doc=ord2doc, max_doc=max_doc)
         gpu = b.GpuIndex(ix, flags=b.DESC_FUSED_ADC)
-        if lutr:
-            gpu.set_option("lutr_min_queries", 0)     # register-table instances (PQ-32, not cosine) even for this small batch
+        # "lutr_min_queries" = 0: the persistent kernel for every pool size and its register-table instances (PQ-32, not
+        # cosine) even for this small batch — the routing of launches with more than 4 x CUs queries
+        gpu.set_option("lutr_min_queries", 0)
         orc = pyoracle.Oracle(b, ix)
         for frac in (0.95, 0.6, 0.3, 0.1):
             words = b.accept_words(np.nonzero(rng.random(max_doc) < frac)[0], max_doc)
-            for k, rk in ((10, 200), (20, 400), (10, 1000)):
+            for k, rk in ((3, 3), (10, 50), (10, 160), (10, 200), (20, 400), (10, 1000)):
                 want = orc.search_batch(q, k, rk, accept=words, accept_num_docs=max_doc)
                 got = gpu.search_batch(q, k, rk, accept=words, accept_num_docs=max_doc)
                 _assert_same(got, want, f"sim={sim} M={pq_M} frac={frac} k={k} rk={rk}")
