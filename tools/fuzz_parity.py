@@ -18,7 +18,7 @@ def run(budget, seed0):
     while time.time() - t0 < budget:
         seed = seed0 + cases
         rng = np.random.default_rng(seed)
-        n = int(rng.integers(150, 2500))
+        n = int(rng.integers(150, int(os.environ.get("FUZZ_NMAX", 2500))))   # FUZZ_NMAX=9000: pools of the 4 096-entry launches too
         R = int(rng.choice([8, 16, 32]))
         sim = int(rng.integers(0, 3))
         M = int(rng.choice([2, 4, 16, 32]))
@@ -58,7 +58,7 @@ def run(budget, seed0):
             if sim == 2:
                 q[:, 0] += 1.0
         for _ in range(4):
-            rk = int(rng.choice([1, 3, 10, 40, 100, 192, 200, 400, 900, 1500]))
+            rk = int(rng.choice([1, 3, 10, 40, 100, 192, 200, 400, 900, 1500, 2500, 3900]))
             rk = min(rk, n)
             k = int(min(rk, rng.choice([1, 5, 10, 50])))
             kw = {}
