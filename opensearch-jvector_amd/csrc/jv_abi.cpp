@@ -44,6 +44,14 @@ int jvk_pqp_max_entries(void);
 int jvk_pqp_blocks_per_cu(const JvIndexDev* ix, int cap, int lds_bytes, int lutr, int filt);
 int jvk_pqp_lutr_ok(const JvIndexDev* ix, int cap);
 hipError_t jvk_launch_search_pqp(const JvIndexDev* ix, const JvSearchArgs* a, int lds_bytes, int blocks, int lutr, hipStream_t s);
+// the same search with pq_M / 16 waves per query, the look-up table in registers split by chunk (jv_kernels_pqw.hip)
+hipError_t jvk_pqw_set_max_lds(int bytes);
+int jvk_pqw_ok(const JvIndexDev* ix, int cap);
+int jvk_pqw_waves(const JvIndexDev* ix);
+int jvk_pqw_lds_rows(void);
+int jvk_pqw_blocks_per_cu(const JvIndexDev* ix, int cap, int lds_bytes);
+hipError_t jvk_launch_search_pqw(const JvIndexDev* ix, const JvSearchArgs* a, int lds_bytes, int blocks, hipStream_t s);
+void jvk_pqw_set_occ3(int on);
 }
 
 namespace {
@@ -73,7 +81,8 @@ int fail(int code, const char* fmt, ...) {
 // Tunables.  Every index carries its own set (jv_index_set_option); jv_set_option only changes the DEFAULTS that
 // indexes created afterwards start from — nothing process-wide is read at call time.
 //   lds_visited_slots / lds_candidates   on-chip scratch geometry of the generic kernels (0 = auto)
-//   force_big_path / force_general_path / no_escalation / no_pqf / no_pqp / no_lutr / pqf_only   rung selection (diagnostics)
+//   force_big_path / force_general_path / no_escalation / no_pqf / no_pqp / no_pqw / no_lutr / pqf_only   rung selection (diagnostics)
+//   pqw_min_queries                      launches with at least this many queries use the several-waves-per-query kernel
 //   spill_tables x spill_slots           per-context pool of visited-set spill tables (512 x 8192 x 4 B = 16 MB, allocated on first use)
 //   big_blocks / big_cand_cap / big_budget_mb   HBM-scratch rung: resident blocks (0 = as many as fit the budget), candidate slots
 //   combine / combine_leaders / combine_max_batch   group commit of concurrent jv_search calls
@@ -81,7 +90,7 @@ int fail(int code, const char* fmt, ...) {
 //   filter_cache                         device-resident doc-filter bitsets kept per index (0 = off)
 //   lutr_min_queries                     launches with more queries keep the PQ look-up table in registers (-1 = 4 per CU)
 //   dbg_ptr                              diagnostic build only
-enum OptId { OPT_LDS_VISITED_SLOTS, OPT_LDS_CANDIDATES, OPT_FORCE_BIG, OPT_FORCE_GENERAL, OPT_NO_ESCALATION, OPT_DBG_PTR, OPT_NO_PQF, OPT_NO_PQP, OPT_NO_LUTR, OPT_LUTR_MIN_QUERIES, OPT_PQP_BLOCKS_PER_CU, OPT_PQF_ONLY, OPT_SPILL_TABLES, OPT_SPILL_SLOTS, OPT_BIG_BLOCKS, OPT_BIG_CAND_CAP, OPT_BIG_BUDGET_MB, OPT_COMBINE, OPT_COMBINE_LEADERS, OPT_COMBINE_MAX_BATCH, OPT_MAX_CONTEXTS, OPT_FILTER_CACHE, OPT_COUNT };
+enum OptId { OPT_LDS_VISITED_SLOTS, OPT_LDS_CANDIDATES, OPT_FORCE_BIG, OPT_FORCE_GENERAL, OPT_NO_ESCALATION, OPT_DBG_PTR, OPT_NO_PQF, OPT_NO_PQP, OPT_NO_LUTR, OPT_LUTR_MIN_QUERIES, OPT_PQP_BLOCKS_PER_CU, OPT_NO_PQW, OPT_PQW_MIN_QUERIES, OPT_PQW_OCC3, OPT_PQF_ONLY, OPT_SPILL_TABLES, OPT_SPILL_SLOTS, OPT_BIG_BLOCKS, OPT_BIG_CAND_CAP, OPT_BIG_BUDGET_MB, OPT_COMBINE, OPT_COMBINE_LEADERS, OPT_COMBINE_MAX_BATCH, OPT_MAX_CONTEXTS, OPT_FILTER_CACHE, OPT_COUNT };
 struct OptName { const char* name; int64_t def; };
 const OptName kOptNames[OPT_COUNT] = {
     {"lds_visited_slots", 0},
@@ -95,6 +104,9 @@ const OptName kOptNames[OPT_COUNT] = {
     {"no_lutr", 0},
     {"lutr_min_queries", -1},
     {"pqp_blocks_per_cu", 0},
+    {"no_pqw", 0},
+    {"pqw_min_queries", 0},
+    {"pqw_occ3", 0},
     {"pqf_only", 0},
     {"spill_tables", 512},
     {"spill_slots", 8192},
@@ -506,8 +518,9 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
     //  kernel at rerankK = 160 —, else round 1's kernel, which is the faster one against the LDS-table variant there)
     const int64_t lutr_min_q = OPT(ix, OPT_LUTR_MIN_QUERIES) >= 0 ? OPT(ix, OPT_LUTR_MIN_QUERIES) : 4 * (int64_t)ix->cu_count;
     const bool lutr_applies = OPT(ix, OPT_NO_LUTR) == 0 && jvk_pqp_lutr_ok(&ix->dev, rk + 64 + ix->dev.R) && nq > lutr_min_q;
+    const bool pqw_applies = !filtered && OPT(ix, OPT_NO_PQW) == 0 && jvk_pqw_ok(&ix->dev, rk + 64 + ix->dev.R) && nq >= OPT(ix, OPT_PQW_MIN_QUERIES);
     const bool pqp_plain = !filtered && g.pool && ix->dev.n < (1 << 30) &&
-                           (rk + 64 + ix->dev.R > 256 || OPT(ix, OPT_LUTR_MIN_QUERIES) == 0 || lutr_applies);
+                           (rk + 64 + ix->dev.R > 256 || OPT(ix, OPT_LUTR_MIN_QUERIES) == 0 || lutr_applies || pqw_applies);
     // (measured at rerankK = 160, 2M docs, 65 536 queries per launch, selectivity 0.9 / 0.5 / 0.3 / 0.15: round 1's filtered
     //  kernel 1.33 M / 0.90 M / 0.27 M / 37 k QPS, this kernel's register-table variant 1.64 M / 1.07 M / 0.68 M / 227 k)
     const bool pqp_filt = filtered && pqf_shape && ix->dev.n < (1 << 29) &&
@@ -549,7 +562,24 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
             x.pqp_lds_bytes = lds;
             return lds;
         };
-        const int lds = plan(ap, lutr != 0);
+        // Several waves per query (jv_kernels_pqw.hip: PQ-32 / PQ-64, unfiltered): table in registers split by chunk, one
+        // wave per chunk.  LDS = [pool | centred query | hash set | rerank scratch] + the waves' exchange rows + ctrl words.
+        const bool pqw = !filtered && OPT(ix, OPT_NO_PQW) == 0 && jvk_pqw_ok(&ix->dev, ap.cand_cap) && nq >= OPT(ix, OPT_PQW_MIN_QUERIES);
+        if (pqw) jvk_pqw_set_occ3(OPT(ix, OPT_PQW_OCC3) != 0 ? 1 : 0);  // (diagnostic switch, process-wide)
+        auto plan_w = [&](JvSearchArgs& x) {
+            const int Wn = jvk_pqw_waves(&ix->dev);
+            const int pool_b = (x.cand_cap + 1) * 8;
+            const int rr_b = qc_b + Wn * JV_TODO * 8 + (x.cand_cap + 64) * 8;
+            x.pqw_lut_off = (std::max(pool_b, qc_b) + 15) & ~15;  // table rows kept in LDS, behind the pool / the centred query
+            const int lut_end = x.pqw_lut_off + Wn * jvk_pqw_lds_rows() * 1024;
+            const int front = (std::max(std::max(16384, lut_end), std::max(qc_b, rr_b)) + 15) & ~15;
+            x.pqp_pool_off = 0;
+            x.pqp_qc_off = 0;
+            x.pqp_scratch_off = front;
+            x.pqp_lds_bytes = front + Wn * 256 + 64 + 128;  // (+ the diagnostic build's phase accumulators)
+            return x.pqp_lds_bytes;
+        };
+        const int lds = pqw ? plan_w(ap) : plan(ap, lutr != 0);
         // second launch for what outgrows the first (more than 63 ties at the rerankK boundary, a longer expansion log):
         // table in LDS, as many tie slots as the largest pool class allows, 4x the log; walks the flag array
         JvSearchArgs ap2 = ap;
@@ -560,7 +590,7 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
         const int lds2 = plan(ap2, false);
         const bool second = lds2 <= kMaxLds && ap2.cand_cap > ap.cand_cap && OPT(ix, OPT_PQF_ONLY) == 0;
         if (lds <= kMaxLds) {
-            int per_cu = jvk_pqp_blocks_per_cu(&ix->dev, ap.cand_cap, lds, lutr, filtered ? 1 : 0);
+            int per_cu = pqw ? jvk_pqw_blocks_per_cu(&ix->dev, ap.cand_cap, lds) : jvk_pqp_blocks_per_cu(&ix->dev, ap.cand_cap, lds, lutr, filtered ? 1 : 0);
             if (OPT(ix, OPT_PQP_BLOCKS_PER_CU) > 0) per_cu = (int)std::min<int64_t>(per_cu, OPT(ix, OPT_PQP_BLOCKS_PER_CU));  // diagnostics
             int blocks = ix->cu_count * per_cu;
             if (blocks > nq) blocks = nq;
@@ -578,7 +608,8 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
             }
             ap.pqp_log = c->pqp_log;
             ap.pqp_counter = c->work_counter + 6;
-            HIPCHK(jvk_launch_search_pqp(&ix->dev, &ap, lds, blocks, lutr, stream));
+            if (pqw) HIPCHK(jvk_launch_search_pqw(&ix->dev, &ap, lds, blocks, stream));
+            else HIPCHK(jvk_launch_search_pqp(&ix->dev, &ap, lds, blocks, lutr, stream));
             if (second) {
                 ap2.pqp_log = c->pqp_log;
                 HIPCHK(jvk_launch_search_pqp(&ix->dev, &ap2, lds2, blocks2, 0, stream));
@@ -969,6 +1000,7 @@ int jv_index_create(const jv_index_desc* desc, jv_index** out) {
         }
         TRYHIP(jvk_set_max_lds(kMaxLds));
         TRYHIP(jvk_pqp_set_max_lds(kMaxLds));
+        TRYHIP(jvk_pqw_set_max_lds(kMaxLds));
         {
             hipDeviceProp_t prop;
             if (hipGetDeviceProperties(&prop, desc->device) == hipSuccess && prop.multiProcessorCount > 0) ix->cu_count = prop.multiProcessorCount;

@@ -89,6 +89,7 @@ struct JvSearchArgs {
     int32_t pqp_scratch_off; // LDS byte offset of the 768-byte merge scratch (kept keys + ranks of one expansion)
     int32_t pqp_lds_bytes;   // dynamic LDS bytes of the launch (register-LUT variant: the visited-count hash set uses all of it)
     int32_t* pqp_counter;    // query dequeue counter (zeroed per call)
+    int32_t pqw_lut_off;     // several-waves kernel: LDS byte offset of the table rows kept in LDS ([W][NL][256] floats)
 };
 
 #define JV_FLAG_OVERFLOW 0x80000000u /* on-chip scratch overflow: query must be re-run on the big path */

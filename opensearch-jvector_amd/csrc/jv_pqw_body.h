@@ -1,0 +1,893 @@
+// jv_pqw_body.h — the persistent pool kernel with SEVERAL WAVES PER QUERY (round 3; instances in jv_kernels_pqw.hip).
+//
+// Same search as jv_pqp_body.h (GraphSearcher.search as called from J/JVectorReader.java:165-173, PQ provider, no filter,
+// threshold <= 0, flat graph) and the same single sorted pool in LDS, but one query is run by a
+// workgroup of W = pq_M / 16 waves:
+//   * the PQ look-up table lives in registers, SPLIT BY CHUNK: wave w holds subspaces 16 w .. 16 w + 15 (64 VGPRs
+//     instead of 128) and scores that chunk for every neighbour of the expanded node; the W chunk sums of a neighbour meet
+//     in the adjacent-pair tree of the canonical order (oracle/jv_oracle.c jvo_pq_score: 16-subspace chunks summed left to
+//     right, chunks combined pairwise) — for W = 2 that is ONE add, so scores stay bit-equal;
+//   * wave 0 owns the pool (best unexpanded entry, rank search, insert, boundary); the other waves hand their chunk sums
+//     over through 256 B of LDS per wave and two workgroup barriers per expansion;
+//   * after the loop all waves share the visited-count pass (one LDS hash set, compare-and-swap from every wave; the log
+//     groups are dealt round robin) and the exact rerank (64-entry batches dealt round robin);
+// Register budget per wave: 64 (table) + the working set, 128 VGPRs at 4 waves per SIMD — the one-wave kernel needed
+// 256 VGPRs + 320 B of scratch per lane.
+#pragma once
+#include "jv_pqp_body.h"
+
+// LDS-only workgroup barrier: waits for this wave's LDS operations, NOT for its global loads (a __syncthreads() would
+// drain the prefetched fused block with vmcnt(0))
+__device__ __forceinline__ void pqw_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// order this wave's own LDS traffic (one wave's lanes exchanging data through LDS)
+__device__ __forceinline__ void pqw_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// keeps a uniform base address on the scalar unit: without it the compiler folds the per-lane offset into a hoisted
+// 64-bit VGPR base, which it then spills (every reload is a vmcnt(0) that drains the prefetched block as well)
+typedef const __attribute__((address_space(1))) unsigned char* pqw_gptr;
+__device__ __forceinline__ pqw_gptr pqw_scalar_base(const void* p) {
+    const uint64_t u = (uint64_t)(uintptr_t)p;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
+    pqw_gptr q = (pqw_gptr)(uintptr_t)(((uint64_t)hi << 32) | lo);
+    asm volatile("" : "+s"(q));
+    return q;
+}
+// (the empty asm keeps the 32-bit lane offset's zero-extension next to the load, where the instruction selector can fold
+//  it into the "scalar base + 32-bit VGPR offset" form; hoisted out of the loop it becomes a 64-bit VGPR pair that spills)
+__device__ __forceinline__ int pqw_ld_i32(pqw_gptr base, uint32_t off) {
+    asm volatile("" : "+v"(off));
+    return *(const __attribute__((address_space(1))) int*)(base + off);
+}
+__device__ __forceinline__ u32x4 pqw_ld_u32x4(pqw_gptr base, uint32_t off) {
+    asm volatile("" : "+v"(off));
+    return *(const __attribute__((address_space(1))) u32x4*)(base + off);
+}
+
+// Diagnostic build only (-DJV_STAMPS): this kernel keeps its per-phase cycle accumulators in LDS (behind the ctrl
+// words) — sixteen 64-bit accumulators in scalar registers cost the loop its register budget and moved the very waits
+// the stamps were meant to find.
+#ifdef JV_STAMPS
+#define PQW_STAMP_DECL unsigned long long* const stl = (unsigned long long*)(smem + a.pqp_scratch_off + W * 256 + 64); unsigned long long st_last = clock64();
+#define PQW_STAMP(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = clock64(); if (lane == 0) stl[i] += t_ - st_last; st_last = t_; __builtin_amdgcn_sched_barrier(0); }
+#define PQW_STAMP_COUNT(i, v) { if (lane == 0) stl[i] += (unsigned long long)(v); }
+#define PQW_STAMP_FLUSH if (lane == 0) { for (int i_ = 0; i_ < 16; i_++) { if (a.dbg) atomicAdd((unsigned long long*)a.dbg + i_, stl[i_]); stl[i_] = 0ull; } }
+#else
+#define PQW_STAMP_DECL
+#define PQW_STAMP(i) {}
+#define PQW_STAMP_COUNT(i, v) {}
+#define PQW_STAMP_FLUSH {}
+#endif
+
+// KEY_MIN materialised where it is stored (hoisted out of the search loop the 64-bit constant becomes a spilled VGPR pair)
+__device__ __forceinline__ int64_t pqw_key_min() {
+    int lo = 0, hi = (int)0x80000000;
+    asm volatile("" : "+v"(lo), "+v"(hi));
+    return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint64_t)(uint32_t)lo);
+}
+
+// ctrl words (ints) behind the exchange area
+enum { PQW_C = 0, PQW_C2 = 1, PQW_WHY = 2, PQW_NP = 3, PQW_NEXP = 4, PQW_EXPANDED = 5, PQW_QI = 6, PQW_AGAIN = 7, PQW_CNT = 8 /* [W <= 4] */, PQW_C3 = 12, PQW_C4 = 13 };
+
+// NCHT: row length in 64-float chunks known at compile time (rerank), 0 = any d
+// CAPK: pool capacity class: 0 -> <= 512 entries, 1 -> <= 1 024, 2 -> <= 2 048
+// W:    waves per query = pq_M / 16 (1, 2 or 4)
+// NL:   the first NL of a wave's 16 subspaces keep their table rows in LDS (plain gathers) instead of registers: every
+//       look-up served from LDS saves four ds_bpermute — the LDS unit is this kernel's busiest resource — and four VGPRs
+template <int NCHT, int CAPK, int W, int NL>
+__device__ void search_one_pqw(const JvIndexDev& ix, const JvSearchArgs& a, const int qi, unsigned char* smem, int32_t* explog) {
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int rk = a.rk, topK = a.topK;
+    const int R = ix.R, cs = ix.pq_code_stride;
+    float* qc_lds = (float*)(smem + a.pqp_qc_off);  // centred query, only during the LUT build (aliases the pool)
+    float* xchg = (float*)(smem + a.pqp_scratch_off);             // [W][64] chunk sums (row 0 unused)
+    int* ctrl = (int*)(smem + a.pqp_scratch_off + W * 256);       // PQW_* words
+    const int log_cap = a.pqp_log_cap;
+    int32_t* o_nodes = a.out_nodes + (size_t)qi * topK;
+    int32_t* o_docs = a.out_docs ? a.out_docs + (size_t)qi * topK : nullptr;
+    float* o_scores = a.out_scores + (size_t)qi * topK;
+
+    // ---- centred query -> this wave's 16 subspaces of the look-up table, in registers ----
+    const float* qg = a.queries + (size_t)qi * ix.d;
+    for (int i = threadIdx.x; i < ix.nch * 64; i += JV_WAVE * W) {
+        float v = i < ix.d ? qg[i] : 0.0f;
+        if (ix.pq_centroid && i < ix.d) v = v - ix.pq_centroid[i];
+        qc_lds[i] = v;
+    }
+    __syncthreads();
+    float* const lutl = (float*)(smem + a.pqw_lut_off) + wv * NL * 256;  // [NL][256] this wave's LDS rows
+    float lutr[16 - NL][4];  // lutr[i - NL][e], lane l = lut[16 wv + i][4 l + e]
+    {
+        const bool l2 = ix.sim == 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {  // (same fmaf chains as build_lut)
+            const int m = 16 * wv + i;
+            const int d0 = ix.pq_sub_off[m], d1 = ix.pq_sub_off[m + 1];
+            float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+            constexpr int PF = 8;
+            for (int db = d0; db < d1; db += PF) {
+                f32x4 cb[PF];
+#pragma unroll
+                for (int u = 0; u < PF; u++) {
+                    if (db + u < d1) cb[u] = *(const f32x4*)(ix.pq_cbT + (size_t)(db + u) * 256 + 4 * lane);
+                    else cb[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int u = 0; u < PF; u++) {
+                    if (db + u < d1) {
+                        const float qc = qc_lds[db + u];
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            if (l2) {
+                                const float df = qc - cb[u][e];
+                                acc4[e] = fmaf(df, df, acc4[e]);
+                            } else {
+                                acc4[e] = fmaf(qc, cb[u][e], acc4[e]);
+                            }
+                        }
+                    }
+                }
+            }
+            if (i < NL) {
+                *(f32x4*)(lutl + i * 256 + 4 * lane) = (f32x4){acc4[0], acc4[1], acc4[2], acc4[3]};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; e++) lutr[i < NL ? 0 : i - NL][e] = acc4[e];
+            }
+        }
+    }
+    __syncthreads();  // every wave is done with qc_lds: the pool may overwrite it
+
+    // this wave's chunk of one code row: 16 look-ups summed left to right (the canonical order inside a chunk)
+    auto adc_chunk_regs = [&](const u32x4 cw) -> float {
+        float sum = 0.0f;
+        // the LDS rows first: NL independent gathers, one round trip
+        float tl[NL > 0 ? NL : 1];
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            const uint32_t code = (cw[i >> 2] >> ((i & 3) * 8)) & 0xFFu;
+            tl[i] = lutl[i * 256 + code];
+        }
+#pragma unroll
+        for (int i = 0; i < NL; i++) sum = sum + tl[i];
+        // the 16 ds_bpermute of four look-ups are issued back to back before the first result is consumed
+#pragma unroll
+        for (int g4 = NL; g4 < 16; g4 += 4) {
+            int t[4][4];
+#pragma unroll
+            for (int ii = 0; ii < 4; ii++) {
+                const int i = g4 + ii;
+                const int w = (int)cw[i >> 2];
+                const int addr = (int)(((uint32_t)w >> ((i & 3) * 8)) & 0xFFu);  // ds_bpermute reads lane (addr >> 2) & 63 = code >> 2
+#pragma unroll
+                for (int e = 0; e < 4; e++) t[ii][e] = __builtin_amdgcn_ds_bpermute(addr, __float_as_int(lutr[i - NL][e]));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ii = 0; ii < 4; ii++) {
+                const int i = g4 + ii;
+                const int w = (int)cw[i >> 2];
+                const int sh = (i & 3) * 8;
+                const int m0 = __builtin_amdgcn_sbfe(w, sh, 1), m1 = __builtin_amdgcn_sbfe(w, sh + 1, 1);  // -1 / 0: code bits 0, 1
+                const int s01 = (m0 & t[ii][1]) | (~m0 & t[ii][0]), s23 = (m0 & t[ii][3]) | (~m0 & t[ii][2]);
+                sum = sum + __int_as_float((m1 & s23) | (~m1 & s01));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return sum;
+    };
+    // chunk sums of lane l's node -> raw distance / dot product: adjacent-pair tree over the W chunks (lanes_tree_sum)
+    auto combine = [&](float s0, int l) -> float {
+        if (W == 1) return s0;
+        const float c1 = xchg[64 + l];
+        if (W == 2) return s0 + c1;
+        const float c2 = xchg[128 + l];
+        const float c3 = W == 4 ? xchg[192 + l] : 0.0f;
+        return (s0 + c1) + (c2 + c3);
+    };
+
+    // ---- the pool: sorted descending; bit 0 of a key = "not expanded yet"; slots [np, cap] hold the minimum key ----
+    const int cap = a.cand_cap;  // entries; slot `cap` is a permanent sentinel
+    int64_t* pool = (int64_t*)(smem + a.pqp_pool_off);
+    for (int i = threadIdx.x; i <= cap; i += JV_WAVE * W) pool[i] = KEY_MIN;
+    int np = 0, nexp = 0, expanded = 0, lo_un = 0;
+    int why = 0;
+    int nrej = 0;         // rejected entries in the pool (all at the boundary score)
+    float bscore = 0.0f;  // score of the rk-th best entry once np >= rk
+    {
+        const int ep = ix.entry;
+        u32x4 cw = (u32x4){0, 0, 0, 0};
+        if (lane == 0) cw = *(const u32x4*)(ix.pq_codes + (size_t)ep * cs + wv * 16);
+        const float s = adc_chunk_regs(cw);
+        if (wv > 0 && lane == 0) xchg[wv * 64] = s;
+        __syncthreads();
+        if (wv == 0) {
+            float sc = map_score(ix.sim == 0 ? 0 : 1, combine(s, 0));
+            sc = __shfl(sc, 0, JV_WAVE);
+            if (lane == 0) pool[0] = pqp_key<false>(sc, ep, true);
+            if (rk <= 1) bscore = sc;
+        }
+        np = 1;
+        __syncthreads();
+    }
+
+    // fused block of the expanded node: lane j < R owns neighbour j (its ordinal: wave 0 only; its 16 code bytes of this
+    // wave's chunk); the runner-up's block is requested one expansion ahead
+    // The search loops run as lambdas over an OPAQUE copy of the lane id: everything derived from it (LDS addresses,
+    // block offsets) is then computed after the table build instead of at kernel entry — hoisted that far, those values
+    // live across the register peak of the table build, get spilled, and every reload inside the loop is a vmcnt(0)
+    // that also drains the prefetched block.
+    auto opaque_lane = [&]() -> int {
+        int l = (int)(threadIdx.x & 63);
+        asm volatile("" : "+v"(l));
+        return l;
+    };
+    int pf_nn = -1;
+    u32x4 pf_cw = (u32x4){0, 0, 0, 0};
+    PQW_STAMP_DECL
+    if (wv == 0) PQW_STAMP(7)  // LUT build + entry point
+    if (wv == 0) {
+        // ================================ wave 0: the pool ================================
+        [&](const int lane) {
+        // Two blocks per scoring pass: lanes 0..31 hold the neighbours of the best unexpanded entry, lanes 32..63 those of
+        // the runner-up (R <= 32).  The runner-up's scores wait in their lanes: when it is still the best entry one
+        // expansion later (9 times out of 10) that expansion needs no pass and no barrier at all.
+        const bool pair = 2 * R <= JV_WAVE;
+        const int hf = pair ? lane >> 5 : 0;
+        const int hl = pair ? lane & 31 : lane;
+        const int jl = min(hl, R - 1);
+        const uint32_t cw_off = (uint32_t)(jl * cs + wv * 16);
+        const uint32_t adj_off = (uint32_t)(jl * 4);
+        int sc_node0 = -1, sc_node1 = -1;  // nodes whose neighbours' scores sit in the lower / upper lanes
+        int pf_node0 = -1, pf_node1 = -1;  // nodes whose blocks were requested ahead into the lower / upper lanes
+        float score = 0.0f;
+        int nn = -1;
+        int64_t pv = KEY_MIN;  // lane t: last key of pool chunk t (low bits may be stale: they never decide a comparison with a new key)
+        while (true) {
+            // ---- best unexpanded entry (every position < lo_un is expanded; sentinels have bit 0 clear) ----
+            int t1 = lo_un >> 6;
+            int64_t e1 = 0;
+            unsigned long long m1 = 0ull;
+            for (; (t1 << 6) < np; t1++) {
+                e1 = pool[min((t1 << 6) + lane, cap)];
+                m1 = __ballot((e1 & 1ll) != 0);
+                if (m1) break;
+            }
+            int c = -1, b1 = 0, idx = 0, pk_lo = 0, pk_hi = 0;
+            bool reject = false;
+            const int e1lo = (int)(uint32_t)(e1 & 0xFFFFFFFFll), e1hi = (int)(e1 >> 32);
+            if (m1) {
+                b1 = __ffsll((long long)m1) - 1;
+                idx = (t1 << 6) + b1;
+                pk_lo = __builtin_amdgcn_readlane(e1lo, b1);
+                pk_hi = __builtin_amdgcn_readlane(e1hi, b1);
+                const float sc = hi_score(pk_hi);
+                c = lo_node<false>(pk_lo);
+                if (sc < a.threshold) why = 1;  // a node the two-queue form would expand but not collect: general path
+                else if (nexp >= log_cap) why = 2;
+                else if (a.visit_limit > 0 && expanded >= a.visit_limit) why = 15;  // Lucene discards this search
+                // strict admission (DESIGN.md "Single-pool search"): when the ADMITTED entries scoring >= the candidate
+                // already fill the result queue (the worst result ties with the candidate), jvector expands the candidate
+                // without admitting it
+                if (why == 0 && expanded >= rk && idx < rk + nrej) {
+                    int ge = idx;
+                    int64_t ee = e1;
+                    for (int tt = t1;;) {
+                        const unsigned long long eq = __ballot((int)(ee >> 32) == pk_hi);
+                        unsigned long long ex = eq & ~__ballot((ee & 1ll) != 0);
+                        if (tt == t1) ex &= ~((2ull << b1) - 1ull);  // positions behind the candidate only
+                        ge += __popcll(ex);
+                        tt++;
+                        if (!(eq >> 63) || (tt << 6) >= np) break;  // the equal-score run ends inside this chunk
+                        ee = pool[min((tt << 6) + lane, cap)];
+                    }
+                    if (np >= rk && sc == bscore) ge -= nrej;
+                    reject = ge >= rk;
+                }
+            }
+            c = __builtin_amdgcn_readfirstlane(c);  // (block addresses are computed on the scalar unit)
+            const bool stop = !m1 || why != 0;
+            int half = -1;
+            if (!stop) half = c == sc_node0 ? 0 : (c == sc_node1 ? 1 : -1);
+            PQW_STAMP(15)  // (diagnostic) find proper
+            if (stop || half < 0) {
+                // ---- scoring pass: the next three unexpanded entries as well (runner-up: scored now; the two after it:
+                // their blocks are requested for the next pass) ----
+                int bn1 = -1, bn2 = -1, bn3 = -1;
+                if (!stop) {
+                    unsigned long long mm = m1 & (m1 - 1ull);
+                    int elo = e1lo;
+                    bool second = false;
+#pragma unroll
+                    for (int k = 1; k < 4; k++) {
+                        if (!mm && !second && ((t1 + 1) << 6) < np) {
+                            const int64_t e2 = pool[min(((t1 + 1) << 6) + lane, cap)];
+                            mm = __ballot((e2 & 1ll) != 0);
+                            elo = (int)(uint32_t)(e2 & 0xFFFFFFFFll);
+                            second = true;
+                        }
+                        int nb = -1;
+                        if (mm) {
+                            nb = lo_node<false>(__builtin_amdgcn_readlane(elo, __ffsll((long long)mm) - 1));
+                            mm &= mm - 1ull;
+                        }
+                        if (k == 1) bn1 = nb;
+                        if (k == 2) bn2 = nb;
+                        if (k == 3) bn3 = nb;
+                    }
+                    if (!pair) bn3 = bn2, bn2 = bn1, bn1 = -1;  // one block per pass: the runner-up is only requested ahead
+                }
+                bn1 = __builtin_amdgcn_readfirstlane(bn1);
+                bn2 = __builtin_amdgcn_readfirstlane(bn2);
+                bn3 = __builtin_amdgcn_readfirstlane(bn3);
+                if (W > 1) {
+                    if (lane == 0) {
+                        ctrl[PQW_C] = stop ? -1 : c;
+                        ctrl[PQW_C2] = bn1;
+                        ctrl[PQW_C3] = bn2;
+                        ctrl[PQW_C4] = bn3;
+                    }
+                    pqw_barrier();  // A: the other waves learn which blocks to score
+                }
+                if (stop) break;
+                PQW_STAMP(0)  // barrier A
+                const int wy = bn1 >= 0 ? bn1 : c;  // (no runner-up: the upper lanes score the same block again, unused)
+                u32x4 cw;
+                {
+                    const bool hit = hf ? pf_node1 == wy : pf_node0 == c;
+                    if (hit) {
+                        nn = pf_nn;
+                        cw = pf_cw;
+                    } else {
+                        const int node = hf ? wy : c;
+                        nn = *(const int32_t*)((const unsigned char*)(ix.adj + (size_t)node * (size_t)R) + adj_off);
+                        cw = *(const u32x4*)(ix.pq_fused + (size_t)node * (size_t)R * (size_t)cs + cw_off);
+                    }
+                }
+                if (hl >= R) nn = -1;
+#ifdef JV_STAMPS
+                asm volatile("" ::"v"(nn), "v"(cw));  // (diagnostic) the wait for this pass's blocks lands in phase 9
+#endif
+                PQW_STAMP(9)  // (diagnostic) wait for the blocks
+                // the blocks of the two entries after the runner-up are requested now, UNCONDITIONALLY (clamped): they are
+                // the likely pair of the next pass, two expansions from here
+                pf_node0 = pair ? bn2 : bn2;
+                pf_node1 = bn3;
+                {
+                    const int x = bn2 >= 0 ? bn2 : c, y = bn3 >= 0 ? bn3 : x;
+                    const int node = hf ? y : x;
+                    pf_nn = *(const int32_t*)((const unsigned char*)(ix.adj + (size_t)node * (size_t)R) + adj_off);
+                    pf_cw = *(const u32x4*)(ix.pq_fused + (size_t)node * (size_t)R * (size_t)cs + cw_off);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const float s0 = adc_chunk_regs(cw);
+                if (W > 1) pqw_barrier();  // B: the other waves' chunk sums are in xchg
+                score = map_score(ix.sim == 0 ? 0 : 1, combine(s0, lane));
+#ifdef JV_STAMPS
+                asm volatile("" ::"v"(score));
+#endif
+                sc_node0 = c;
+                sc_node1 = pair ? bn1 : -1;
+                half = 0;
+                PQW_STAMP(2)  // ADC + exchange
+            }
+            // mark the entry expanded; log the node
+            if (lane == b1) ((int*)pool)[2 * idx] = pk_lo & (reject ? ~3 : ~1);
+            nrej += reject ? 1 : 0;
+            if (lane == 0) explog[nexp] = c;
+            nexp++;
+            lo_un = idx + 1;
+            expanded++;
+            if (half == 0) sc_node0 = -1;
+            else sc_node1 = -1;
+            PQW_STAMP(1)
+            bool keep = nn >= 0 && hf == half;
+            if (np >= rk && score < bscore) keep = false;  // below the boundary for good
+            const int64_t v = pqp_key<false>(score, nn, true);
+            // ---- rank of the surviving keys in the pool; "same node" = equal up to the low bits.  Wave-cooperative, one key
+            // at a time (2-3 survive on average): the last key of every 64-entry chunk sits in lane t of `pv` (registers),
+            // one ballot finds the key's chunk, ONE contiguous (conflict-free) chunk read and two more ballots give its
+            // rank and tell whether the node is already in the pool.  Four keys' chunk reads are in flight together.
+            int rold = 0;
+            unsigned long long todo_m = __ballot(keep);
+            if (__popcll(todo_m) > 6) {
+                // many survivors (the pool is still filling: every neighbour is a candidate): per-lane 8-ary search, all
+                // lanes at once, cost independent of their number
+                if (keep) {
+                    int lo = 0;
+                    if (CAPK == 3) lo = rank_level<512, 8>(pool, lo, cap, v);
+                    if (CAPK == 2) lo = rank_level<512, 4>(pool, lo, cap, v);
+                    if (CAPK == 1) lo = rank_level<256, 4>(pool, lo, cap, v);
+                    if (CAPK == 1) lo = rank_level<64, 4>(pool, lo, cap, v);
+                    else lo = rank_level<64, 8>(pool, lo, cap, v);
+                    lo = rank_level<8, 8>(pool, lo, cap, v);
+                    int64_t p3[9];
+#pragma unroll
+                    for (int k2 = 0; k2 < 9; k2++) p3[k2] = pool[min(lo + k2, cap)];
+                    int c3 = 0;
+                    bool dup = false;
+#pragma unroll
+                    for (int k2 = 0; k2 < 9; k2++) {
+                        if (k2 < 8) c3 += p3[k2] > v ? 1 : 0;
+                        dup |= (p3[k2] | 3ll) == v;
+                    }
+                    rold = lo + c3;
+                    if (dup) keep = false;
+                }
+            } else {
+                const int vlo_ = (int)(uint32_t)(v & 0xFFFFFFFFll), vhi_ = (int)(v >> 32);
+                while (todo_m) {
+                    int jj[4], tcs[4];
+                    int64_t kk[4], ee[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        jj[u] = -1;
+                        tcs[u] = 0;
+                        kk[u] = 0;
+                        ee[u] = 0;
+                        if (todo_m) {
+                            const int j = __ffsll((long long)todo_m) - 1;
+                            todo_m &= todo_m - 1ull;
+                            jj[u] = j;
+                            kk[u] = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(vhi_, j) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane(vlo_, j));
+                            tcs[u] = __popcll(__ballot(pv > kk[u]));  // chunks whose last key ranks ahead of the new key
+                            ee[u] = pool[min((tcs[u] << 6) + lane, cap)];
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        if (jj[u] >= 0) {
+                            const int r = (tcs[u] << 6) + __popcll(__ballot(ee[u] > kk[u]));
+                            const bool dup = __ballot((ee[u] | 3ll) == kk[u]) != 0ull;  // same node => same score => same key up to the low bits
+                            if (lane == jj[u]) {
+                                rold = r;
+                                if (dup) keep = false;
+                            }
+                        }
+                    }
+                }
+            }
+            unsigned long long km = __ballot(keep);
+            int nk = __popcll(km);
+            PQW_STAMP_COUNT(8, __popcll(km))
+            PQW_STAMP(3)  // boundary test + rank search + duplicate test
+            if (nk > 0) {
+                int rnew = 0, r_min, r_max;
+                if (nk == 1) {
+                    // the common case: one new key, every entry behind it moves up by one
+                    r_min = r_max = __builtin_amdgcn_readlane(rold, __ffsll((long long)km) - 1);
+                    for (int t = (np - 1) >> 6; t >= (r_min >> 6); t--) {
+                        const int pos = (t << 6) + lane;
+                        const int64_t e = pool[min(pos, cap)];
+                        if (pos < np && pos >= r_min) pool[pos + 1] = e;
+                    }
+                } else {
+                    // every kept key is read out of its lane in turn and compared by all lanes at once: rank among the new
+                    // keys, twins (the same neighbour twice in one adjacency row of a malformed graph: keep the first)
+                    const int vlo = (int)(uint32_t)(v & 0xFFFFFFFFll), vhi = (int)(v >> 32);
+                    for (int attempt = 0; attempt < 2; attempt++) {
+                        rnew = 0;
+                        bool twin = false;
+                        unsigned long long it = km;
+                        while (it) {
+                            const int j = __ffsll((long long)it) - 1;
+                            it &= it - 1ull;
+                            const int64_t kj = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(vhi, j) << 32) |
+                                                         (uint64_t)(uint32_t)__builtin_amdgcn_readlane(vlo, j));
+                            rnew += kj > v ? 1 : 0;
+                            twin |= kj == v && j < lane;
+                        }
+                        const unsigned long long km2 = __ballot(keep && !twin);
+                        if (km2 == km) break;
+                        keep = keep && !twin;
+                        km = km2;
+                        nk = __popcll(km);
+                    }
+                    const int lane_first = __ffsll((long long)__ballot(keep && rnew == 0)) - 1;     // largest new key
+                    const int lane_last = __ffsll((long long)__ballot(keep && rnew == nk - 1)) - 1;  // smallest new key
+                    r_min = __builtin_amdgcn_readlane(rold, lane_first);
+                    r_max = __builtin_amdgcn_readlane(rold, lane_last);
+                    PQW_STAMP(14)  // (diagnostic) ranks among the new keys
+                    // in-place shift, from the last occupied chunk down to the chunk of the first insertion point
+                    const int t_mixed = r_max >> 6;  // chunks above it shift uniformly by nk
+                    for (int t = (np - 1) >> 6; t >= (r_min >> 6); t--) {
+                        const int pos = (t << 6) + lane;
+                        const int64_t e = pool[min(pos, cap)];
+                        int cnt = nk;
+                        if (t <= t_mixed) {
+                            const int cs0 = t << 6;
+                            cnt = __popcll(__ballot(keep && rold <= cs0));
+                            unsigned long long inm = __ballot(keep && rold > cs0 && rold <= cs0 + 63);
+                            while (inm) {
+                                const int j = __ffsll((long long)inm) - 1;
+                                inm &= inm - 1ull;
+                                cnt += pos >= __builtin_amdgcn_readlane(rold, j) ? 1 : 0;
+                            }
+                        }
+                        if (pos < np && cnt > 0) pool[pos + cnt] = e;
+                    }
+                }
+                if (keep) pool[rold + rnew] = v;
+                PQW_STAMP_COUNT(11, nk)
+                PQW_STAMP_COUNT(12, ((np - 1) >> 6) - (r_min >> 6) + 1)
+                PQW_STAMP(4)  // ranks among the new keys + shift + insert
+                // boundary = the rk-th best entry; entries behind it stay only while they tie with its score
+                const int ntot = np + nk;
+                np = ntot;
+                if (ntot >= rk) {
+                    const int bhi = (int)(pool[rk - 1] >> 32);
+                    const float nb = hi_score(bhi);
+                    if (nb != bscore) nrej = 0;  // the boundary rose: every rejected entry (they tied with the old one) falls off below
+                    bscore = nb;
+                    if (ntot > rk) {
+                        const int slack = cap - rk - R;
+                        int run = 0;
+                        for (int p0 = rk;; p0 += JV_WAVE) {
+                            const int64_t eb = pool[min(p0 + lane, cap)];
+                            const unsigned long long mt = __ballot((int)(eb >> 32) == bhi);  // (a sentinel never matches)
+                            if (~mt) {
+                                run += __ffsll((long long)~mt) - 1;
+                                break;
+                            }
+                            run += JV_WAVE;
+                            if (run >= slack) break;
+                        }
+                        if (run >= slack) {
+                            why = 3;  // more boundary ties than this launch tracks: announced at the top of the next round
+                        } else {
+                            np = rk + run;
+                            for (int p0 = np; p0 < ntot; p0 += JV_WAVE)
+                                if (p0 + lane < ntot) pool[p0 + lane] = pqw_key_min();
+                        }
+                    }
+                }
+                if (lane >= (r_min >> 6)) pv = pool[min((lane << 6) + 63, cap)];  // chunks from the first insertion point on changed
+                lo_un = lo_un < r_min ? lo_un : r_min;
+                PQW_STAMP(5)  // boundary + trim
+                if (why != 0) {  // (why = 3) leave through the common exit so that every wave sees it
+                    if (W > 1) {
+                        if (lane == 0) ctrl[PQW_C] = -1;
+                        pqw_barrier();
+                    }
+                    break;
+                }
+            }
+        }
+        PQW_STAMP(5)
+        if (why == 0 && nrej > 0) {
+            // take the rejected entries out: what remains in front is jvector's result queue
+            int carry = 0;
+            for (int t = 0; (t << 6) < np; t++) {
+                const int pos = (t << 6) + lane;
+                const int64_t e = pool[min(pos, cap)];
+                const bool rej = pos < np && !(e & 2ll);
+                const unsigned long long rm = __ballot(rej);
+                const int shift = carry + __popcll(rm & ((1ull << lane) - 1ull));
+                if (pos < np && !rej && shift > 0) pool[pos - shift] = e;
+                carry += __popcll(rm);
+            }
+            for (int p0 = np - carry; p0 < np; p0 += JV_WAVE)
+                if (p0 + lane < np) pool[p0 + lane] = KEY_MIN;
+            np -= carry;
+        }
+        if (lane == 0) {
+            ctrl[PQW_WHY] = why;
+            ctrl[PQW_NP] = np;
+            ctrl[PQW_NEXP] = nexp;
+            ctrl[PQW_EXPANDED] = expanded;
+        }
+        // the log was written by lane 0 and is read back by every wave: drain the stores (read side: L1-bypassing loads)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        }(opaque_lane());
+    } else {
+        // ================================ waves 1 .. W-1: chunk sums ================================
+        [&](const int lane) {
+        const bool pair = 2 * R <= JV_WAVE;
+        const int hf = pair ? lane >> 5 : 0;
+        const int hl = pair ? lane & 31 : lane;
+        const int jl = min(hl, R - 1);
+        const uint32_t cw_off = (uint32_t)(jl * cs + wv * 16);
+        int pf_node0 = -1, pf_node1 = -1;
+        while (true) {
+            pqw_barrier();  // A
+            const int c = __builtin_amdgcn_readfirstlane(ctrl[PQW_C]);
+            const int bn1 = __builtin_amdgcn_readfirstlane(ctrl[PQW_C2]);
+            const int bn2 = __builtin_amdgcn_readfirstlane(ctrl[PQW_C3]);
+            const int bn3 = __builtin_amdgcn_readfirstlane(ctrl[PQW_C4]);
+            if (c < 0) break;
+            const int wy = bn1 >= 0 ? bn1 : c;
+            u32x4 cw;
+            {
+                const bool hit = hf ? pf_node1 == wy : pf_node0 == c;
+                if (hit) {
+                    cw = pf_cw;
+                } else {
+                    const int node = hf ? wy : c;
+                    cw = *(const u32x4*)(ix.pq_fused + (size_t)node * (size_t)R * (size_t)cs + cw_off);
+                }
+            }
+            pf_node0 = bn2;
+            pf_node1 = bn3;
+            {
+                const int x = bn2 >= 0 ? bn2 : c, y = bn3 >= 0 ? bn3 : x;
+                const int node = hf ? y : x;
+                pf_cw = *(const u32x4*)(ix.pq_fused + (size_t)node * (size_t)R * (size_t)cs + cw_off);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const float s = adc_chunk_regs(cw);
+            xchg[wv * 64 + lane] = s;
+            pqw_barrier();  // B
+        }
+        }(opaque_lane());
+    }
+    __syncthreads();
+    why = __builtin_amdgcn_readfirstlane(ctrl[PQW_WHY]);
+    np = __builtin_amdgcn_readfirstlane(ctrl[PQW_NP]);
+    nexp = __builtin_amdgcn_readfirstlane(ctrl[PQW_NEXP]);
+    expanded = __builtin_amdgcn_readfirstlane(ctrl[PQW_EXPANDED]);
+
+    // the pool moves to registers (chunk t to wave t % W) so that the whole LDS allocation can serve as the hash set
+    constexpr int PCH = 32 / W;
+    int PL[PCH], PH[PCH];
+    if (why == 0) {
+#pragma unroll
+        for (int u = 0; u < PCH; u++) {
+            const int t = u * W + wv;
+            PL[u] = 0;
+            PH[u] = (int)0x80000000;
+            if ((t << 6) < np) {
+                const int64_t e = pool[min((t << 6) + lane, cap)];
+                PL[u] = (int)(uint32_t)(e & 0xFFFFFFFFll);
+                PH[u] = (int)(e >> 32);
+            }
+        }
+    }
+    __syncthreads();
+    int visited = 0;
+    if (why == 0) {
+        // ---- jvector's visitedCount: distinct neighbours of the expanded nodes, entry point excluded; `parts` hash
+        // classes are counted one after the other when one table cannot hold them all ----
+        uint32_t* vh = (uint32_t*)smem;
+        const int hash_bytes = a.pqp_scratch_off;  // everything in front of the exchange / ctrl words
+        int vslots = 1;
+        while (vslots * 2 * 4 <= hash_bytes) vslots <<= 1;
+        const uint32_t vmask = (uint32_t)vslots - 1u;
+        const int vshift = 32 - (31 - __clz(vslots));
+        const int vlimit = (vslots / 16) * 13;
+        const int vlimit_w = vlimit / W;  // fresh entries one wave may add per class
+        int parts = 1;
+        while (parts < 64 && (long long)nexp * 7 > (long long)vlimit * parts * 2) parts <<= 1;
+        const int rows_per = JV_WAVE / R;
+        constexpr int VB = 8;             // adjacency batches per group
+        const int G = rows_per * VB;      // log entries per group: 16 at R = 32 (divides 64: one log chunk)
+        bool again = true;
+        while (again && why == 0) {
+            again = false;
+            visited = 0;
+            for (int p = 0; p < parts && !again; p++) {
+                __syncthreads();
+                for (int i = threadIdx.x; i < vslots; i += JV_WAVE * W) vh[i] = HASH_EMPTY;
+                if (threadIdx.x == 0) ctrl[PQW_AGAIN] = 0;
+                __syncthreads();
+                auto part_of = [&](uint32_t node) -> int { return (int)(((node * 0x85EBCA6Bu) >> 20) & (uint32_t)(parts - 1)); };
+                if (threadIdx.x == 0 && part_of((uint32_t)ix.entry) == p) visited_insert_lds(vh, vmask, vshift, (uint32_t)ix.entry);
+                __syncthreads();
+                int cnt = 0;
+                bool over = false;
+                // The log is pulled into registers 2 048 entries at a time; this wave takes every W-th group of rows; two
+                // groups are kept in flight ahead of the one that probes.  Loads are unconditional with clamped indices.
+                for (int blk0 = 0; blk0 < nexp && !over; blk0 += 2048) {
+                    const int nblk = min(2048, nexp - blk0);
+                    i32x32 logv;
+#pragma unroll
+                    for (int g = 0; g < 32; g++) {
+                        logv[g] = 0;
+                        if (g * 64 < nblk)
+                            logv[g] = __hip_atomic_load(&explog[blk0 + min(g * 64 + lane, nblk - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    const int e_last = (nblk - 1) / G * G;  // first entry of the last group
+                    auto load_group = [&](int e0, int (&dst)[VB]) {
+                        const int e0c = min(e0, e_last);
+                        const int cur = logv[__builtin_amdgcn_readfirstlane(e0c >> 6)];
+#pragma unroll
+                        for (int u = 0; u < VB; u++) {
+                            const int e = min(e0c + u * rows_per + lane / R, nblk - 1);
+                            const int node = __builtin_amdgcn_ds_bpermute((e & 63) << 2, cur);
+                            dst[u] = ix.adj[(size_t)node * R + (lane % R)];
+                        }
+                    };
+                    int q0[VB], q1[VB];
+                    const int step = G * W;
+                    load_group(wv * G, q0);
+                    load_group(wv * G + step, q1);
+                    for (int e0 = wv * G; e0 < nblk; e0 += step) {
+                        int nb[VB];
+#pragma unroll
+                        for (int u = 0; u < VB; u++) {
+                            const int e = e0 + u * rows_per + lane / R;
+                            nb[u] = (e < nblk && lane < rows_per * R) ? q0[u] : -1;
+                            if (nb[u] >= 0 && parts > 1 && part_of((uint32_t)nb[u]) != p) nb[u] = -1;
+                            q0[u] = q1[u];
+                        }
+                        load_group(e0 + 2 * step, q1);
+                        int pending = 0;
+#pragma unroll
+                        for (int u = 0; u < VB; u++) pending += __popcll(__ballot(nb[u] >= 0));
+                        if (cnt + pending > vlimit_w) {
+                            over = true;
+                            break;
+                        }
+                        uint32_t hh[VB];
+                        bool pend[VB];
+#pragma unroll
+                        for (int u = 0; u < VB; u++) {
+                            pend[u] = nb[u] >= 0;
+                            hh[u] = ((uint32_t)nb[u] * 0x9E3779B1u) >> vshift;
+                        }
+                        for (;;) {
+                            uint32_t oldv[VB];
+#pragma unroll
+                            for (int u = 0; u < VB; u++) oldv[u] = pend[u] ? atomicCAS(&vh[hh[u]], HASH_EMPTY, (uint32_t)nb[u]) : 0u;
+                            bool more = false;
+#pragma unroll
+                            for (int u = 0; u < VB; u++) {
+                                const bool fresh = pend[u] && oldv[u] == HASH_EMPTY;
+                                cnt += __popcll(__ballot(fresh));
+                                if (pend[u]) {
+                                    if (fresh || oldv[u] == (uint32_t)nb[u]) pend[u] = false;
+                                    else hh[u] = (hh[u] + 1) & vmask, more = true;
+                                }
+                            }
+                            if (!__any(more)) break;
+                        }
+                    }
+                }
+                if (over && lane == 0) ctrl[PQW_AGAIN] = 1;
+                visited += cnt;
+                __syncthreads();
+                again = __builtin_amdgcn_readfirstlane(ctrl[PQW_AGAIN]) != 0;
+            }
+            if (again) {
+                parts <<= 1;
+                if (parts > 64) why = 4;
+            }
+        }
+        if (lane == 0) ctrl[PQW_CNT + wv] = visited;
+        __syncthreads();
+        visited = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < W; w2++) visited += __builtin_amdgcn_readfirstlane(ctrl[PQW_CNT + w2]);
+        // (the entry point went into its class's set before the counted inserts: it is never counted)
+    }
+    if (wv == 0) {
+        PQW_STAMP(6)  // visited-count pass
+        PQW_STAMP_FLUSH
+    }
+    const int nres = np < rk ? np : rk;
+    // ---- rerank scratch: query, per-wave todo lists, the pool / exact keys ----
+    float* q_lds = (float*)smem;
+    size_t roff = (size_t)ix.nch * 64 * sizeof(float);
+    float* todo_score = (float*)(smem + roff) + wv * JV_TODO;
+    roff += (size_t)W * JV_TODO * sizeof(float);
+    int32_t* todo = (int32_t*)(smem + roff) + wv * JV_TODO;
+    roff += (size_t)W * JV_TODO * sizeof(int32_t);
+    int64_t* fin = (int64_t*)(smem + roff);  // [np] the pool comes back here; the exact keys overwrite it in place
+    __syncthreads();
+    if (why == 0) {
+#pragma unroll
+        for (int u = 0; u < PCH; u++) {
+            const int t = u * W + wv;
+            if ((t << 6) < np) fin[(t << 6) + lane] = (int64_t)(((uint64_t)(uint32_t)PH[u] << 32) | (uint64_t)(uint32_t)PL[u]);
+        }
+        for (int i = threadIdx.x; i < ix.nch * 64; i += JV_WAVE * W) q_lds[i] = i < ix.d ? qg[i] : 0.0f;
+    }
+    __syncthreads();
+    int above = 0;
+    if (why == 0) {
+        for (int i = lane; i < nres; i += JV_WAVE) above += key_score(fin[i]) >= a.rerank_floor ? 1 : 0;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) above += __shfl_xor(above, o, JV_WAVE);
+        // rerankFloor above every approximate score AND a tie at the best one: jvector rescores the first best entry of
+        // its result heap's array, which only the HBM-scratch rung reconstructs (replay_first_best)
+        if (above == 0 && nres >= 2 && key_score(fin[0]) == key_score(fin[1])) why = 6;
+    }
+    if (why != 0) {
+        if (wv == 0) {
+            if (lane == 0) {
+                a.out_flags[qi] = why == 15 ? (int32_t)JV_FLAG_EARLY : (int32_t)(JV_FLAG_OVERFLOW | ((uint32_t)why << 8));
+                a.out_count[qi] = 0;
+                if (why == 15) {
+                    int32_t* st = a.out_stats + (size_t)qi * 4;
+                    st[0] = 0;
+                    st[1] = 0;
+                    st[2] = expanded;
+                    st[3] = expanded;
+                }
+            }
+            for (int i = lane; i < topK; i += JV_WAVE) {
+                o_nodes[i] = -1;
+                if (o_docs) o_docs[i] = -1;
+                o_scores[i] = 0.0f;
+            }
+        }
+        return;
+    }
+    // ---- rerank (NodeQueue.rerank) with the exact scorer: 64-entry batches dealt round robin to the waves ----
+    float qnorm2 = 0.0f;
+    if (ix.sim == 2) qnorm2 = query_norm2(ix, q_lds, lane), qnorm2 = __shfl(qnorm2, 0, JV_WAVE);
+    __syncthreads();  // every wave has read fin[0], fin[1] and counted `above` before the first exact key lands
+    for (int b0 = wv * JV_WAVE; b0 < nres; b0 += JV_WAVE * W) {
+        const int i = b0 + lane;
+        bool take = false;
+        int node = 0;
+        if (i < nres) {
+            const int64_t k = fin[i];
+            node = lo_node<false>((int)(uint32_t)(k & 0xFFFFFFFFll));
+            take = above > 0 ? key_score(k) >= a.rerank_floor : i == 0;  // position 0 is the best approximate entry
+        }
+        const unsigned long long tm = __ballot(take);
+        const int m = __popcll(tm);
+        const int slot = __popcll(tm & ((1ull << lane) - 1ull));
+        if (take) todo[slot] = node;
+        pqw_wave_sync();
+        if (m > 0) {
+            score_rows<NCHT, 1>(ix, q_lds, todo, m, todo_score, qnorm2, 1.0f, lane);  // (rows in flight sized for 128 VGPRs)
+            pqw_wave_sync();
+        }
+        if (i < nres) fin[i] = take ? make_key(todo_score[slot], node) : KEY_MIN;
+        pqw_wave_sync();
+    }
+    __syncthreads();
+    if (wv != 0) return;
+    const int reranked = above > 0 ? above : (nres > 0 ? 1 : 0);
+    int cnt = 0;
+    for (; cnt < topK && cnt < reranked; cnt++) {
+        int64_t bk;
+        int bidx;
+        scan_max(fin, nres, lane, bk, bidx);
+        if (lane == 0) {
+            const int node = key_node(bk);
+            o_nodes[cnt] = node;
+            if (o_docs) o_docs[cnt] = ix.ord2doc ? ix.ord2doc[node] : node;
+            o_scores[cnt] = key_score(bk);
+            fin[bidx] = KEY_MIN;
+        }
+        pqw_wave_sync();
+    }
+    for (int i = cnt + lane; i < topK; i += JV_WAVE) {
+        o_nodes[i] = -1;
+        if (o_docs) o_docs[i] = -1;
+        o_scores[i] = 0.0f;
+    }
+    PQW_STAMP(13)  // rerank + top-K
+    if (lane == 0) {
+        a.out_count[qi] = cnt;
+        int32_t* st = a.out_stats + (size_t)qi * 4;
+        st[0] = visited;
+        st[1] = reranked;
+        st[2] = expanded;
+        st[3] = expanded;
+        a.out_flags[qi] = 0;
+    }
+}
+
+// Persistent grid: one workgroup (W waves) per resident LDS slot, queries dequeued in order.
+// OCC = waves per SIMD the register budget is sized for (4: 128 VGPRs, 8 workgroups of 2 waves per CU)
+template <int NCHT, int CAPK, int W, int OCC, int NL = 4>
+__global__ __launch_bounds__(JV_WAVE * W, OCC) void jv_search_pqw_kernel(const JvIndexDev ix, const JvSearchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int32_t* explog = a.pqp_log + (size_t)blockIdx.x * (size_t)a.pqp_log_cap;
+    int* ctrl = (int*)(smem + a.pqp_scratch_off + W * 256);
+#ifdef JV_STAMPS
+    if (threadIdx.x < 16) ((unsigned long long*)(smem + a.pqp_scratch_off + W * 256 + 64))[threadIdx.x] = 0ull;
+#endif
+    for (;;) {
+        if (threadIdx.x == 0) ctrl[PQW_QI] = atomicAdd(a.pqp_counter, 1);
+        __syncthreads();
+        const int qi = __builtin_amdgcn_readfirstlane(ctrl[PQW_QI]);
+        if (qi >= a.nq) break;
+        search_one_pqw<NCHT, CAPK, W, NL>(ix, a, qi, smem, explog);
+        __syncthreads();
+    }
+}

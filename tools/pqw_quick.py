@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Development check of the several-waves-per-query kernel (jv_kernels_pqw.hip) against the one-wave kernel on a
+C3-shaped index: identical ids / score bits / counters / flags, and the throughput of both.
+env: N (docs, default 2M), B (queries per launch), RKS (comma list), DIST, STAMPS=1 (diagnostic build + phase shares),
+JV_OPT_<name>=<int> per-index options applied to both runs."""
+import importlib, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import __graft_entry__ as g
+g.load_package()
+b = importlib.import_module("opensearch_jvector_amd.binding")
+stamps = os.environ.get("STAMPS", "0") == "1"
+if stamps:
+    b.LIB_PATH = os.path.join(os.path.dirname(b.LIB_PATH), "libjvgpu_stamps.so")
+    b.load_library(b.LIB_PATH)
+gb = importlib.import_module("opensearch_jvector_amd.builder_gpu")
+import bench
+
+n = int(os.environ.get("N", 2_000_000)); d = int(os.environ.get("D", 768)); M = int(os.environ.get("M", 32)); B = int(os.environ.get("B", 65536))
+rks = [int(x) for x in os.environ.get("RKS", "160,1200").split(",")]
+dev = torch.device("cuda", 0)
+t0 = time.time()
+base, q = bench.make_pq_data(torch, os.environ.get("DIST", "rotated"), n, B, d, M, 0, n, False, dev)
+adj, entry = gb.build_graph_gpu(torch, base, 0, R=32, L=100, verbose=False)
+pq = gb.pq_train_encode_gpu(torch, base, M, 0)
+desc, keep = b.make_desc_device(n, d, 32, base.data_ptr(), adj.data_ptr(), entry, 0, pq_M=M, pq_K=pq["K"],
+                                pq_codebooks=pq["codebooks"], pq_centroid=pq["centroid"], pq_codes_ptr=pq["codes"].data_ptr(),
+                                borrow=True, extra_flags=b.DESC_FUSED_ADC)
+ix = b.GpuIndex(desc=desc, keepalive=keep, flags=b.DESC_BORROW)
+print(f"index ready in {time.time() - t0:.1f} s", flush=True)
+for key, val in os.environ.items():
+    if key.startswith("JV_OPT_"):
+        ix.set_option(key[len("JV_OPT_"):].lower(), int(val))
+dbg = torch.zeros(16, dtype=torch.int64, device=dev)
+
+
+def run(no_pqw, rk, iters=3):
+    ix.set_option("no_pqw", no_pqw)
+    o = [torch.full((B, 10), -7, dtype=torch.int32, device=dev), torch.full((B, 10), -7, dtype=torch.int32, device=dev),
+         torch.zeros((B, 10), dtype=torch.float32, device=dev), torch.zeros((B,), dtype=torch.int32, device=dev),
+         torch.zeros((B, 4), dtype=torch.int32, device=dev), torch.zeros((B,), dtype=torch.int32, device=dev)]
+    best = 1e9
+    for it in range(iters):
+        if stamps:
+            dbg.zero_()
+            ix.set_option("dbg_ptr", dbg.data_ptr())
+        torch.cuda.synchronize(); t = time.time()
+        ix.search_batch_device(q.data_ptr(), B, 10, rk, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(),
+                               o[4].data_ptr(), o[5].data_ptr())
+        torch.cuda.synchronize(); best = min(best, time.time() - t)
+    if stamps:
+        ix.set_option("dbg_ptr", 0)
+    return [x.cpu().numpy() for x in o], best, dbg.cpu().numpy().astype(np.float64)
+
+
+names = ["find best/runner-up + block select", "prefetch issue + mark expanded + log", "ADC (+ exchange)", "boundary test + rank search + dedupe",
+         "ranks among new + shift + insert", "boundary + trim", "visited-count pass", "LUT build + entry point", "rerank + top-K"]
+for rk in rks:
+    old, t_old, v_old = run(1, rk)
+    new, t_new, v_new = run(0, rk)
+    eq = [np.array_equal(old[i].view(np.uint32) if old[i].dtype == np.float32 else old[i], new[i].view(np.uint32) if new[i].dtype == np.float32 else new[i]) for i in range(6)]
+    st = new[4].astype(np.float64).mean(0)
+    bad = int((old[0] != new[0]).any(1).sum())
+    print(f"rk={rk}: one-wave {B / t_old:,.0f} QPS, several-waves {B / t_new:,.0f} QPS ({t_old / t_new:.2f}x); equal nodes/docs/scores/count/stats/flags = {eq}; "
+          f"queries with different ids {bad}; expansions/query {st[2]:.1f} visited {st[0]:.1f}; flagged(new) {(new[5] != 0).sum()}", flush=True)
+    if not all(eq):
+        i = int(np.argmax((old[0] != new[0]).any(1) | (old[4] != new[4]).any(1)))
+        print("  first differing query", i, "\n   old", old[0][i], old[4][i], old[5][i], "\n   new", new[0][i], new[4][i], new[5][i])
+    if stamps:
+        for label, v in (("one-wave", v_old), ("several-waves (wave 0)", v_new)):
+            cyc = np.concatenate([v[:8], v[13:14]])
+            ne = max(st[2], 1) * B
+            print(f"  {label}: cycles per expansion by phase")
+            for i, nme in enumerate(names):
+                print(f"     {nme:40s} {100 * cyc[i] / max(cyc.sum(), 1):5.1f} %   {cyc[i] / ne:8.0f}")
+            print(f"     raw slots / expansion: " + " ".join(f"[{i}]={v[i] / ne:.0f}" for i in range(16)))
+ix.close()
