@@ -230,12 +230,17 @@ typedef struct jv_index_info {
     int64_t filter_cache_hits, filter_cache_misses;
 } jv_index_info;
 int jv_index_get_info(const jv_index* index, jv_index_info* out);
+/* Diagnostics: launches per kernel family since the handle was created — "launches_pqw" (several-waves-per-query pool
+ * kernel), "launches_pqp" (one-wave pool kernel), "launches_pqf" (round-1 fused-PQ kernel), "launches_lds" (generic LDS
+ * kernel).  Lets a test or an operator see which rung served a workload.  JV_EINVAL for unknown names. */
+int jv_index_get_counter(const jv_index* index, const char* name, int64_t* out);
 
 /* Tunables are PER INDEX: jv_index_set_option changes one handle; jv_set_option only changes the defaults that indexes
  * created afterwards start from (nothing process-wide is read at call time).  Names: "lds_visited_slots",
  * "lds_candidates", "force_big_path", "force_general_path", "big_blocks", "big_cand_cap", "big_budget_mb",
  * "spill_tables", "spill_slots", "combine", "combine_leaders", "combine_max_batch", "max_contexts", "filter_cache"
- * (+ diagnostics: "no_escalation", "no_pqf", "no_pqp", "no_lutr", "lutr_min_queries", "pqf_only", "dbg_ptr").
+ * (+ diagnostics: "no_escalation", "no_pqf", "no_pqp", "no_pqw", "pqw_min_queries", "no_lutr", "lutr_min_queries",
+ * "pqf_only", "dbg_ptr").
  * JV_EINVAL for unknown names. */
 int jv_set_option(const char* name, int64_t value);
 int jv_index_set_option(jv_index* index, const char* name, int64_t value);

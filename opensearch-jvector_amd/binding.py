@@ -24,7 +24,7 @@ NUM_STATS = 4
 ABI_SYMBOLS = [
     "jv_index_create", "jv_index_destroy", "jv_search", "jv_search_batch", "jv_search_batch_device",
     "jv_score_ordinals", "jv_merge_topk_device", "jv_index_get_info", "jv_set_option", "jv_last_error",
-    "jv_abi_version", "jv_search_ex", "jv_search_batch_ex", "jv_index_set_option", "jv_shard_group_create",
+    "jv_abi_version", "jv_search_ex", "jv_search_batch_ex", "jv_index_set_option", "jv_index_get_counter", "jv_shard_group_create",
     "jv_shard_group_destroy", "jv_search_sharded_batch",
 ]
 QFLAG_RETRIED_BIG, QFLAG_EARLY_TERMINATED = 0x1, 0x2
@@ -249,6 +249,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.jv_search_batch_ex.restype = C.c_int
     lib.jv_index_set_option.argtypes = [vp, C.c_char_p, i64]
     lib.jv_index_set_option.restype = C.c_int
+    lib.jv_index_get_counter.argtypes = [vp, C.c_char_p, C.POINTER(i64)]
+    lib.jv_index_get_counter.restype = C.c_int
     lib.jv_shard_group_create.argtypes = [C.POINTER(vp), i32, C.POINTER(vp)]
     lib.jv_shard_group_create.restype = C.c_int
     lib.jv_shard_group_destroy.argtypes = [vp]
@@ -310,6 +312,12 @@ class GpuIndex:
     def set_option(self, name: str, value: int):
         """Per-index tunable (jv_index_set_option)."""
         _check(self.lib, self.lib.jv_index_set_option(self.handle, name.encode(), int(value)))
+
+    def counter(self, name: str) -> int:
+        """Launch counters per kernel family (jv_index_get_counter)."""
+        out = C.c_int64(0)
+        _check(self.lib, self.lib.jv_index_get_counter(self.handle, name.encode(), C.byref(out)))
+        return int(out.value)
 
     def _params(self, topK, rerankK, threshold, rerank_floor, acc, accept_num_docs, visit_limit, accept_key):
         p = JvSearchParams()

@@ -249,7 +249,10 @@ struct jv_index {
     int64_t filter_hits = 0, filter_misses = 0;
     Ctx* async_ctx = nullptr;
     std::mutex async_mu;
+    // launches per kernel family since creation (jv_index_get_counter): which rung served a call is observable
+    std::atomic<int64_t> launches[8] = {};
 };
+enum { LAUNCH_PQW = 0, LAUNCH_PQP, LAUNCH_PQF, LAUNCH_LDS, LAUNCH_BIG };
 
 #define OPT(ixp, id) ((ixp)->opts.v[id].load(std::memory_order_relaxed))
 
@@ -610,6 +613,7 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
             ap.pqp_counter = c->work_counter + 6;
             if (pqw) HIPCHK(jvk_launch_search_pqw(&ix->dev, &ap, lds, blocks, stream));
             else HIPCHK(jvk_launch_search_pqp(&ix->dev, &ap, lds, blocks, lutr, stream));
+            ix->launches[pqw ? LAUNCH_PQW : LAUNCH_PQP]++;
             if (second) {
                 ap2.pqp_log = c->pqp_log;
                 HIPCHK(jvk_launch_search_pqp(&ix->dev, &ap2, lds2, blocks2, 0, stream));
@@ -645,6 +649,7 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
         };
         if (shape_ok && rerank_b <= lut_b && loop_bytes(ap) <= kMaxLds) {
             HIPCHK(jvk_launch_search_pqf(&ix->dev, &ap, (loop_bytes(ap) + 15) & ~15, stream));
+            ix->launches[LAUNCH_PQF]++;
             pqf = true;
             if (second_rung && OPT(ix, OPT_PQF_ONLY) == 0) {
                 JvSearchArgs ap2 = ap;
@@ -658,8 +663,10 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
     }
     if (pqf && OPT(ix, OPT_PQF_ONLY) != 0) return JV_OK;
     if (!force_big) {
-        if (!pqf)
+        if (!pqf) {
             HIPCHK(jvk_launch_search_lds(&ix->dev, &a, pq ? 1 : 0, g.pool ? 1 : 0, ix->build_client ? 2 : 0, g.lds_fast, stream));
+            ix->launches[LAUNCH_LDS]++;
+        }
         // (after a PQF launch the flagged queries go straight to the rung below: generic kernel, 4x visited table)
         // escalation: queries that overflowed the on-chip visited set are retried with a 4x larger table
         // (fewer resident queries, but only the flagged few run) before the HBM-scratch path
@@ -1044,6 +1051,17 @@ int jv_index_get_info(const jv_index* index, jv_index_info* out) {
     }
     out->scratch_bytes = scratch;
     return JV_OK;
+}
+
+int jv_index_get_counter(const jv_index* index, const char* name, int64_t* out) {
+    if (!index || !name || !out) return fail(JV_EINVAL, "index/name/out is NULL");
+    static const char* const kNames[] = {"launches_pqw", "launches_pqp", "launches_pqf", "launches_lds"};
+    for (int i = 0; i < 4; i++)
+        if (strcmp(name, kNames[i]) == 0) {
+            *out = index->launches[i].load();
+            return JV_OK;
+        }
+    return fail(JV_EINVAL, "unknown counter '%s'", name);
 }
 
 int jv_search_batch_device(jv_index* index, const float* d_queries, int32_t nq, int32_t topK, int32_t rerankK,

@@ -238,12 +238,15 @@ def test_fused_adc_layout_parity(pkg, pyoracle, small_sets, sim, M, R):
         if M == 32 and R == 32 and sim != 2:
             # the large-launch variant of the headline kernel (look-up table in registers) on this small batch, and the
             # round-1 LDS-pool kernel: both must give the same bits
+            # (the several-waves kernel that serves this shape by default has its own file, tests/test_gpu_pqw.py)
             for opt, val, back in (("lutr_min_queries", 0, -1), ("no_pqp", 1, 0)):
                 try:
+                    gpu.set_option("no_pqw", 1)
                     gpu.set_option(opt, val)
                     _assert_same(gpu.search_batch(q, k, rk), want, f"fused/{opt} sim={sim} M={M} R={R} k={k} rk={rk}")
                 finally:
                     gpu.set_option(opt, back)
+                    gpu.set_option("no_pqw", 0)
     gpu.close()
 
 
@@ -366,6 +369,7 @@ def test_score_tie_storm_register_table_kernel(pkg, pyoracle, seed):
         orc = pyoracle.Oracle(b, ixq)
         for lutr in (1, 0):
             gpu = b.GpuIndex(ixq, flags=b.DESC_FUSED_ADC)
+            gpu.set_option("no_pqw", 1)   # the one-wave kernels (several waves: tests/test_gpu_pqw.py::test_tie_storm_and_second_launch)
             gpu.set_option("lutr_min_queries", 0)
             gpu.set_option("no_lutr", 1 - lutr)
             for k, rk in ((1, 1), (3, 4), (10, 16), (10, 40), (20, 100), (50, 300)):

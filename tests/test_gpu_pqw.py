@@ -1,0 +1,126 @@
+"""GPU parity of the several-waves-per-query pool kernel (csrc/jv_pqw_body.h: PQ-32 -> two waves, PQ-64 -> four; table in
+registers split by chunk + rows in LDS; two fused blocks per scoring pass) against the CPU oracle, and against the
+one-wave kernels it replaces on these shapes.  Same bar as tests/test_gpu_parity.py: ids, score bits, all four counters."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _assert_same(got, want, what=""):
+    assert np.array_equal(got.count, want.count), f"{what}: result counts differ"
+    assert np.array_equal(got.nodes, want.nodes), f"{what}: neighbour ids differ"
+    assert np.array_equal(got.docs, want.docs), f"{what}: doc ids differ"
+    assert np.array_equal(got.stats, want.stats), f"{what}: visited/reranked/expanded counters differ"
+    assert np.array_equal(got.scores.view(np.uint32), want.scores.view(np.uint32)), f"{what}: score bits differ"
+
+
+def _both_kernels(gpu, what, fn, want):
+    """runs `fn` on the several-waves kernel (and proves it was that kernel) and on the one-wave kernels"""
+    before = gpu.counter("launches_pqw")
+    _assert_same(fn(), want, what + " [several waves]")
+    assert gpu.counter("launches_pqw") > before, what + ": the several-waves kernel did not run"
+    try:
+        gpu.set_option("no_pqw", 1)
+        before = gpu.counter("launches_pqw")
+        _assert_same(fn(), want, what + " [one wave]")
+        assert gpu.counter("launches_pqw") == before
+    finally:
+        gpu.set_option("no_pqw", 0)
+
+
+@pytest.mark.parametrize("sim", [0, 1])
+@pytest.mark.parametrize("M,R,d", [(32, 32, 64), (32, 16, 64), (32, 24, 96), (32, 8, 64), (64, 32, 128), (64, 16, 128), (32, 64, 64)])
+def test_shapes_and_pool_classes(pkg, pyoracle, sim, M, R, d):
+    """every (waves per query, neighbours per row) shape the kernel accepts — R = 64 runs one block per pass, the others
+    two — over beams from 1 to 1 900 (all three pool capacity classes), with rerank floors"""
+    b, bl, dg = pkg.binding, pkg.builder, pkg.datagen
+    n = 4000
+    base = dg.splitmix_uniform(70 + d + R, n, d) - np.float32(0.25)
+    if sim == 1:
+        base = dg.l2_normalize(base)
+    q = dg.splitmix_uniform(71 + d + R, 48, d) - np.float32(0.25)
+    ix = bl.build_index_cpu(base, sim, R=R, L=60, pq_M=M)
+    gpu = b.GpuIndex(ix, flags=b.DESC_FUSED_ADC)
+    orc = pyoracle.Oracle(b, ix)
+    for k, rk, floor in [(1, 1, 0.0), (10, 10, 0.0), (10, 50, 0.0), (10, 120, 0.0), (20, 400, 0.0), (10, 500, 0.0), (50, 1000, 0.0),
+                         (10, 1900, 0.0), (10, 64, 0.55), (10, 64, 100.0)]:
+        want = orc.search_batch(q, k, rk, rerank_floor=floor)
+        _both_kernels(gpu, f"sim={sim} M={M} R={R} k={k} rk={rk} floor={floor}", lambda: gpu.search_batch(q, k, rk, rerank_floor=floor), want)
+    gpu.close()
+
+
+@pytest.mark.parametrize("seed", [41, 42])
+def test_tie_storm_and_second_launch(pkg, pyoracle, seed):
+    """whole groups of nodes share one PQ code: strict admission (rejected entries), tie runs longer than the first
+    launch's 64 slots (redone by the wider one-wave launch) and reranks over tied pools, through the several-waves kernel"""
+    b, bl = pkg.binding, pkg.builder
+    rng = np.random.default_rng(seed)
+    n, d, R = 600, 32, 16
+    base = np.zeros((n, d), dtype=np.float32)
+    base[:, :4] = rng.integers(0, 2, size=(n, 4))
+    adj = np.stack([rng.permutation(n)[:R] for _ in range(n)]).astype(np.int32)
+    q = np.zeros((64, d), dtype=np.float32)
+    q[:, :4] = rng.integers(0, 2, size=(64, 4)) + np.float32(0.5) * (rng.random((64, 4)) < 0.3)
+    for sim in (0, 1):
+        cb, cen, codes, K = bl.pq_train_encode_cpu(base, 32, sim)
+        ixq = b.IndexData(vectors=base, adj=adj, entry_node=int(rng.integers(0, n)), similarity=sim, pq_codebooks=cb, pq_centroid=cen,
+                          pq_codes=codes, pq_M=32, pq_K=K)
+        orc = pyoracle.Oracle(b, ixq)
+        gpu = b.GpuIndex(ixq, flags=b.DESC_FUSED_ADC)
+        for k, rk in ((1, 1), (3, 4), (10, 16), (10, 40), (20, 100), (50, 300)):
+            _both_kernels(gpu, f"ties sim={sim} seed={seed} k={k} rk={rk}", lambda: gpu.search_batch(q, k, rk), orc.search_batch(q, k, rk))
+        gpu.set_option("pqf_only", 1)  # ladder off: the first launch alone must leave the long tie runs unanswered
+        unanswered = 0
+        for k, rk in ((10, 16), (10, 40), (20, 100)):
+            _, status, _, _ = gpu.search_batch_ex(q, k, rk)
+            unanswered += int((status != 0).sum())
+        assert unanswered > 0, "tie fixture no longer reaches past the first launch"
+        gpu.close()
+
+
+@pytest.mark.parametrize("seed", [5, 6])
+def test_malformed_graphs_and_duplicates(pkg, pyoracle, seed):
+    """holes, self loops, the same neighbour twice in a row (twins inside one scoring pass), unreachable nodes, exact
+    duplicate vectors (identical keys up to the node id)"""
+    b, bl = pkg.binding, pkg.builder
+    rng = np.random.default_rng(seed)
+    n, d, R = 900, 64, 32
+    uniq = rng.random((n // 2, d)).astype(np.float32)
+    base = np.concatenate([uniq, uniq[rng.integers(0, n // 2, n - n // 2)]])
+    adj = rng.integers(0, n, size=(n, R)).astype(np.int32)
+    adj[rng.random((n, R)) < 0.15] = -1
+    for i in range(0, n, 7):
+        adj[i, rng.integers(0, R)] = i
+        adj[i, 1] = adj[i, 0]
+    q = rng.random((40, d)).astype(np.float32)
+    for sim in (0, 1):
+        cb, cen, codes, K = bl.pq_train_encode_cpu(base, 32, sim)
+        ixq = b.IndexData(vectors=base, adj=adj, entry_node=int(rng.integers(0, n)), similarity=sim, pq_codebooks=cb, pq_centroid=cen,
+                          pq_codes=codes, pq_M=32, pq_K=K)
+        gpu, orc = b.GpuIndex(ixq, flags=b.DESC_FUSED_ADC), pyoracle.Oracle(b, ixq)
+        for k, rk in ((5, 20), (10, 64), (3, 3), (10, 300)):
+            _both_kernels(gpu, f"malformed sim={sim} seed={seed} k={k} rk={rk}", lambda: gpu.search_batch(q, k, rk), orc.search_batch(q, k, rk))
+        gpu.close()
+
+
+def test_many_queries_per_resident_workgroup_and_visit_limit(pkg, pyoracle):
+    """more queries than resident workgroups (persistent dequeue), doc map, Lucene's visit limit with per-query status"""
+    b, bl, dg = pkg.binding, pkg.builder, pkg.datagen
+    n, d = 3000, 64
+    base = dg.splitmix_uniform(91, n, d)
+    q = dg.splitmix_uniform(92, 6000, d)
+    rng = np.random.default_rng(9)
+    ord2doc = rng.permutation(2 * n)[:n].astype(np.int32)
+    ix = bl.build_index_cpu(base, 0, R=32, L=60, pq_M=32, ord2doc=ord2doc, max_doc=2 * n)
+    gpu, orc = b.GpuIndex(ix, flags=b.DESC_FUSED_ADC), pyoracle.Oracle(b, ix)
+    want = orc.search_batch(q, 10, 80)
+    _both_kernels(gpu, "6000 queries", lambda: gpu.search_batch(q, 10, 80), want)
+    # visit limit: a query whose search would expand more nodes is flagged early-terminated and returns nothing
+    lim = int(np.median(want.stats[:64, 2]))
+    got, status, flags, rc = gpu.search_batch_ex(q[:64], 10, 80, visit_limit=lim)
+    early = (flags & b.QFLAG_EARLY_TERMINATED) != 0
+    assert early.any() and (~early).any()
+    assert np.array_equal(got.nodes[~early], want.nodes[:64][~early])
+    assert (got.count[early] == 0).all()
+    gpu.close()
