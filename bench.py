@@ -408,19 +408,41 @@ def main():
                     help="only warm-up + timed launches of the query kernel (needs --rerankk): no recall sweep, no p50, no CPU leg")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
+    # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU under
+    # torch.distributed.run) as a CHILD process — before this process touches HIP — relay its output and exit with its code.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        log("launching " + " ".join(cmd))
+        raise SystemExit(subprocess.call(cmd, env=env))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("JV_BENCH_LAUNCH_CHECK") == "1":  # (tests/test_bench_launch.py: the launch path alone, no GPU needed)
+        print(f"launch-check rank {rank} of {world} local_rank {local_rank} gpus {args.gpus}", flush=True)
+        raise SystemExit(0 if world == args.gpus else 3)
+
+    import torch
+    import torch.distributed as dist
+
     if world != args.gpus:
-        log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+        raise SystemExit(f"bench: WORLD_SIZE={world} but --gpus {args.gpus}: launch N ranks for --gpus N (or run `python bench.py --gpus N`, which does)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
     # one rank per GPU; (debug only: JV_BENCH_BACKEND=gloo lets several ranks share one GPU to exercise the
     # shard / all-gather / merge path on a single-GPU box — the collective then stages through the host)
     backend = os.environ.get("JV_BENCH_BACKEND", "nccl")
+    if world > 1 and backend == "nccl" and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench: --gpus {world} needs {world} GPUs, this node shows {torch.cuda.device_count()} "
+                         "(JV_BENCH_BACKEND=gloo lets ranks share a GPU for a functional check only)")
     local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -430,6 +452,8 @@ def main():
             dist.init_process_group(backend="nccl", device_id=device)
         else:
             dist.init_process_group(backend=backend)
+        if dist.get_world_size() != args.gpus or dist.get_backend() != backend:
+            raise SystemExit(f"bench: process group is {dist.get_backend()} x {dist.get_world_size()}, expected {backend} x {args.gpus}")
 
     graft.load_package()
     binding = importlib.import_module("opensearch_jvector_amd.binding")
@@ -452,7 +476,9 @@ def main():
     # N > 1: doc-ID-range shards.  Default = the north star's curve: the SAME corpus (10M docs) split over the
     # ranks ("strong": total work fixed; every rank searches every query on its n/N docs, rerankK is re-swept
     # so that the MERGED recall@10 stays >= 0.95).  JV_BENCH_SCALING=weak keeps n docs per GPU instead.
-    scaling = os.environ.get("JV_BENCH_SCALING", "strong" if (world > 1 and not wl.get("per_gpu")) else "weak")
+    # (the label does not depend on N: c2/c3/c5 lines belong to the strong curve — the same corpus on 1, 2, 4, 8 GPUs —,
+    #  c4 lines to the weak one)
+    scaling = os.environ.get("JV_BENCH_SCALING", "weak" if wl.get("per_gpu") else "strong")
     if world > 1 and scaling == "strong":
         lo_doc, hi_doc = sharding.shard_range(n_cfg, world, rank)
         n, row_offset, n_total = hi_doc - lo_doc, lo_doc, n_cfg
@@ -556,6 +582,8 @@ def main():
     cus = torch.cuda.get_device_properties(device).multi_processor_count
     reg_table = pq_M == 32 and sim != 2 and eng.B > 4 * cus
     main_kernel = ("jv_search_pqp_kernel" if (rk + 64 + R > 256 or reg_table) else "jv_search_pqf_kernel") if fused else "jv_search_lds_kernel"
+    if fused and eng.index.counter("launches_pqw") > 0:
+        main_kernel = "jv_search_pqw_kernel"  # several waves per query (PQ-32 / PQ-64, L2 or dot product, no filter)
     recall_txt = "nan" if chosen_recall != chosen_recall else f"{chosen_recall:.4f}"
     metric = "queries/sec at recall@10>=0.95" if target_met in (True, None) else \
         f"queries/sec at recall@10={recall_txt} (target 0.95 NOT reached by any rerankK of the sweep)"
@@ -569,6 +597,7 @@ def main():
         "value": round(qps, 1),
         "unit": "queries/s",
         "n_gpus": world,
+        "rccl_ranks": (world if (world > 1 and backend == "nccl") else 0),
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),

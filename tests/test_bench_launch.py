@@ -1,0 +1,32 @@
+"""bench.py --gpus N must start its N ranks by itself: the driver's `python bench.py --gpus 8` has no launcher
+around it.  Checked here without a GPU: JV_BENCH_LAUNCH_CHECK=1 makes every rank report itself and stop before torch/HIP."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, extra_env=None):
+    env = dict(os.environ, JV_BENCH_LAUNCH_CHECK="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(extra_env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=300)
+
+
+def test_plain_invocation_with_gpus_2_starts_two_ranks():
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = sorted(l for l in r.stdout.splitlines() if l.startswith("launch-check"))
+    assert lines == ["launch-check rank 0 of 2 local_rank 0 gpus 2", "launch-check rank 1 of 2 local_rank 1 gpus 2"], r.stdout
+
+
+def test_single_gpu_invocation_does_not_spawn():
+    r = _run([])
+    assert r.returncode == 0 and r.stdout.strip() == "launch-check rank 0 of 1 local_rank 0 gpus 1"
+
+
+def test_world_size_mismatch_is_an_error():
+    r = _run(["--gpus", "4"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode == 3
