@@ -166,7 +166,9 @@ typedef struct jv_search_params {
      * searches that stay below the limit are unchanged (same ids, scores, counters).  0 = never stop early. */
     int64_t visit_limit;
     /* Identity of the filter's CONTENTS for the device-side filter cache (option "filter_cache", per index): a bitset
-     * that was uploaded before is served from HBM instead of crossing PCIe again.  0 = the library hashes the words. */
+     * that was uploaded before is served from HBM instead of crossing PCIe again.  0 = the library hashes the words.
+     * The key (or hash) only FINDS a cached copy: it is served after a byte-for-byte comparison with the caller's words,
+     * so a colliding hash or a re-used key can never apply another filter's bits (they carry deletes and doc-level security). */
     uint64_t accept_key;
 } jv_search_params;
 

@@ -225,6 +225,8 @@ struct FilterEntry {
     uint64_t stamp = 0;
     int users = 0;  // launches in flight that read it
     hipEvent_t ready = nullptr;  // recorded after the upload: consumers on other streams wait for it
+    std::vector<uint64_t> host;  // the cached bits: a hit is served only after a memcmp against the caller's bitset (the key —
+                                 // a 64-bit content hash or a caller-supplied number — only finds the candidate entry)
 };
 
 }  // namespace
@@ -1128,7 +1130,10 @@ int filter_acquire(jv_index* ix, const uint64_t* words, size_t nwords, uint64_t 
     int victim = -1;
     for (size_t i = 0; i < ix->filters.size(); i++) {
         FilterEntry& f = ix->filters[i];
-        if (f.key == key && f.words == nwords && f.d_words) {
+        // The bitset carries doc-level security and deletes: never trust the key alone.  A colliding hash or a re-used caller
+        // key with different bits is a miss (and, entry idle, the entry is refilled below).
+        if (f.key == key && f.words == nwords && f.d_words && f.host.size() == nwords &&
+            memcmp(f.host.data(), words, nwords * 8) == 0) {
             f.users++;
             f.stamp = ++ix->filter_clock;
             ix->filter_hits++;
@@ -1156,7 +1161,12 @@ int filter_acquire(jv_index* ix, const uint64_t* words, size_t nwords, uint64_t 
         f.cap_words = nwords;
     }
     f.key = 0;  // not valid until the copy is enqueued
-    HIPCHK(hipMemcpyAsync(f.d_words, words, nwords * 8, hipMemcpyHostToDevice, stream));
+    try {
+        f.host.assign(words, words + nwords);  // (also the staging source: the caller's buffer may be gone before the copy runs)
+    } catch (const std::bad_alloc&) {
+        return JV_OK;  // no cache entry: the caller uploads the bits itself
+    }
+    HIPCHK(hipMemcpyAsync(f.d_words, f.host.data(), nwords * 8, hipMemcpyHostToDevice, stream));
     HIPCHK(hipEventRecord(f.ready, stream));
     f.key = key;
     f.words = nwords;
@@ -1254,12 +1264,16 @@ int search_batch_host(jv_index* index, const float* queries, int32_t nq, int32_t
         const uint64_t* shared = accept_doc_words;
         uint64_t key = ex.accept_key;
         if (!shared && accept_list && copy_words && OPT(index, OPT_FILTER_CACHE) > 0) {
-            key = hash_words(accept_list[0], copy_words);
+            // (same bits, not same hash: every query of a combined batch is answered under ITS caller's filter)
             bool same = true;
             for (int i = 1; i < nq && same; i++)
-                same = accept_list[i] == accept_list[0] || hash_words(accept_list[i], copy_words) == key;
-            if (same) shared = accept_list[0];
-            else key = 0;
+                same = accept_list[i] == accept_list[0] || memcmp(accept_list[i], accept_list[0], copy_words * 8) == 0;
+            if (same) {
+                shared = accept_list[0];
+                key = hash_words(accept_list[0], copy_words);
+            } else {
+                key = 0;
+            }
         }
         if (shared && copy_words) {
             if ((rc = filter_acquire(index, shared, copy_words, key, c->stream, &d_accept, &filter_slot)) != JV_OK) return rc;

@@ -124,16 +124,52 @@ __global__ __launch_bounds__(256) void jvb_pq_encode_kernel(const float* __restr
     }
 }
 
+// Subspaces wider than PQE_MAX_DS dimensions (few subspaces over a long vector: d = 768 with M = 8, d = 1536 with M = 16;
+// the reference accepts any num_pq_subspaces, K/index/.../KNNVectorsFormatParams.java:143): the same sequential fmaf
+// chain with the vector's components re-read per centroid (L1 / L2 hits) instead of held in registers.
+__global__ __launch_bounds__(256) void jvb_pq_encode_wide_kernel(const float* __restrict__ vectors, long long n, int d, int stride,
+                                                                 int M, int K, const int32_t* __restrict__ sub_off,
+                                                                 const float* __restrict__ codebooks, const long long* __restrict__ cb_off,
+                                                                 const float* __restrict__ centroid, uint8_t* __restrict__ codes,
+                                                                 int code_stride) {
+    const int m = blockIdx.y;
+    const int d0 = sub_off[m], ds = sub_off[m + 1] - d0;
+    const float* cb = codebooks + cb_off[m];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float* row = vectors + (size_t)i * (size_t)stride + d0;
+        float best = 3.4028234663852886e38f;
+        int bc = 0;
+        for (int c = 0; c < K; c++) {
+            const float* cv = cb + (size_t)c * ds;
+            float acc = 0.0f;
+            for (int j = 0; j < ds; j++) {
+                const float xj = centroid ? row[j] - centroid[d0 + j] : row[j];
+                const float df = xj - cv[j];
+                acc = fmaf(df, df, acc);
+            }
+            if (acc < best) {
+                best = acc;
+                bc = c;
+            }
+        }
+        codes[(size_t)i * (size_t)code_stride + m] = (uint8_t)bc;
+    }
+}
+
 // device pointers everywhere; sub_off [M + 1] int32, cb_off [M] int64
 extern "C" int jvb_pq_encode_device(const float* vectors, long long n, int d, int stride, int M, int K, const int32_t* sub_off,
                                     const float* codebooks, const long long* cb_off, const float* centroid, uint8_t* codes,
                                     int code_stride, int max_ds, void* stream) {
     if (n <= 0) return 0;
-    if (max_ds > PQE_MAX_DS || M <= 0 || K <= 0 || K > 256) return -4;
+    if (max_ds <= 0 || M <= 0 || K <= 0 || K > 256) return -4;
     long long bx = (n + 255) / 256;
     if (bx > 8192) bx = 8192;
     dim3 grid((unsigned)bx, (unsigned)M);
-    jvb_pq_encode_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(vectors, n, d, stride, M, K, sub_off, codebooks, cb_off, centroid, codes,
-                                                                code_stride);
+    if (max_ds > PQE_MAX_DS)
+        jvb_pq_encode_wide_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(vectors, n, d, stride, M, K, sub_off, codebooks, cb_off, centroid,
+                                                                         codes, code_stride);
+    else
+        jvb_pq_encode_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(vectors, n, d, stride, M, K, sub_off, codebooks, cb_off, centroid, codes,
+                                                                    code_stride);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

@@ -13,7 +13,7 @@ def _gb():
     return torch, importlib.import_module("opensearch_jvector_amd.builder_gpu")
 
 
-@pytest.mark.parametrize("d,M,sim", [(64, 16, 0), (50, 8, 0), (96, 32, 1), (768, 32, 0), (130, 7, 2)])
+@pytest.mark.parametrize("d,M,sim", [(64, 16, 0), (50, 8, 0), (96, 32, 1), (768, 32, 0), (130, 7, 2), (768, 8, 0), (200, 3, 1)])  # the last two: subspaces wider than 64 dims
 def test_pq_encode_kernel_equals_cpu_encoder(pkg, pyoracle, d, M, sim):
     """codes from jvb_pq_encode_kernel == codes from jvb_pq_encode_cpu on the SAME codebooks (bit-exact: both take the
     argmin of the canonical fmaf-chain distance, ties to the lowest centroid), with uneven subspaces and with / without
