@@ -244,6 +244,11 @@ __device__ void search_one_pqw(const JvIndexDev& ix, const JvSearchArgs& a, cons
         float score = 0.0f;
         int nn = -1;
         int64_t pv = KEY_MIN;  // lane t: last key of pool chunk t (low bits may be stale: they never decide a comparison with a new key)
+        // ranks of BOTH halves' keys are taken in the pass iteration (the per-lane search costs the same for 32 or 64 keys); the
+        // runner-up's half keeps them for its own expansion, corrected there for the keys the first half inserted meanwhile
+        int rold_s = 0;
+        bool cand_s = false;
+        unsigned long long ins_lo = 0ull;  // lanes (lower half) whose keys went into the pool in the pass iteration
         while (true) {
             // ---- best unexpanded entry (every position < lo_un is expanded; sentinels have bit 0 clear) ----
             int t1 = lo_un >> 6;
@@ -290,6 +295,7 @@ __device__ void search_one_pqw(const JvIndexDev& ix, const JvSearchArgs& a, cons
             const bool stop = !m1 || why != 0;
             int half = -1;
             if (!stop) half = c == sc_node0 ? 0 : (c == sc_node1 ? 1 : -1);
+            bool fresh = false;  // this iteration runs a scoring pass
             PQW_STAMP(15)  // (diagnostic) find proper
             if (stop || half < 0) {
                 // ---- scoring pass: the next three unexpanded entries as well (runner-up: scored now; the two after it:
@@ -370,6 +376,7 @@ __device__ void search_one_pqw(const JvIndexDev& ix, const JvSearchArgs& a, cons
                 sc_node0 = c;
                 sc_node1 = pair ? bn1 : -1;
                 half = 0;
+                fresh = true;
                 PQW_STAMP(2)  // ADC + exchange
             }
             // mark the entry expanded; log the node
@@ -382,74 +389,94 @@ __device__ void search_one_pqw(const JvIndexDev& ix, const JvSearchArgs& a, cons
             if (half == 0) sc_node0 = -1;
             else sc_node1 = -1;
             PQW_STAMP(1)
-            bool keep = nn >= 0 && hf == half;
-            if (np >= rk && score < bscore) keep = false;  // below the boundary for good
             const int64_t v = pqp_key<false>(score, nn, true);
-            // ---- rank of the surviving keys in the pool; "same node" = equal up to the low bits.  Wave-cooperative, one key
-            // at a time (2-3 survive on average): the last key of every 64-entry chunk sits in lane t of `pv` (registers),
-            // one ballot finds the key's chunk, ONE contiguous (conflict-free) chunk read and two more ballots give its
-            // rank and tell whether the node is already in the pool.  Four keys' chunk reads are in flight together.
-            int rold = 0;
-            unsigned long long todo_m = __ballot(keep);
-            if (__popcll(todo_m) > 6) {
-                // many survivors (the pool is still filling: every neighbour is a candidate): per-lane 8-ary search, all
-                // lanes at once, cost independent of their number
-                if (keep) {
-                    int lo = 0;
-                    if (CAPK == 3) lo = rank_level<512, 8>(pool, lo, cap, v);
-                    if (CAPK == 2) lo = rank_level<512, 4>(pool, lo, cap, v);
-                    if (CAPK == 1) lo = rank_level<256, 4>(pool, lo, cap, v);
-                    if (CAPK == 1) lo = rank_level<64, 4>(pool, lo, cap, v);
-                    else lo = rank_level<64, 8>(pool, lo, cap, v);
-                    lo = rank_level<8, 8>(pool, lo, cap, v);
-                    int64_t p3[9];
-#pragma unroll
-                    for (int k2 = 0; k2 < 9; k2++) p3[k2] = pool[min(lo + k2, cap)];
-                    int c3 = 0;
-                    bool dup = false;
-#pragma unroll
-                    for (int k2 = 0; k2 < 9; k2++) {
-                        if (k2 < 8) c3 += p3[k2] > v ? 1 : 0;
-                        dup |= (p3[k2] | 3ll) == v;
-                    }
-                    rold = lo + c3;
-                    if (dup) keep = false;
-                }
-            } else {
-                const int vlo_ = (int)(uint32_t)(v & 0xFFFFFFFFll), vhi_ = (int)(v >> 32);
-                while (todo_m) {
-                    int jj[4], tcs[4];
-                    int64_t kk[4], ee[4];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        jj[u] = -1;
-                        tcs[u] = 0;
-                        kk[u] = 0;
-                        ee[u] = 0;
-                        if (todo_m) {
-                            const int j = __ffsll((long long)todo_m) - 1;
-                            todo_m &= todo_m - 1ull;
-                            jj[u] = j;
-                            kk[u] = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(vhi_, j) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane(vlo_, j));
-                            tcs[u] = __popcll(__ballot(pv > kk[u]));  // chunks whose last key ranks ahead of the new key
-                            ee[u] = pool[min((tcs[u] << 6) + lane, cap)];
+            bool keep;
+            int rold;
+            if (fresh) {
+                bool cand = nn >= 0;
+                if (np >= rk && score < bscore) cand = false;  // below the boundary for good
+                // ---- rank of the surviving keys in the pool; "same node" = equal up to the low bits ----
+                int rold_a = 0;
+                unsigned long long todo_m = __ballot(cand);
+                if (__popcll(todo_m) > 6) {
+                    // many survivors (the pool is still filling: every neighbour is a candidate): per-lane 8-ary search, all
+                    // lanes at once, cost independent of their number
+                    if (cand) {
+                        int lo = 0;
+                        if (CAPK == 3) lo = rank_level<512, 8>(pool, lo, cap, v);
+                        if (CAPK == 2) lo = rank_level<512, 4>(pool, lo, cap, v);
+                        if (CAPK == 1) lo = rank_level<256, 4>(pool, lo, cap, v);
+                        if (CAPK == 1) lo = rank_level<64, 4>(pool, lo, cap, v);
+                        else lo = rank_level<64, 8>(pool, lo, cap, v);
+                        lo = rank_level<8, 8>(pool, lo, cap, v);
+                        int64_t p3[9];
+    #pragma unroll
+                        for (int k2 = 0; k2 < 9; k2++) p3[k2] = pool[min(lo + k2, cap)];
+                        int c3 = 0;
+                        bool dup = false;
+    #pragma unroll
+                        for (int k2 = 0; k2 < 9; k2++) {
+                            if (k2 < 8) c3 += p3[k2] > v ? 1 : 0;
+                            dup |= (p3[k2] | 3ll) == v;
                         }
+                        rold_a = lo + c3;
+                        if (dup) cand = false;
                     }
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        if (jj[u] >= 0) {
-                            const int r = (tcs[u] << 6) + __popcll(__ballot(ee[u] > kk[u]));
-                            const bool dup = __ballot((ee[u] | 3ll) == kk[u]) != 0ull;  // same node => same score => same key up to the low bits
-                            if (lane == jj[u]) {
-                                rold = r;
-                                if (dup) keep = false;
+                } else {
+                    const int vlo_ = (int)(uint32_t)(v & 0xFFFFFFFFll), vhi_ = (int)(v >> 32);
+                    while (todo_m) {
+                        int jj[4], tcs[4];
+                        int64_t kk[4], ee[4];
+    #pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            jj[u] = -1;
+                            tcs[u] = 0;
+                            kk[u] = 0;
+                            ee[u] = 0;
+                            if (todo_m) {
+                                const int j = __ffsll((long long)todo_m) - 1;
+                                todo_m &= todo_m - 1ull;
+                                jj[u] = j;
+                                kk[u] = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(vhi_, j) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane(vlo_, j));
+                                tcs[u] = __popcll(__ballot(pv > kk[u]));  // chunks whose last key ranks ahead of the new key
+                                ee[u] = pool[min((tcs[u] << 6) + lane, cap)];
+                            }
+                        }
+    #pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            if (jj[u] >= 0) {
+                                const int r = (tcs[u] << 6) + __popcll(__ballot(ee[u] > kk[u]));
+                                const bool dup = __ballot((ee[u] | 3ll) == kk[u]) != 0ull;  // same node => same score => same key up to the low bits
+                                if (lane == jj[u]) {
+                                    rold_a = r;
+                                    if (dup) cand = false;
+                                }
                             }
                         }
                     }
                 }
+                rold_s = rold_a;
+                cand_s = cand;
+                keep = cand && hf == 0;
+                rold = rold_a;
+            } else {
+                // the runner-up's half: ranked against the pool as it was before the first half's keys went in
+                keep = cand_s && hf == 1;
+                if (np >= rk && score < bscore) keep = false;  // (the boundary may have risen since)
+                rold = rold_s;
+                unsigned long long it = ins_lo;
+                const int vlo2 = (int)(uint32_t)(v & 0xFFFFFFFFll), vhi2 = (int)(v >> 32);
+                while (it) {
+                    const int j = __ffsll((long long)it) - 1;
+                    it &= it - 1ull;
+                    const int64_t kj = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(vhi2, j) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane(vlo2, j));
+                    rold += kj > v ? 1 : 0;
+                    if (kj == v) keep = false;  // the same node in both rows: it went in with the first half
+                }
             }
             unsigned long long km = __ballot(keep);
             int nk = __popcll(km);
+            if (fresh) ins_lo = km;  // (twins inside the row are taken out below)
             PQW_STAMP_COUNT(8, __popcll(km))
             PQW_STAMP(3)  // boundary test + rank search + duplicate test
             if (nk > 0) {
@@ -457,10 +484,18 @@ __device__ void search_one_pqw(const JvIndexDev& ix, const JvSearchArgs& a, cons
                 if (nk == 1) {
                     // the common case: one new key, every entry behind it moves up by one
                     r_min = r_max = __builtin_amdgcn_readlane(rold, __ffsll((long long)km) - 1);
-                    for (int t = (np - 1) >> 6; t >= (r_min >> 6); t--) {
-                        const int pos = (t << 6) + lane;
-                        const int64_t e = pool[min(pos, cap)];
-                        if (pos < np && pos >= r_min) pool[pos + 1] = e;
+                    // (four chunks are read before the first is written back: one LDS round trip per four chunks instead of
+                    //  one per chunk — the pool wave's time is mostly such round trips)
+                    const int t_lo = r_min >> 6;
+                    for (int t0 = (np - 1) >> 6; t0 >= t_lo; t0 -= 4) {
+                        int64_t e4[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) e4[u] = pool[min((max(t0 - u, 0) << 6) + lane, cap)];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const int pos = ((t0 - u) << 6) + lane;
+                            if (t0 - u >= t_lo && pos < np && pos >= r_min) pool[pos + 1] = e4[u];
+                        }
                     }
                 } else {
                     // every kept key is read out of its lane in turn and compared by all lanes at once: rank among the new
@@ -483,6 +518,7 @@ __device__ void search_one_pqw(const JvIndexDev& ix, const JvSearchArgs& a, cons
                         keep = keep && !twin;
                         km = km2;
                         nk = __popcll(km);
+                        if (fresh) ins_lo = km;
                     }
                     const int lane_first = __ffsll((long long)__ballot(keep && rnew == 0)) - 1;     // largest new key
                     const int lane_last = __ffsll((long long)__ballot(keep && rnew == nk - 1)) - 1;  // smallest new key
@@ -491,21 +527,30 @@ __device__ void search_one_pqw(const JvIndexDev& ix, const JvSearchArgs& a, cons
                     PQW_STAMP(14)  // (diagnostic) ranks among the new keys
                     // in-place shift, from the last occupied chunk down to the chunk of the first insertion point
                     const int t_mixed = r_max >> 6;  // chunks above it shift uniformly by nk
-                    for (int t = (np - 1) >> 6; t >= (r_min >> 6); t--) {
-                        const int pos = (t << 6) + lane;
-                        const int64_t e = pool[min(pos, cap)];
-                        int cnt = nk;
-                        if (t <= t_mixed) {
-                            const int cs0 = t << 6;
-                            cnt = __popcll(__ballot(keep && rold <= cs0));
-                            unsigned long long inm = __ballot(keep && rold > cs0 && rold <= cs0 + 63);
-                            while (inm) {
-                                const int j = __ffsll((long long)inm) - 1;
-                                inm &= inm - 1ull;
-                                cnt += pos >= __builtin_amdgcn_readlane(rold, j) ? 1 : 0;
+                    const int t_lo = r_min >> 6;
+                    for (int t0 = (np - 1) >> 6; t0 >= t_lo; t0 -= 4) {
+                        int64_t e4[4];  // (four chunks in flight, as above)
+#pragma unroll
+                        for (int u = 0; u < 4; u++) e4[u] = pool[min((max(t0 - u, 0) << 6) + lane, cap)];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const int t = t0 - u;
+                            if (t >= t_lo) {
+                                const int pos = (t << 6) + lane;
+                                int cnt = nk;
+                                if (t <= t_mixed) {
+                                    const int cs0 = t << 6;
+                                    cnt = __popcll(__ballot(keep && rold <= cs0));
+                                    unsigned long long inm = __ballot(keep && rold > cs0 && rold <= cs0 + 63);
+                                    while (inm) {
+                                        const int j = __ffsll((long long)inm) - 1;
+                                        inm &= inm - 1ull;
+                                        cnt += pos >= __builtin_amdgcn_readlane(rold, j) ? 1 : 0;
+                                    }
+                                }
+                                if (pos < np && cnt > 0) pool[pos + cnt] = e4[u];
                             }
                         }
-                        if (pos < np && cnt > 0) pool[pos + cnt] = e;
                     }
                 }
                 if (keep) pool[rold + rnew] = v;
