@@ -739,6 +739,22 @@ def cpu_baseline(torch, binding, eng, rk, budget_s):
     same_ids = bool(np.array_equal(eng.out_nodes[:m].cpu().numpy(), r.nodes[:m]))
     same_bits = bool(np.array_equal(eng.out_scores[:m].cpu().numpy().view(np.uint32), r.scores[:m].view(np.uint32)))
     same_stats = bool(np.array_equal(eng.out_stats[:m].cpu().numpy(), r.stats[:m]))
+    # the same sample with the explicit AVX2 paths (look-up-table gathers, software prefetch of code rows and rerank rows):
+    # same operation order, so the answers must be identical; the better of the two is `value`
+    simd = None
+    try:
+        orc.lib.jvo_set_simd(1)
+        orc.search_batch(sample[:min(4 * cores, nsample)], k, rk, threads=cores)
+        t3 = time.perf_counter()
+        r2 = orc.search_batch(sample, k, rk, threads=cores)
+        dt_simd = time.perf_counter() - t3
+        simd = {"qps": round(nsample / dt_simd, 1), "ids_equal_plain_loops": bool(np.array_equal(r2.nodes, r.nodes)),
+                "score_bits_equal_plain_loops": bool(np.array_equal(r2.scores.view(np.uint32), r.scores.view(np.uint32)))}
+    finally:
+        orc.lib.jvo_set_simd(0)
+    plain_qps = nsample / dt
+    if simd and simd["qps"] > plain_qps and simd["ids_equal_plain_loops"]:
+        dt = dt_simd
     # single-thread figure (the reference's JMH style is one thread)
     n1 = max(8, min(256, nsample))
     orc.search_batch(sample[:8], k, rk, threads=1)
@@ -757,6 +773,7 @@ def cpu_baseline(torch, binding, eng, rk, budget_s):
             "sample": f"{nsample} queries of the same workload, same index/rerankK, OpenMP one query per thread with "
                       f"per-thread reusable searcher scratch ({dt:.1f}s); C restatement of jVector's search (real jVector "
                       f"needs a JVM: not available)",
+            "plain_loops_qps": round(plain_qps, 1), "explicit_avx2": simd,
             "single_thread_qps": round(n1 / dt1, 1), "cpu_model": cpu_model,
             "host_threads": host_threads, "cpu_quota_cpus": quota, "gpu_ids_equal_oracle_on_sample": same_ids,
             "gpu_score_bits_equal_oracle_on_sample": same_bits, "gpu_counters_equal_oracle_on_sample": same_stats}

@@ -261,6 +261,15 @@ int jv_search_sharded_batch(jv_shard_group* group, const float* queries, int32_t
                             float threshold, float rerankFloor, int32_t* out_docs, float* out_scores,
                             int32_t* out_count, int32_t* out_stats);
 
+/* The same with jv_search_params: the doc filter is a bitset over the GLOBAL doc-id space of the group (every shard's
+ * ord2doc maps into it; the reference hands every leaf search its acceptDocs, J/JVectorReader.java:157-163), visit_limit
+ * applies to every shard's search on its own, out_status[i] (optional) is JV_OK / JV_ENOMEM per query, out_flags[i] (optional)
+ * the OR of the shards' JV_QFLAG_* words (EARLY_TERMINATED: at least one shard stopped at the visit limit and contributed
+ * nothing).  On any error every stream of the group is drained before the call returns. */
+int jv_search_sharded_batch_ex(jv_shard_group* group, const float* queries, int32_t nq, const jv_search_params* params,
+                               int32_t* out_docs, float* out_scores, int32_t* out_count, int32_t* out_stats,
+                               int32_t* out_status, int32_t* out_flags);
+
 /* Thread-local message of the calling thread's most recent failing call ("" if none). */
 const char* jv_last_error(void);
 

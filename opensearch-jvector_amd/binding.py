@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "jv_index_create", "jv_index_destroy", "jv_search", "jv_search_batch", "jv_search_batch_device",
     "jv_score_ordinals", "jv_merge_topk_device", "jv_index_get_info", "jv_set_option", "jv_last_error",
     "jv_abi_version", "jv_search_ex", "jv_search_batch_ex", "jv_index_set_option", "jv_index_get_counter", "jv_shard_group_create",
-    "jv_shard_group_destroy", "jv_search_sharded_batch",
+    "jv_shard_group_destroy", "jv_search_sharded_batch", "jv_search_sharded_batch_ex",
 ]
 QFLAG_RETRIED_BIG, QFLAG_EARLY_TERMINATED = 0x1, 0x2
 
@@ -257,6 +257,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.jv_shard_group_destroy.restype = None
     lib.jv_search_sharded_batch.argtypes = [vp, vp, i32, i32, i32, f32, f32, vp, vp, vp, vp]
     lib.jv_search_sharded_batch.restype = C.c_int
+    lib.jv_search_sharded_batch_ex.argtypes = [vp, vp, i32, C.POINTER(JvSearchParams), vp, vp, vp, vp, vp, vp]
+    lib.jv_search_sharded_batch_ex.restype = C.c_int
     _lib = lib
     return lib
 
@@ -451,6 +453,33 @@ class ShardGroup:
         _check(self.lib, self.lib.jv_search_sharded_batch(self.handle, q.ctypes.data, nq, topK, rerankK, threshold, rerank_floor,
                                                           docs.ctypes.data, scores.ctypes.data, count.ctypes.data, stats.ctypes.data))
         return SearchResult(docs.copy(), docs, scores, count, stats)
+
+
+    def search_batch_ex(self, queries: np.ndarray, topK: int, rerankK: int, threshold: float = 0.0, rerank_floor: float = 0.0,
+                        accept: Optional[np.ndarray] = None, accept_num_docs: int = 0, visit_limit: int = 0):
+        """jv_search_sharded_batch_ex: doc filter over the GLOBAL doc-id space, visit limit per shard search; returns
+        (SearchResult, status [nq], flags [nq], rc)."""
+        q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, self.d)
+        nq = q.shape[0]
+        docs = np.full((nq, topK), -1, dtype=np.int32)
+        scores = np.zeros((nq, topK), dtype=np.float32)
+        count = np.zeros(nq, dtype=np.int32)
+        stats = np.zeros((nq, NUM_STATS), dtype=np.int32)
+        status = np.zeros(nq, dtype=np.int32)
+        flags = np.zeros(nq, dtype=np.int32)
+        acc = None if accept is None else np.ascontiguousarray(accept, dtype=np.uint64)
+        p = JvSearchParams()
+        p.struct_size = C.sizeof(JvSearchParams)
+        p.topK, p.rerankK, p.threshold, p.rerankFloor = topK, rerankK, threshold, rerank_floor
+        p.accept_doc_words = _ptr(acc)
+        p.accept_num_docs = accept_num_docs
+        p.visit_limit = visit_limit
+        p.accept_key = 0
+        rc = self.lib.jv_search_sharded_batch_ex(self.handle, q.ctypes.data, nq, C.byref(p), docs.ctypes.data, scores.ctypes.data,
+                                                 count.ctypes.data, stats.ctypes.data, status.ctypes.data, flags.ctypes.data)
+        if rc not in (JV_OK, JV_ENOMEM):
+            _check(self.lib, rc)
+        return SearchResult(docs.copy(), docs, scores, count, stats), status, flags, rc
 
 
 def merge_topk_device(device: int, d_docs: int, d_scores: int, nq: int, lists: int, k: int, d_out_docs: int,

@@ -19,7 +19,9 @@
 #include <vector>
 
 #include <errno.h>
+#include <sched.h>
 #include <semaphore.h>
+#include <time.h>
 
 #include "../../include/jvgpu.h"
 #include "jv_device.h"
@@ -52,6 +54,10 @@ int jvk_pqw_lds_rows(void);
 int jvk_pqw_blocks_per_cu(const JvIndexDev* ix, int cap, int lds_bytes);
 hipError_t jvk_launch_search_pqw(const JvIndexDev* ix, const JvSearchArgs* a, int lds_bytes, int blocks, hipStream_t s);
 void jvk_pqw_set_occ3(int on);
+// device-resident query server (jv_kernels_pqs.hip)
+hipError_t jvk_pqs_set_max_lds(int bytes);
+int jvk_pqs_blocks_per_cu(const JvIndexDev* ix, int cap, int lds_bytes);
+hipError_t jvk_launch_serve_pqw(const JvIndexDev* ix, const JvSearchArgs* a, int lds_bytes, int blocks, hipStream_t s);
 }
 
 namespace {
@@ -88,9 +94,12 @@ int fail(int code, const char* fmt, ...) {
 //   combine / combine_leaders / combine_max_batch   group commit of concurrent jv_search calls
 //   max_contexts                         cap of per-index launch contexts (callers beyond it wait)
 //   filter_cache                         device-resident doc-filter bitsets kept per index (0 = off)
+//   serve / serve_wgs_per_cu / serve_idle_ms   device-resident query server for one-query calls (resident workgroups per CU, idle time before it leaves)
+//   lazy_big_rung                        host-pointer calls enqueue the HBM-scratch rung only when a row came back flagged (it serialises batches otherwise)
+//   direct_completion                    combined one-query calls: rows land in pinned memory, every caller is woken by its own query's completion word
 //   lutr_min_queries                     launches with more queries keep the PQ look-up table in registers (-1 = 4 per CU)
 //   dbg_ptr                              diagnostic build only
-enum OptId { OPT_LDS_VISITED_SLOTS, OPT_LDS_CANDIDATES, OPT_FORCE_BIG, OPT_FORCE_GENERAL, OPT_NO_ESCALATION, OPT_DBG_PTR, OPT_NO_PQF, OPT_NO_PQP, OPT_NO_LUTR, OPT_LUTR_MIN_QUERIES, OPT_PQP_BLOCKS_PER_CU, OPT_NO_PQW, OPT_PQW_MIN_QUERIES, OPT_PQW_OCC3, OPT_PQF_ONLY, OPT_SPILL_TABLES, OPT_SPILL_SLOTS, OPT_BIG_BLOCKS, OPT_BIG_CAND_CAP, OPT_BIG_BUDGET_MB, OPT_COMBINE, OPT_COMBINE_LEADERS, OPT_COMBINE_MAX_BATCH, OPT_MAX_CONTEXTS, OPT_FILTER_CACHE, OPT_COUNT };
+enum OptId { OPT_LDS_VISITED_SLOTS, OPT_LDS_CANDIDATES, OPT_FORCE_BIG, OPT_FORCE_GENERAL, OPT_NO_ESCALATION, OPT_DBG_PTR, OPT_NO_PQF, OPT_NO_PQP, OPT_NO_LUTR, OPT_LUTR_MIN_QUERIES, OPT_PQP_BLOCKS_PER_CU, OPT_NO_PQW, OPT_PQW_MIN_QUERIES, OPT_PQW_OCC3, OPT_PQF_ONLY, OPT_SPILL_TABLES, OPT_SPILL_SLOTS, OPT_BIG_BLOCKS, OPT_BIG_CAND_CAP, OPT_BIG_BUDGET_MB, OPT_COMBINE, OPT_COMBINE_LEADERS, OPT_COMBINE_MAX_BATCH, OPT_MAX_CONTEXTS, OPT_FILTER_CACHE, OPT_DIRECT_COMPLETION, OPT_LAZY_BIG, OPT_SERVE, OPT_SERVE_WGS_PER_CU, OPT_SERVE_IDLE_MS, OPT_COUNT };
 struct OptName { const char* name; int64_t def; };
 const OptName kOptNames[OPT_COUNT] = {
     {"lds_visited_slots", 0},
@@ -118,6 +127,11 @@ const OptName kOptNames[OPT_COUNT] = {
     {"combine_max_batch", 2048},
     {"max_contexts", 8},
     {"filter_cache", 8},
+    {"direct_completion", 1},
+    {"lazy_big_rung", 1},
+    {"serve", 1},
+    {"serve_wgs_per_cu", 2},
+    {"serve_idle_ms", 100},
 };
 struct Opts {
     std::atomic<int64_t> v[OPT_COUNT];
@@ -159,6 +173,11 @@ struct Ctx {
     size_t arena_cap = 0;
     float* h_query = nullptr;    // pinned staging for small query batches
     size_t h_query_cap = 0;
+    // combined one-query calls: the kernels write the rows straight into this pinned, device-visible arena
+    // [nodes|docs|scores|count|stats|flags|done] and the owner of a query is woken when ITS completion word is set
+    uint8_t* h_direct = nullptr;
+    size_t direct_cap = 0;
+    hipEvent_t ev_direct = nullptr;
     int32_t* work_counter = nullptr;  // [0] big-path dequeue, [1] spill-table allocator, [2..] rung counters
     // pool of visited-set spill tables of the generic kernels (allocated on the first launch that can use it)
     uint32_t* spill = nullptr;
@@ -231,6 +250,7 @@ struct FilterEntry {
 
 }  // namespace
 
+struct JvQueryServer;
 struct jv_index {
     Opts opts;
     Combiner combiner;
@@ -253,8 +273,10 @@ struct jv_index {
     std::mutex async_mu;
     // launches per kernel family since creation (jv_index_get_counter): which rung served a call is observable
     std::atomic<int64_t> launches[8] = {};
+    struct JvQueryServer* server = nullptr;  // device-resident query server (created by the first eligible one-query call)
+    std::mutex server_mu;
 };
-enum { LAUNCH_PQW = 0, LAUNCH_PQP, LAUNCH_PQF, LAUNCH_LDS, LAUNCH_BIG };
+enum { LAUNCH_PQW = 0, LAUNCH_PQP, LAUNCH_PQF, LAUNCH_LDS, LAUNCH_BIG, LAUNCH_SERVE, SERVED_QUERIES };
 
 #define OPT(ixp, id) ((ixp)->opts.v[id].load(std::memory_order_relaxed))
 
@@ -272,9 +294,15 @@ int dev_alloc(jv_index* ix, T** out, size_t count) {
     return JV_OK;
 }
 
+void free_with_servers_paused(void* p);  // hipFree synchronises the device: resident query servers must leave first
+static inline hipError_t jv_free(void* p) {
+    free_with_servers_paused(p);
+    return hipSuccess;
+}
+
 int grow(void** p, size_t* cap, size_t need, size_t elem) {
     if (need <= *cap && *p) return JV_OK;
-    if (*p) HIPCHK(hipFree(*p));
+    if (*p) jv_free(*p);
     *p = nullptr;
     size_t ncap = need < 16 ? 16 : need + need / 2;
     HIPCHK(hipMalloc(p, ncap * elem));
@@ -298,15 +326,17 @@ int ctx_create(jv_index* ix, Ctx** out) {
 
 void ctx_destroy(Ctx* c) {
     if (!c) return;
-    hipFree(c->d_queries);
-    hipFree(c->d_flags);
-    hipFree(c->d_accept);
-    hipFree(c->d_arena);
+    jv_free(c->d_queries);
+    jv_free(c->d_flags);
+    jv_free(c->d_accept);
+    jv_free(c->d_arena);
     if (c->h_arena) hipHostFree(c->h_arena);
     if (c->h_query) hipHostFree(c->h_query);
-    hipFree(c->work_counter);
-    hipFree(c->spill);
-    hipFree(c->pqp_log);
+    if (c->h_direct) hipHostFree(c->h_direct);
+    if (c->ev_direct) hipEventDestroy(c->ev_direct);
+    jv_free(c->work_counter);
+    jv_free(c->spill);
+    jv_free(c->pqp_log);
     if (c->last_use) hipEventDestroy(c->last_use);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -426,14 +456,14 @@ int ensure_big(jv_index* ix, DeviceScratch& sc, int rk, int* cap_out, int* block
     // grow: wait for the launches still using the old buffers
     HIPCHK(hipEventSynchronize(sc.last_use));
     if (sc.vis_bytes < need_vis || !sc.big_visited) {
-        if (sc.big_visited) HIPCHK(hipFree(sc.big_visited));
+        if (sc.big_visited) HIPCHK(jv_free(sc.big_visited));
         sc.big_visited = nullptr;
         sc.vis_bytes = 0;
         HIPCHK(hipMalloc((void**)&sc.big_visited, need_vis));
         sc.vis_bytes = need_vis;
     }
     if (sc.cand_bytes < need_cand || !sc.big_cand) {
-        if (sc.big_cand) HIPCHK(hipFree(sc.big_cand));
+        if (sc.big_cand) HIPCHK(jv_free(sc.big_cand));
         sc.big_cand = nullptr;
         sc.cand_bytes = 0;
         HIPCHK(hipMalloc((void**)&sc.big_cand, need_cand));
@@ -446,7 +476,7 @@ int ensure_big(jv_index* ix, DeviceScratch& sc, int rk, int* cap_out, int* block
 int ensure_spill(jv_index* ix, Ctx* c) {
     const int st = (int)OPT(ix, OPT_SPILL_TABLES), ss = next_pow2((int)OPT(ix, OPT_SPILL_SLOTS));
     if (c->spill_tables != st || c->spill_slots != ss) {
-        if (c->spill) HIPCHK(hipFree(c->spill));
+        if (c->spill) HIPCHK(jv_free(c->spill));
         c->spill = nullptr;
         c->spill_tables = c->spill_slots = 0;
         if (st > 0 && ss > 0) {
@@ -458,11 +488,34 @@ int ensure_spill(jv_index* ix, Ctx* c) {
     return JV_OK;
 }
 
+// LDS plan of the several-waves pool kernel for a pool of x.cand_cap entries:
+// [pool | centred query | table rows | hash set | rerank scratch] + the waves' exchange rows + ctrl words
+int plan_pqw_lds(const jv_index* ix, JvSearchArgs& x) {
+    const int Wn = jvk_pqw_waves(&ix->dev);
+    const int qc_b = ix->dev.nch * 64 * 4;
+    const int pool_b = (x.cand_cap + 1) * 8;
+    const int rr_b = qc_b + Wn * JV_TODO * 8 + (x.cand_cap + 64) * 8;
+    x.pqw_lut_off = (std::max(pool_b, qc_b) + 15) & ~15;  // table rows kept in LDS, behind the pool / the centred query
+    const int lut_end = x.pqw_lut_off + Wn * jvk_pqw_lds_rows() * 1024;
+    const int front = (std::max(std::max(16384, lut_end), std::max(qc_b, rr_b)) + 15) & ~15;
+    x.pqp_pool_off = 0;
+    x.pqp_qc_off = 0;
+    x.pqp_scratch_off = front;
+    x.pqp_lds_bytes = front + Wn * 256 + 64 + 128;  // (+ the diagnostic build's phase accumulators)
+    return x.pqp_lds_bytes;
+}
+
 // enqueue one batch on `stream`; all pointers are device pointers
 int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queries, int nq, int topK, int rk,
                   float thr, float floor_, const uint64_t* d_accept, int64_t accept_docs, int32_t* d_nodes,
                   int32_t* d_docs, float* d_scores, int32_t* d_count, int32_t* d_stats, int32_t* d_flags,
-                  int64_t accept_stride = 0, int64_t visit_limit = 0) {
+                  int64_t accept_stride = 0, int64_t visit_limit = 0, int32_t* done = nullptr, int phase = 0,
+                  bool* big_deferred = nullptr) {
+    // phase 0: the whole ladder (device-pointer API: nothing can be decided on the host between the rungs);
+    // phase 1: the on-chip rungs only — the HBM-scratch rung lives in ONE arena per device and chains every batch behind the
+    //          previous one through its event, so host-pointer callers enqueue it only when a row actually came back flagged
+    //          (*big_deferred says whether that is still owed);  phase 2: the HBM-scratch rung alone, for the flagged rows.
+    if (big_deferred) *big_deferred = false;
     const bool pq = ix->dev.pq_M > 0;
     // the single-pool form is exact only without a filter and with threshold <= 0 (kernel re-checks scores)
     Geometry g = plan_geometry(ix, rk, d_accept == nullptr && thr <= 0.0f, 0, thr > 0.0f);
@@ -492,6 +545,7 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
     a.cand_cap = g.cand_cap;
     a.res_cap = g.res_cap;
     a.visit_limit = visit_limit > 0 ? (int32_t)std::min<int64_t>(visit_limit, INT32_MAX) : 0;
+    a.done = done;  // (completion words: honoured by the several-waves pool kernel; rows of other kernels are final at stream end)
     a.work_counter = c->work_counter;
     a.retry_only = 0;
     a.spill = c->spill;
@@ -502,6 +556,7 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
     a.dbg = (int64_t*)(uintptr_t)OPT(ix, OPT_DBG_PTR);  // always 0 unless a diagnostic run set it
     const bool force_big = OPT(ix, OPT_FORCE_BIG) != 0 || !g.fast_ok;
     HIPCHK(hipMemsetAsync(c->work_counter, 0, 8 * sizeof(int32_t), stream));
+    if (phase != 2) {
     // headline path: PQ + fused layout + single pool + flat graph -> specialised kernel without an in-loop
     // visited set (jv_kernels.hip "PQF"); anything it cannot hold is flagged and falls through to the ladder
     bool pqf = false;
@@ -571,20 +626,7 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
         // wave per chunk.  LDS = [pool | centred query | hash set | rerank scratch] + the waves' exchange rows + ctrl words.
         const bool pqw = !filtered && OPT(ix, OPT_NO_PQW) == 0 && jvk_pqw_ok(&ix->dev, ap.cand_cap) && nq >= OPT(ix, OPT_PQW_MIN_QUERIES);
         if (pqw) jvk_pqw_set_occ3(OPT(ix, OPT_PQW_OCC3) != 0 ? 1 : 0);  // (diagnostic switch, process-wide)
-        auto plan_w = [&](JvSearchArgs& x) {
-            const int Wn = jvk_pqw_waves(&ix->dev);
-            const int pool_b = (x.cand_cap + 1) * 8;
-            const int rr_b = qc_b + Wn * JV_TODO * 8 + (x.cand_cap + 64) * 8;
-            x.pqw_lut_off = (std::max(pool_b, qc_b) + 15) & ~15;  // table rows kept in LDS, behind the pool / the centred query
-            const int lut_end = x.pqw_lut_off + Wn * jvk_pqw_lds_rows() * 1024;
-            const int front = (std::max(std::max(16384, lut_end), std::max(qc_b, rr_b)) + 15) & ~15;
-            x.pqp_pool_off = 0;
-            x.pqp_qc_off = 0;
-            x.pqp_scratch_off = front;
-            x.pqp_lds_bytes = front + Wn * 256 + 64 + 128;  // (+ the diagnostic build's phase accumulators)
-            return x.pqp_lds_bytes;
-        };
-        const int lds = pqw ? plan_w(ap) : plan(ap, lutr != 0);
+        const int lds = pqw ? plan_pqw_lds(ix, ap) : plan(ap, lutr != 0);
         // second launch for what outgrows the first (more than 63 ties at the rerankK boundary, a longer expansion log):
         // table in LDS, as many tie slots as the largest pool class allows, 4x the log; walks the flag array
         JvSearchArgs ap2 = ap;
@@ -605,7 +647,7 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
             size_t need = (size_t)blocks * (size_t)ap.pqp_log_cap;
             if (second) need = std::max(need, (size_t)blocks2 * (size_t)ap2.pqp_log_cap);
             if (need > c->pqp_log_ints) {
-                if (c->pqp_log) HIPCHK(hipFree(c->pqp_log));
+                if (c->pqp_log) HIPCHK(jv_free(c->pqp_log));
                 c->pqp_log = nullptr;
                 c->pqp_log_ints = 0;
                 HIPCHK(hipMalloc((void**)&c->pqp_log, need * sizeof(int32_t)));
@@ -685,6 +727,11 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
             }
         }
     }
+    }
+    if (phase == 1 && !force_big) {
+        if (big_deferred) *big_deferred = true;
+        return JV_OK;
+    }
     {
         // last rung: the device's shared HBM scratch; its users are ordered through the scratch event
         DeviceScratch& sc = g_scratch[ix->device & 63];
@@ -713,6 +760,267 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
         HIPCHK(hipEventRecord(sc.last_use, stream));
     }
     return JV_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Device-resident query server (kernel: jv_serve_pqw_kernel, jv_pqw_body.h).  One-query calls on shapes the several-waves
+// pool kernel runs (PQ-32 / PQ-64 fused, no filter, threshold <= 0) do not launch anything: the caller copies its query into
+// a slot of a pinned ring, publishes it in ticket order and sleeps until the slot's completion word is set.  The grid is
+// started on demand, leaves by itself after `serve_idle_ms` without work and is asked to leave (STOP) before anything in this
+// library synchronises the device or frees memory.
+// ---------------------------------------------------------------------------------------------------------------------
+}  // namespace
+struct JvQueryServer {
+    jv_index* ix = nullptr;
+    hipStream_t stream = nullptr;
+    unsigned char* ring = nullptr;  // pinned, device-visible: [slots][slot_bytes]
+    int32_t* h_words = nullptr;     // pinned: JV_SH_*
+    int32_t* d_words = nullptr;     // device: JV_SV_*
+    int32_t* log = nullptr;         // device: expansion logs of the resident workgroups
+    int slots = 0, slot_bytes = 0, cap_max = 0, blocks = 0, lds = 0;
+    JvSearchArgs args{};
+    std::atomic<uint32_t> reserve{0};
+    std::atomic<uint32_t>* slot_free = nullptr;  // slot i may be filled by the call holding sequence number slot_free[i]
+    std::mutex mu;                  // launch / stop
+    std::atomic<int> inflight{0};
+    std::atomic<int> lat_us{3000};  // running estimate of one query's latency (how long a caller sleeps before it polls)
+};
+namespace {
+typedef JvQueryServer Server;
+
+std::mutex g_servers_mu;
+std::vector<Server*> g_servers;  // every live server of the process (device-wide synchronisation points pause them)
+
+void server_stop_locked(Server* sv) {  // sv->mu held: ask the grid to leave and wait until it has
+    if (!sv->stream) return;
+    __atomic_store_n(&sv->h_words[JV_SH_STOP], 1, __ATOMIC_RELEASE);
+    hipStreamSynchronize(sv->stream);
+    __atomic_store_n(&sv->h_words[JV_SH_ALIVE], 0, __ATOMIC_RELEASE);
+    __atomic_store_n(&sv->h_words[JV_SH_STOP], 0, __ATOMIC_RELEASE);
+}
+
+// RAII: no query server runs on `device` while this object lives (hipFree / hipDeviceSynchronize would otherwise wait for
+// a grid that only leaves when it is idle).  Callers that arrive meanwhile wait on the servers' launch mutexes.
+struct ServerPause {
+    std::vector<Server*> held;
+    explicit ServerPause(int device) {
+        std::lock_guard<std::mutex> g(g_servers_mu);
+        for (Server* sv : g_servers)
+            if (sv->ix->device == device) {
+                sv->mu.lock();
+                server_stop_locked(sv);
+                held.push_back(sv);
+            }
+    }
+    ~ServerPause() {
+        for (Server* sv : held) sv->mu.unlock();
+    }
+};
+
+void free_with_servers_paused(void* p) {
+    if (!p) return;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    bool any;
+    {
+        std::lock_guard<std::mutex> g(g_servers_mu);
+        any = !g_servers.empty();
+    }
+    if (any) {
+        ServerPause pause(dev);
+        hipFree(p);
+    } else {
+        hipFree(p);
+    }
+}
+
+void server_destroy(jv_index* ix) {
+    Server* sv = ix->server;
+    if (!sv) return;
+    {
+        std::lock_guard<std::mutex> g(g_servers_mu);
+        g_servers.erase(std::remove(g_servers.begin(), g_servers.end(), sv), g_servers.end());
+    }
+    {
+        std::lock_guard<std::mutex> lk(sv->mu);
+        server_stop_locked(sv);
+    }
+    if (sv->stream) hipStreamDestroy(sv->stream);
+    if (sv->ring) hipHostFree(sv->ring);
+    if (sv->h_words) hipHostFree(sv->h_words);
+    hipFree(sv->d_words);
+    hipFree(sv->log);
+    delete[] sv->slot_free;
+    delete sv;
+    ix->server = nullptr;
+}
+
+int server_launch_locked(Server* sv) {  // sv->mu held, grid not alive
+    jv_index* ix = sv->ix;
+    HIPCHK(hipSetDevice(ix->device));
+    // tickets continue where the last grid stopped: HEAD / PUBLISHED stay, the exit count and the idle clock restart
+    HIPCHK(hipMemsetAsync(sv->d_words + JV_SV_LOCK, 0, 4 * sizeof(int32_t), sv->stream));  // LOCK, EXITED, LAST_CLAIM, STOP_SEEN
+    __atomic_store_n(&sv->h_words[JV_SH_ALIVE], 1, __ATOMIC_RELEASE);
+    hipError_t e = jvk_launch_serve_pqw(&ix->dev, &sv->args, sv->lds, sv->blocks, sv->stream);
+    if (e != hipSuccess) {
+        __atomic_store_n(&sv->h_words[JV_SH_ALIVE], 0, __ATOMIC_RELEASE);
+        return fail(JV_EDEVICE, "query server launch failed: %s", hipGetErrorString(e));
+    }
+    ix->launches[LAUNCH_SERVE]++;
+    return JV_OK;
+}
+
+// the index's server, able to hold pools of `need_cap` entries; nullptr (with *rc set) when it cannot be provided
+Server* server_get(jv_index* ix, int need_cap, int* rc) {
+    *rc = JV_OK;
+    std::lock_guard<std::mutex> lk(ix->server_mu);
+    if (ix->server && ix->server->cap_max >= need_cap) return ix->server;
+    if (ix->server) {  // a larger beam than the ring was planned for: rebuild it once nothing is in flight
+        Server* old = ix->server;
+        while (old->inflight.load() > 0) sched_yield();
+        server_destroy(ix);
+    }
+    if (hipSetDevice(ix->device) != hipSuccess) {
+        *rc = fail(JV_EDEVICE, "hipSetDevice failed");
+        return nullptr;
+    }
+    Server* sv = new Server();
+    sv->ix = ix;
+    auto bail = [&](const char* what, hipError_t e) -> Server* {
+        *rc = fail(e == hipErrorOutOfMemory ? JV_ENOMEM : JV_EDEVICE, "query server: %s: %s", what, hipGetErrorString(e));
+        ix->server = sv;
+        server_destroy(ix);
+        return nullptr;
+    };
+    const int R = ix->dev.R;
+    sv->cap_max = std::min(2048, std::max(need_cap, 512));
+    JvSearchArgs& a = sv->args;
+    a = JvSearchArgs{};
+    a.cand_cap = sv->cap_max;
+    a.rk = sv->cap_max - 64 - R;
+    a.topK = 1;
+    a.nq = 1;
+    a.pqp_log_cap = (3 * a.rk + 64 + 3) & ~3;
+    sv->lds = plan_pqw_lds(ix, a);
+    const int per_cu = std::min<int>(jvk_pqs_blocks_per_cu(&ix->dev, sv->cap_max, sv->lds), (int)std::max<int64_t>(1, OPT(ix, OPT_SERVE_WGS_PER_CU)));
+    sv->blocks = ix->cu_count * per_cu;
+    sv->slots = next_pow2(std::max(1024, 2 * sv->blocks));
+    const int qbytes = ((ix->dev.nch * 64 * 4) + 255) & ~255;
+    sv->slot_bytes = (JV_SERVE_QUERY_OFF + qbytes + 255) & ~255;
+    hipError_t e = hipStreamCreateWithFlags(&sv->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) return bail("stream", e);
+    if ((e = hipHostMalloc((void**)&sv->ring, (size_t)sv->slots * sv->slot_bytes, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) return bail("ring", e);
+    if ((e = hipHostMalloc((void**)&sv->h_words, 64, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) return bail("host words", e);
+    memset(sv->h_words, 0, 64);
+    memset(sv->ring, 0, (size_t)sv->slots * sv->slot_bytes);
+    if ((e = hipMalloc((void**)&sv->d_words, 64)) != hipSuccess) return bail("device words", e);
+    if ((e = hipMemset(sv->d_words, 0, 64)) != hipSuccess) return bail("device words", e);
+    if ((e = hipMalloc((void**)&sv->log, (size_t)sv->blocks * (size_t)a.pqp_log_cap * sizeof(int32_t))) != hipSuccess) return bail("logs", e);
+    sv->slot_free = new std::atomic<uint32_t>[(size_t)sv->slots];
+    for (int i = 0; i < sv->slots; i++) sv->slot_free[i].store((uint32_t)i);
+    a.pqp_log = sv->log;
+    a.serve_ring = sv->ring;
+    a.serve_slots = sv->slots;
+    a.serve_slot_bytes = sv->slot_bytes;
+    a.serve_dev = sv->d_words;
+    a.serve_host = sv->h_words;
+    a.serve_idle_ticks = (int32_t)std::min<int64_t>(2000000000, std::max<int64_t>(1, OPT(ix, OPT_SERVE_IDLE_MS)) * 100000);  // 100 MHz
+    a.done_all = 1;
+    ix->server = sv;
+    {
+        std::lock_guard<std::mutex> g(g_servers_mu);
+        g_servers.push_back(sv);
+    }
+    return sv;
+}
+
+// one query through the server.  Returns JV_OK with the row filled, a negative code, or +1 when the caller should take the
+// launch path instead (not eligible, or the row came back flagged for the ladder).
+int serve_query(jv_index* ix, const float* query, int32_t topK, int32_t rerankK, float rerankFloor, int64_t visit_limit,
+                int32_t* out_nodes, int32_t* out_docs, float* out_scores, int32_t* out_count, int32_t* out_stats, int32_t* out_flags) {
+    const int cap = rerankK + 64 + ix->dev.R;
+    if (OPT(ix, OPT_SERVE) == 0 || OPT(ix, OPT_NO_PQW) != 0 || OPT(ix, OPT_NO_PQF) != 0 || OPT(ix, OPT_NO_PQP) != 0 ||
+        OPT(ix, OPT_FORCE_BIG) != 0 || OPT(ix, OPT_FORCE_GENERAL) != 0 || OPT(ix, OPT_PQF_ONLY) != 0)
+        return 1;
+    if (topK < 1 || topK > JV_SERVE_TOPK_MAX || ix->dev.pq_M <= 0 || !ix->dev.pq_fused || !jvk_pqw_ok(&ix->dev, cap) || ix->build_client) return 1;
+    int rc = JV_OK;
+    Server* sv = server_get(ix, cap, &rc);
+    if (!sv) return rc != JV_OK ? rc : 1;
+    sv->inflight++;
+    struct Leave {
+        Server* sv;
+        ~Leave() { sv->inflight--; }
+    } leave{sv};
+    const uint32_t seq = sv->reserve.fetch_add(1);
+    const int si = (int)(seq & (uint32_t)(sv->slots - 1));
+    for (int spins = 0; sv->slot_free[si].load(std::memory_order_acquire) != seq; spins++) {  // the slot's previous occupant is still reading its row
+        if (spins > 64) sched_yield();
+    }
+    unsigned char* sp = sv->ring + (size_t)si * (size_t)sv->slot_bytes;
+    JvServeSlot* slot = (JvServeSlot*)sp;
+    slot->topK = topK;
+    slot->rk = rerankK;
+    slot->visit_limit = visit_limit > 0 ? (int32_t)std::min<int64_t>(visit_limit, INT32_MAX) : 0;
+    slot->rerank_floor = rerankFloor;
+    slot->done = 0;
+    slot->count = 0;
+    slot->flags = 0;
+    memcpy(sp + JV_SERVE_QUERY_OFF, query, (size_t)ix->dev.d * sizeof(float));
+    // publish in ticket order
+    for (int spins = 0; (uint32_t)__atomic_load_n(&sv->h_words[JV_SH_TAIL], __ATOMIC_ACQUIRE) != seq; spins++) {
+        if (spins > 256) sched_yield();
+    }
+    __atomic_store_n(&sv->h_words[JV_SH_TAIL], (int32_t)(seq + 1), __ATOMIC_RELEASE);
+    struct timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    auto ensure_alive = [&]() -> int {
+        if (__atomic_load_n(&sv->h_words[JV_SH_ALIVE], __ATOMIC_ACQUIRE) != 0) return JV_OK;
+        std::lock_guard<std::mutex> lk(sv->mu);
+        if (__atomic_load_n(&sv->h_words[JV_SH_ALIVE], __ATOMIC_ACQUIRE) != 0) return JV_OK;
+        hipStreamSynchronize(sv->stream);  // (the previous grid has signalled its exit: let its launch retire)
+        return server_launch_locked(sv);
+    };
+    if ((rc = ensure_alive()) != JV_OK) {
+        // nobody will ever answer this slot: give it back in order (the row is simply never read)
+        sv->slot_free[si].store(seq + (uint32_t)sv->slots, std::memory_order_release);
+        return rc;
+    }
+    // sleep through most of the expected latency, then poll
+    const int est = sv->lat_us.load(std::memory_order_relaxed);
+    long nap_ns = (long)est * 600;  // 0.6 x
+    for (int it = 0;; it++) {
+        if (__atomic_load_n(&slot->done, __ATOMIC_ACQUIRE) != 0) break;
+        if (it < 3 && est < 200) {
+            sched_yield();
+            continue;
+        }
+        struct timespec ts = {0, std::max<long>(20000, std::min<long>(nap_ns, 5000000))};
+        nanosleep(&ts, nullptr);
+        nap_ns = std::max<long>(20000, (long)est * 25);  // then every est / 40
+        if ((it & 7) == 7 && (rc = ensure_alive()) != JV_OK) {
+            sv->slot_free[si].store(seq + (uint32_t)sv->slots, std::memory_order_release);
+            return rc;
+        }
+    }
+    struct timespec t1;
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    const int us = (int)std::min<int64_t>(1000000, (int64_t)(t1.tv_sec - t0.tv_sec) * 1000000 + (t1.tv_nsec - t0.tv_nsec) / 1000);
+    sv->lat_us.store((est * 7 + us) / 8, std::memory_order_relaxed);
+    const uint32_t f = (uint32_t)slot->flags;
+    int ret = JV_OK;
+    if (f & (JV_FLAG_OVERFLOW | JV_FLAG_FAILED)) {
+        ret = 1;  // the ladder's business (boundary ties beyond the first launch's slack, rerankFloor corner, ...): launch path
+    } else {
+        if (out_nodes) memcpy(out_nodes, slot->nodes, sizeof(int32_t) * (size_t)topK);
+        if (out_docs) memcpy(out_docs, slot->docs, sizeof(int32_t) * (size_t)topK);
+        if (out_scores) memcpy(out_scores, slot->scores, sizeof(float) * (size_t)topK);
+        if (out_count) *out_count = slot->count;
+        if (out_stats) memcpy(out_stats, slot->stats, sizeof(int32_t) * 4);
+        if (out_flags) *out_flags = (int32_t)(f & (JV_FLAG_BIG | JV_FLAG_EARLY));
+        ix->launches[SERVED_QUERIES]++;
+    }
+    sv->slot_free[si].store(seq + (uint32_t)sv->slots, std::memory_order_release);
+    return ret;
 }
 
 int check_common(jv_index* index, const void* q, int nq, int topK, int rk, float thr) {
@@ -752,13 +1060,17 @@ int jv_index_set_option(jv_index* index, const char* name, int64_t value) {
 void jv_index_destroy(jv_index* ix) {
     if (!ix) return;
     hipSetDevice(ix->device);
-    hipDeviceSynchronize();
+    server_destroy(ix);
+    {
+        ServerPause pause(ix->device);  // (other handles' query servers on this device leave while it is synchronised)
+        hipDeviceSynchronize();
+    }
     for (Ctx* c : ix->all_ctx) ctx_destroy(c);
     for (FilterEntry& f : ix->filters) {
-        hipFree(f.d_words);
+        jv_free(f.d_words);
         if (f.ready) hipEventDestroy(f.ready);
     }
-    for (void* p : ix->owned) hipFree(p);
+    for (void* p : ix->owned) jv_free(p);
     delete ix;
 }
 
@@ -1010,6 +1322,7 @@ int jv_index_create(const jv_index_desc* desc, jv_index** out) {
         TRYHIP(jvk_set_max_lds(kMaxLds));
         TRYHIP(jvk_pqp_set_max_lds(kMaxLds));
         TRYHIP(jvk_pqw_set_max_lds(kMaxLds));
+        TRYHIP(jvk_pqs_set_max_lds(kMaxLds));
         {
             hipDeviceProp_t prop;
             if (hipGetDeviceProperties(&prop, desc->device) == hipSuccess && prop.multiProcessorCount > 0) ix->cu_count = prop.multiProcessorCount;
@@ -1057,8 +1370,8 @@ int jv_index_get_info(const jv_index* index, jv_index_info* out) {
 
 int jv_index_get_counter(const jv_index* index, const char* name, int64_t* out) {
     if (!index || !name || !out) return fail(JV_EINVAL, "index/name/out is NULL");
-    static const char* const kNames[] = {"launches_pqw", "launches_pqp", "launches_pqf", "launches_lds"};
-    for (int i = 0; i < 4; i++)
+    static const char* const kNames[] = {"launches_pqw", "launches_pqp", "launches_pqf", "launches_lds", "launches_big", "launches_serve", "served_queries"};
+    for (int i = 0; i < 7; i++)
         if (strcmp(name, kNames[i]) == 0) {
             *out = index->launches[i].load();
             return JV_OK;
@@ -1066,11 +1379,26 @@ int jv_index_get_counter(const jv_index* index, const char* name, int64_t* out) 
     return fail(JV_EINVAL, "unknown counter '%s'", name);
 }
 
+static int search_batch_device_impl(jv_index* index, const float* d_queries, int32_t nq, int32_t topK, int32_t rerankK,
+                                    float threshold, float rerankFloor, const uint64_t* d_accept_doc_words,
+                                    int64_t accept_num_docs, int64_t visit_limit, int32_t* d_out_nodes, int32_t* d_out_docs,
+                                    float* d_out_scores, int32_t* d_out_count, int32_t* d_out_stats,
+                                    int32_t* d_out_flags, void* hip_stream);
+
 int jv_search_batch_device(jv_index* index, const float* d_queries, int32_t nq, int32_t topK, int32_t rerankK,
                            float threshold, float rerankFloor, const uint64_t* d_accept_doc_words,
                            int64_t accept_num_docs, int32_t* d_out_nodes, int32_t* d_out_docs,
                            float* d_out_scores, int32_t* d_out_count, int32_t* d_out_stats,
                            int32_t* d_out_flags, void* hip_stream) {
+    return search_batch_device_impl(index, d_queries, nq, topK, rerankK, threshold, rerankFloor, d_accept_doc_words, accept_num_docs, 0,
+                                    d_out_nodes, d_out_docs, d_out_scores, d_out_count, d_out_stats, d_out_flags, hip_stream);
+}
+
+static int search_batch_device_impl(jv_index* index, const float* d_queries, int32_t nq, int32_t topK, int32_t rerankK,
+                                    float threshold, float rerankFloor, const uint64_t* d_accept_doc_words,
+                                    int64_t accept_num_docs, int64_t visit_limit, int32_t* d_out_nodes, int32_t* d_out_docs,
+                                    float* d_out_scores, int32_t* d_out_count, int32_t* d_out_stats,
+                                    int32_t* d_out_flags, void* hip_stream) {
     int rc = check_common(index, d_queries, nq, topK, rerankK, threshold);
     if (rc != JV_OK) return rc;
     if (nq == 0) return JV_OK;
@@ -1106,7 +1434,7 @@ int jv_search_batch_device(jv_index* index, const float* d_queries, int32_t nq, 
         }
     } else {
         rc = enqueue_batch(index, c, s, d_queries, nq, topK, rerankK, threshold, rerankFloor, d_accept_doc_words,
-                           accept_num_docs, d_out_nodes, d_out_docs, d_out_scores, d_out_count, d_out_stats, d_out_flags);
+                           accept_num_docs, d_out_nodes, d_out_docs, d_out_scores, d_out_count, d_out_stats, d_out_flags, 0, visit_limit);
         if (rc != JV_OK) return rc;
     }
     if (!hip_stream) HIPCHK(hipStreamSynchronize(s));
@@ -1153,7 +1481,7 @@ int filter_acquire(jv_index* ix, const uint64_t* words, size_t nwords, uint64_t 
     if (!f.ready) HIPCHK(hipEventCreateWithFlags(&f.ready, hipEventDisableTiming));
     if (f.cap_words < nwords) {
         // (the entry is not in use: every launch that read it has been synchronised by its caller)
-        if (f.d_words) HIPCHK(hipFree(f.d_words));
+        if (f.d_words) HIPCHK(jv_free(f.d_words));
         f.d_words = nullptr;
         f.cap_words = 0;
         f.key = 0;
@@ -1188,6 +1516,12 @@ struct HostSearchExtras {
     uint64_t accept_key = 0;
     int32_t* out_status = nullptr;  // [nq] per-query JV_OK / JV_ENOMEM
     int32_t* out_flags = nullptr;   // [nq] JV_QFLAG_*
+    // direct delivery (combined one-query calls): on_launched() once the batch is on the GPU, then on_ready(i, ...) exactly
+    // once per query, as soon as its row is final (the pointers address the row inside the pinned arena)
+    void* user = nullptr;
+    void (*on_launched)(void* user) = nullptr;
+    void (*on_ready)(void* user, int i, const int32_t* nodes, const int32_t* docs, const float* scores, int32_t count,
+                     const int32_t* stats, int32_t qflags, int status) = nullptr;
 };
 
 // host-pointer batch.  `accept_list` (optional, nq host pointers) gives every query its own doc filter of
@@ -1237,7 +1571,7 @@ int search_batch_host(jv_index* index, const float* queries, int32_t nq, int32_t
     const size_t o_nodes = 0, o_docs = outn, o_scores = 2 * outn, o_count = 3 * outn, o_stats = o_count + (size_t)nq,
                  o_flags = o_stats + 4 * (size_t)nq, total4 = o_flags + (size_t)nq;
     if (total4 * 4 > c->arena_cap) {
-        hipFree(c->d_arena);
+        jv_free(c->d_arena);
         c->d_arena = nullptr;
         if (c->h_arena) hipHostFree(c->h_arena);
         c->h_arena = nullptr;
@@ -1247,7 +1581,23 @@ int search_batch_host(jv_index* index, const float* queries, int32_t nq, int32_t
         HIPCHK(hipHostMalloc((void**)&c->h_arena, cap, hipHostMallocDefault));
         c->arena_cap = cap;
     }
-    int32_t* const a32 = (int32_t*)c->d_arena;
+    const bool direct = ex.on_ready != nullptr;
+    int32_t* done = nullptr;
+    if (direct) {
+        const size_t need = (total4 + (size_t)nq) * 4;
+        if (need > c->direct_cap) {
+            if (c->h_direct) hipHostFree(c->h_direct);
+            c->h_direct = nullptr;
+            c->direct_cap = 0;
+            const size_t cap = std::max<size_t>(need + need / 4, 65536);
+            HIPCHK(hipHostMalloc((void**)&c->h_direct, cap, hipHostMallocMapped | hipHostMallocCoherent));
+            c->direct_cap = cap;
+        }
+        if (!c->ev_direct) HIPCHK(hipEventCreateWithFlags(&c->ev_direct, hipEventDisableTiming));
+        done = (int32_t*)c->h_direct + total4;
+        memset(done, 0, (size_t)nq * 4);
+    }
+    int32_t* const a32 = direct ? (int32_t*)c->h_direct : (int32_t*)c->d_arena;
     int32_t* const dn = a32 + o_nodes;
     int32_t* const dd = a32 + o_docs;
     float* const dsc = (float*)(a32 + o_scores);
@@ -1301,11 +1651,80 @@ int search_batch_host(jv_index* index, const float* queries, int32_t nq, int32_t
     } else {
         HIPCHK(hipMemcpyAsync(c->d_queries, queries, qbytes, hipMemcpyHostToDevice, c->stream));
     }
+    const int phase1 = OPT(index, OPT_LAZY_BIG) != 0 ? 1 : 0;
+    bool big_owed = false;
     rc = enqueue_batch(index, c, c->stream, c->d_queries, nq, topK, rerankK, threshold, rerankFloor, d_accept,
-                       accept_num_docs, dn, dd, dsc, dc, dst, dfl, accept_stride, ex.visit_limit);
+                       accept_num_docs, dn, dd, dsc, dc, dst, dfl, accept_stride, ex.visit_limit, done, phase1, &big_owed);
     if (rc != JV_OK) return rc;
+    auto enqueue_big = [&]() {  // the HBM-scratch rung for the rows the on-chip rungs flagged
+        big_owed = false;
+        return enqueue_batch(index, c, c->stream, c->d_queries, nq, topK, rerankK, threshold, rerankFloor, d_accept, accept_num_docs,
+                             dn, dd, dsc, dc, dst, dfl, accept_stride, ex.visit_limit, nullptr, 2, nullptr);
+    };
+    if (direct) {
+        // Rows land in pinned host memory.  A row whose completion word is set is final; every row is once the stream has
+        // run dry (the rungs behind the first launch only touch flagged rows).  One poller per batch: this thread.
+        HIPCHK(hipEventRecord(c->ev_direct, c->stream));
+        if (ex.on_launched) ex.on_launched(ex.user);
+        const int32_t* h32d = (const int32_t*)c->h_direct;
+        std::vector<char> delivered((size_t)nq, 0);
+        int remaining = nq, failed_d = 0, first_d = -1;
+        for (int spins = 0; remaining > 0; spins++) {
+            const hipError_t qe = hipEventQuery(c->ev_direct);
+            if (qe != hipSuccess && qe != hipErrorNotReady) return fail(JV_EDEVICE, "hipEventQuery failed: %s", hipGetErrorString(qe));
+            bool finished = qe == hipSuccess;
+            if (finished && big_owed) {
+                bool any = false;
+                for (int i = 0; i < nq && !any; i++)
+                    any = !delivered[(size_t)i] && ((uint32_t)h32d[o_flags + (size_t)i] & JV_FLAG_OVERFLOW) != 0;
+                if (any) {
+                    if ((rc = enqueue_big()) != JV_OK) return rc;
+                    HIPCHK(hipEventRecord(c->ev_direct, c->stream));
+                    finished = false;  // (rows without the flag are final and are handed out below)
+                }
+                big_owed = false;
+            }
+            for (int i = 0; i < nq; i++) {
+                if (delivered[(size_t)i]) continue;
+                const bool on_chip_done = qe == hipSuccess && ((uint32_t)h32d[o_flags + (size_t)i] & JV_FLAG_OVERFLOW) == 0;
+                if (!finished && !on_chip_done && __atomic_load_n(&done[i], __ATOMIC_ACQUIRE) == 0) continue;
+                const uint32_t f = (uint32_t)h32d[o_flags + (size_t)i];
+                const bool bad = (f & (JV_FLAG_FAILED | JV_FLAG_OVERFLOW)) != 0;
+                if (bad) {
+                    failed_d++;
+                    if (first_d < 0) first_d = i;
+                }
+                ex.on_ready(ex.user, i, h32d + o_nodes + (size_t)i * topK, h32d + o_docs + (size_t)i * topK,
+                            (const float*)(h32d + o_scores) + (size_t)i * topK, h32d[o_count + (size_t)i], h32d + o_stats + 4 * (size_t)i,
+                            (int32_t)(f & (JV_FLAG_BIG | JV_FLAG_EARLY)), bad ? JV_ENOMEM : JV_OK);
+                delivered[(size_t)i] = 1;
+                remaining--;
+            }
+            if (remaining > 0 && !finished) {
+                if (spins < 64) sched_yield();
+                else {
+                    struct timespec ts = {0, 20000};  // 20 us
+                    nanosleep(&ts, nullptr);
+                }
+            }
+        }
+        if (failed_d)
+            return fail(JV_ENOMEM, "%d of %d queries (first: %d) overflowed the HBM scratch; raise option big_cand_cap (the other rows are valid)",
+                        failed_d, nq, first_d);
+        return JV_OK;
+    }
     HIPCHK(hipMemcpyAsync(c->h_arena, c->d_arena, total4 * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (big_owed) {
+        const int32_t* fl0 = (const int32_t*)c->h_arena + o_flags;
+        bool any = false;
+        for (int i = 0; i < nq && !any; i++) any = ((uint32_t)fl0[i] & JV_FLAG_OVERFLOW) != 0;
+        if (any) {
+            if ((rc = enqueue_big()) != JV_OK) return rc;
+            HIPCHK(hipMemcpyAsync(c->h_arena, c->d_arena, total4 * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+        }
+    }
     const int32_t* h32 = (const int32_t*)c->h_arena;
     if (out_nodes) memcpy(out_nodes, h32 + o_nodes, outn * 4);
     if (out_docs) memcpy(out_docs, h32 + o_docs, outn * 4);
@@ -1388,6 +1807,11 @@ int search_single(jv_index* index, const float* query, int32_t topK, int32_t rer
         return search_batch_host(index, query, 1, topK, rerankK, threshold, rerankFloor, accept_doc_words, nullptr,
                                  accept_num_docs, out_nodes, out_docs, out_scores, out_count, out_stats, ex);
     }
+    if (!accept_doc_words && threshold <= 0.0f) {
+        // shapes the several-waves pool kernel runs: no launch at all, the device-resident server answers
+        rc = serve_query(index, query, topK, rerankK, rerankFloor, visit_limit, out_nodes, out_docs, out_scores, out_count, out_stats, out_flags);
+        if (rc <= 0) return rc;  // (1 = not eligible / a row for the ladder: the launch path below)
+    }
     Combiner& cb = index->combiner;
     PendingSearch me;
     me.query = query;
@@ -1468,6 +1892,71 @@ int search_single(jv_index* index, const float* query, int32_t topK, int32_t rer
         rc = search_batch_host(index, query, 1, topK, rerankK, threshold, rerankFloor, me.accept, nullptr, me.accept_docs,
                                out_nodes, out_docs, out_scores, out_count, out_stats, ex);
         if (rc != JV_OK) snprintf(me.err, sizeof(me.err), "%s", g_last_error.c_str());
+    } else if (OPT(index, OPT_DIRECT_COMPLETION) != 0) {
+        // Direct delivery: the kernels write every row into pinned memory and set a completion word per query; this thread
+        // (the batch's only poller) hands each answer to its owner the moment it is final — a caller no longer waits for
+        // the slowest query of the launch it happened to share — and frees the leader slot as soon as the batch is on the GPU.
+        qbuf.resize(nb * d);
+        abuf.resize(nb);
+        for (size_t i = 0; i < nb; i++) {
+            memcpy(qbuf.data() + i * d, batch[i]->query, d * sizeof(float));
+            abuf[i] = batch[i]->accept;
+        }
+        struct Deliver {
+            std::vector<PendingSearch*>* batch;
+            std::vector<char> served;
+            PendingSearch* me;
+            Combiner* cb;
+            bool* passed;
+            int topK;
+            int my_rc;
+        } dl{&batch, std::vector<char>(nb, 0), &me, &cb, &passed, topK, JV_OK};
+        HostSearchExtras ex;
+        ex.visit_limit = visit_limit;
+        ex.user = &dl;
+        ex.on_launched = [](void* u) {
+            Deliver* dv = (Deliver*)u;
+            std::lock_guard<std::mutex> g(dv->cb->mu);
+            pass_leadership(*dv->cb);
+            *dv->passed = true;
+        };
+        ex.on_ready = [](void* u, int i, const int32_t* nodes, const int32_t* docs, const float* scores, int32_t count,
+                         const int32_t* stats, int32_t qflags, int status) {
+            Deliver* dv = (Deliver*)u;
+            PendingSearch* r = (*dv->batch)[(size_t)i];
+            if (status == JV_OK) {
+                if (r->out_nodes) memcpy(r->out_nodes, nodes, sizeof(int32_t) * dv->topK);
+                if (r->out_docs) memcpy(r->out_docs, docs, sizeof(int32_t) * dv->topK);
+                if (r->out_scores) memcpy(r->out_scores, scores, sizeof(float) * dv->topK);
+                if (r->out_count) *r->out_count = count;
+                if (r->out_stats) memcpy(r->out_stats, stats, sizeof(int32_t) * 4);
+                if (r->out_flags) *r->out_flags = qflags;
+            } else {
+                snprintf(r->err, sizeof(r->err), "the query overflowed the HBM scratch; raise option big_cand_cap");
+            }
+            dv->served[(size_t)i] = 1;
+            if (r != dv->me) {
+                r->rc = status;
+                sem_post(&r->sem);  // r's frame may be gone as soon as this returns
+            } else {
+                dv->my_rc = status;
+            }
+        };
+        rc = search_batch_host(index, qbuf.data(), (int32_t)nb, topK, rerankK, threshold, rerankFloor, nullptr,
+                               me.accept ? abuf.data() : nullptr, me.accept_docs, nullptr, nullptr, nullptr, nullptr, nullptr, ex);
+        // a launch-level failure leaves owners unserved: they all get its code
+        for (size_t i = 0; i < nb; i++) {
+            if (dl.served[i]) continue;
+            PendingSearch* r = batch[i];
+            snprintf(r->err, sizeof(r->err), "%s", g_last_error.c_str());
+            if (r != &me) {
+                r->rc = rc;
+                sem_post(&r->sem);
+            } else {
+                dl.my_rc = rc;
+            }
+        }
+        rc = dl.my_rc;
     } else {
         qbuf.resize(nb * d);
         nbuf.resize(nb * topK);
@@ -1606,7 +2095,7 @@ int jv_score_ordinals(jv_index* index, const float* query, const int32_t* ordina
     if ((rc = grow((void**)&c->d_queries, &c->queries_cap, (size_t)d, sizeof(float))) != JV_OK) return rc;
     const size_t need = (size_t)count * 8;
     if (need > c->arena_cap) {
-        hipFree(c->d_arena);
+        jv_free(c->d_arena);
         c->d_arena = nullptr;
         if (c->h_arena) hipHostFree(c->h_arena);
         c->h_arena = nullptr;
@@ -1656,7 +2145,8 @@ struct jv_shard_group {
         int32_t *d_nodes = nullptr, *d_docs = nullptr, *d_count = nullptr, *d_stats = nullptr, *d_flags = nullptr;
         float* d_scores = nullptr;
         int32_t* d_pairs = nullptr;  // [nq][k] (doc, score bits)
-        size_t cap_q = 0, cap_out = 0, cap_nq = 0;
+        uint64_t* d_accept = nullptr;  // the batch's doc filter (GLOBAL doc ids), copied to this shard's device
+        size_t cap_q = 0, cap_out = 0, cap_nq = 0, cap_acc = 0;
     };
     std::vector<PerShard> per;
     // on shards[0]'s device: gathered (doc, score) pairs [G][nq][k] + merged output + per-shard stats / flags
@@ -1672,7 +2162,7 @@ namespace {
 template <typename T>
 int regrow(T** p, size_t* cap, size_t need) {
     if (need <= *cap && *p) return JV_OK;
-    if (*p) HIPCHK(hipFree(*p));
+    if (*p) HIPCHK(jv_free(*p));
     *p = nullptr;
     *cap = 0;
     HIPCHK(hipMalloc((void**)p, (need ? need : 1) * sizeof(T)));
@@ -1701,8 +2191,15 @@ int jv_shard_group_create(jv_index* const* shards, int32_t num_shards, jv_shard_
             // peer access both ways where the fabric offers it (xGMI); the gather falls back to staged copies otherwise
             int can = 0;
             if (hipDeviceCanAccessPeer(&can, shards[g]->device, shards[0]->device) == hipSuccess && can) {
-                hipError_t pe = hipDeviceEnablePeerAccess(shards[0]->device, 0);
+                hipError_t pe = hipDeviceEnablePeerAccess(shards[0]->device, 0);  // (current device = shard g's)
                 if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+            }
+            can = 0;
+            if (hipDeviceCanAccessPeer(&can, shards[0]->device, shards[g]->device) == hipSuccess && can &&
+                hipSetDevice(shards[0]->device) == hipSuccess) {
+                hipError_t pe = hipDeviceEnablePeerAccess(shards[g]->device, 0);
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+                e = hipSetDevice(shards[g]->device);
             }
         }
         if (e != hipSuccess) {
@@ -1726,24 +2223,25 @@ void jv_shard_group_destroy(jv_shard_group* grp) {
         hipSetDevice(grp->shards[g]->device);
         jv_shard_group::PerShard& p = grp->per[g];
         if (p.stream) hipStreamSynchronize(p.stream);
-        hipFree(p.d_queries);
-        hipFree(p.d_nodes);
-        hipFree(p.d_docs);
-        hipFree(p.d_scores);
-        hipFree(p.d_pairs);
-        hipFree(p.d_count);
-        hipFree(p.d_stats);
-        hipFree(p.d_flags);
+        jv_free(p.d_queries);
+        jv_free(p.d_nodes);
+        jv_free(p.d_docs);
+        jv_free(p.d_scores);
+        jv_free(p.d_pairs);
+        jv_free(p.d_accept);
+        jv_free(p.d_count);
+        jv_free(p.d_stats);
+        jv_free(p.d_flags);
         if (p.done) hipEventDestroy(p.done);
         if (p.stream) hipStreamDestroy(p.stream);
     }
     if (!grp->shards.empty()) hipSetDevice(grp->shards[0]->device);
-    hipFree(grp->g_docs);
-    hipFree(grp->g_scores);
-    hipFree(grp->m_docs);
-    hipFree(grp->m_scores);
-    hipFree(grp->g_stats);
-    hipFree(grp->g_flags);
+    jv_free(grp->g_docs);
+    jv_free(grp->g_scores);
+    jv_free(grp->m_docs);
+    jv_free(grp->m_scores);
+    jv_free(grp->g_stats);
+    jv_free(grp->g_flags);
     if (grp->merge_stream) hipStreamDestroy(grp->merge_stream);
     delete grp;
 }
@@ -1751,10 +2249,28 @@ void jv_shard_group_destroy(jv_shard_group* grp) {
 int jv_search_sharded_batch(jv_shard_group* grp, const float* queries, int32_t nq, int32_t topK, int32_t rerankK,
                             float threshold, float rerankFloor, int32_t* out_docs, float* out_scores,
                             int32_t* out_count, int32_t* out_stats) {
+    jv_search_params p{};
+    p.struct_size = sizeof(p);
+    p.topK = topK;
+    p.rerankK = rerankK;
+    p.threshold = threshold;
+    p.rerankFloor = rerankFloor;
+    return jv_search_sharded_batch_ex(grp, queries, nq, &p, out_docs, out_scores, out_count, out_stats, nullptr, nullptr);
+}
+
+int jv_search_sharded_batch_ex(jv_shard_group* grp, const float* queries, int32_t nq, const jv_search_params* prm, int32_t* out_docs,
+                               float* out_scores, int32_t* out_count, int32_t* out_stats, int32_t* out_status, int32_t* out_flags) {
     if (!grp) return fail(JV_EINVAL, "group is NULL");
+    if (!prm || prm->struct_size != sizeof(jv_search_params)) return fail(JV_EINVAL, "jv_search_params is NULL or has the wrong struct_size");
+    const int32_t topK = prm->topK, rerankK = prm->rerankK;
+    const float threshold = prm->threshold, rerankFloor = prm->rerankFloor;
     const int G = (int)grp->shards.size();
     int rc = check_common(grp->shards[0], queries, nq, topK, rerankK, threshold);
     if (rc != JV_OK) return rc;
+    if (prm->accept_doc_words && prm->accept_num_docs < 0) return fail(JV_EINVAL, "accept_num_docs < 0");
+    if (prm->visit_limit < 0) return fail(JV_EINVAL, "visit_limit < 0");
+    if (out_status && nq > 0) memset(out_status, 0, sizeof(int32_t) * (size_t)nq);
+    if (out_flags && nq > 0) memset(out_flags, 0, sizeof(int32_t) * (size_t)nq);
     if (nq == 0) return JV_OK;
     if (!out_docs || !out_scores) return fail(JV_EINVAL, "output pointer is NULL");
     if ((int64_t)G * topK * 8 > 64 * 1024) return fail(JV_EUNSUPPORTED, "shards * topK too large for one merge tile");
@@ -1770,23 +2286,38 @@ int jv_search_sharded_batch(jv_shard_group* grp, const float* queries, int32_t n
     HIPCHK(hipSetDevice(dev0));
     if ((rc = regrow(&grp->g_docs, &grp->cap_g, 2 * outn * (size_t)G)) != JV_OK) return rc;
     if (!grp->g_stats || grp->cap_s < (size_t)G * (size_t)nq) {
-        if (grp->g_stats) HIPCHK(hipFree(grp->g_stats));
+        if (grp->g_stats) HIPCHK(jv_free(grp->g_stats));
         grp->g_stats = nullptr;
         HIPCHK(hipMalloc((void**)&grp->g_stats, (size_t)G * (size_t)nq * 4 * sizeof(int32_t)));
-        if (grp->g_flags) HIPCHK(hipFree(grp->g_flags));
+        if (grp->g_flags) HIPCHK(jv_free(grp->g_flags));
         grp->g_flags = nullptr;
         HIPCHK(hipMalloc((void**)&grp->g_flags, (size_t)G * (size_t)nq * sizeof(int32_t)));
         grp->cap_s = (size_t)G * (size_t)nq;
     }
     if (!grp->m_docs || grp->cap_m < outn) {
-        if (grp->m_docs) HIPCHK(hipFree(grp->m_docs));
-        if (grp->m_scores) HIPCHK(hipFree(grp->m_scores));
+        if (grp->m_docs) HIPCHK(jv_free(grp->m_docs));
+        if (grp->m_scores) HIPCHK(jv_free(grp->m_scores));
         grp->m_docs = nullptr;
         grp->m_scores = nullptr;
         HIPCHK(hipMalloc((void**)&grp->m_docs, outn * sizeof(int32_t)));
         HIPCHK(hipMalloc((void**)&grp->m_scores, outn * sizeof(float)));
         grp->cap_m = outn;
     }
+    // whatever happens below: nothing of this call may still be in flight on the group's buffers when it returns, and the
+    // calling thread gets its device back
+    struct Drain {
+        jv_shard_group* grp;
+        int dev_before;
+        ~Drain() {
+            for (size_t g = 0; g < grp->per.size(); g++) {
+                if (hipSetDevice(grp->shards[g]->device) == hipSuccess && grp->per[g].stream) hipStreamSynchronize(grp->per[g].stream);
+            }
+            if (!grp->shards.empty() && hipSetDevice(grp->shards[0]->device) == hipSuccess && grp->merge_stream) hipStreamSynchronize(grp->merge_stream);
+            if (dev_before >= 0) hipSetDevice(dev_before);
+        }
+    } drain{grp, -1};
+    (void)hipGetDevice(&drain.dev_before);
+    const size_t acc_words = prm->accept_doc_words ? ((size_t)prm->accept_num_docs + 63) / 64 : 0;
     // 1. every shard searches the whole batch on its own device and stream
     for (int g = 0; g < G; g++) {
         jv_index* ix = grp->shards[(size_t)g];
@@ -1794,10 +2325,10 @@ int jv_search_sharded_batch(jv_shard_group* grp, const float* queries, int32_t n
         HIPCHK(hipSetDevice(ix->device));
         if ((rc = regrow(&p.d_queries, &p.cap_q, (size_t)nq * d)) != JV_OK) return rc;
         if (p.cap_out < outn) {
-            hipFree(p.d_nodes);
-            hipFree(p.d_docs);
-            hipFree(p.d_scores);
-            hipFree(p.d_pairs);
+            jv_free(p.d_nodes);
+            jv_free(p.d_docs);
+            jv_free(p.d_scores);
+            jv_free(p.d_pairs);
             p.d_nodes = p.d_docs = p.d_pairs = nullptr;
             p.d_scores = nullptr;
             p.cap_out = 0;
@@ -1808,9 +2339,9 @@ int jv_search_sharded_batch(jv_shard_group* grp, const float* queries, int32_t n
             p.cap_out = outn;
         }
         if (p.cap_nq < (size_t)nq) {
-            hipFree(p.d_count);
-            hipFree(p.d_stats);
-            hipFree(p.d_flags);
+            jv_free(p.d_count);
+            jv_free(p.d_stats);
+            jv_free(p.d_flags);
             p.d_count = p.d_stats = p.d_flags = nullptr;
             p.cap_nq = 0;
             HIPCHK(hipMalloc((void**)&p.d_count, (size_t)nq * 4));
@@ -1819,8 +2350,15 @@ int jv_search_sharded_batch(jv_shard_group* grp, const float* queries, int32_t n
             p.cap_nq = (size_t)nq;
         }
         HIPCHK(hipMemcpyAsync(p.d_queries, queries, (size_t)nq * d * sizeof(float), hipMemcpyHostToDevice, p.stream));
-        rc = jv_search_batch_device(ix, p.d_queries, nq, topK, rerankK, threshold, rerankFloor, nullptr, 0, p.d_nodes, p.d_docs,
-                                    p.d_scores, p.d_count, p.d_stats, p.d_flags, (void*)p.stream);
+        const uint64_t* d_acc = nullptr;
+        if (prm->accept_doc_words) {
+            // the filter is over GLOBAL doc ids (every shard's ord2doc maps into that space), so every shard gets the same bits
+            if ((rc = regrow(&p.d_accept, &p.cap_acc, acc_words ? acc_words : 1)) != JV_OK) return rc;
+            if (acc_words) HIPCHK(hipMemcpyAsync(p.d_accept, prm->accept_doc_words, acc_words * 8, hipMemcpyHostToDevice, p.stream));
+            d_acc = p.d_accept;
+        }
+        rc = search_batch_device_impl(ix, p.d_queries, nq, topK, rerankK, threshold, rerankFloor, d_acc, d_acc ? prm->accept_num_docs : 0,
+                                      prm->visit_limit, p.d_nodes, p.d_docs, p.d_scores, p.d_count, p.d_stats, p.d_flags, (void*)p.stream);
         if (rc != JV_OK) return rc;
         // 2. gather: this shard's [nq][k] (doc, score) pairs go to slot g of the [G][nq][k] buffer on device 0 in ONE
         //    peer copy over xGMI (+ the counters and flags)
@@ -1843,10 +2381,16 @@ int jv_search_sharded_batch(jv_shard_group* grp, const float* queries, int32_t n
     int failed = 0;
     for (int i = 0; i < nq; i++) {
         int32_t st[4] = {0, 0, 0, 0};
+        uint32_t fl = 0;
+        bool bad = false;
         for (int g = 0; g < G; g++) {
             for (int j = 0; j < 4; j++) st[j] += h_stats[((size_t)g * (size_t)nq + (size_t)i) * 4 + (size_t)j];
-            if ((uint32_t)h_flags[(size_t)g * (size_t)nq + (size_t)i] & (JV_FLAG_FAILED | JV_FLAG_OVERFLOW)) failed++;
+            const uint32_t f = (uint32_t)h_flags[(size_t)g * (size_t)nq + (size_t)i];
+            if (f & (JV_FLAG_FAILED | JV_FLAG_OVERFLOW)) bad = true, failed++;
+            fl |= f & (JV_FLAG_BIG | JV_FLAG_EARLY);  // (EARLY: at least one shard's search hit the visit limit and returned nothing)
         }
+        if (out_status && bad) out_status[i] = JV_ENOMEM;
+        if (out_flags) out_flags[i] = (int32_t)fl;
         if (out_stats) memcpy(out_stats + (size_t)i * 4, st, sizeof(st));
         if (out_count) {
             int c = 0;

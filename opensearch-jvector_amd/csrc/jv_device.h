@@ -89,8 +89,35 @@ struct JvSearchArgs {
     int32_t pqp_scratch_off; // LDS byte offset of the 768-byte merge scratch (kept keys + ranks of one expansion)
     int32_t pqp_lds_bytes;   // dynamic LDS bytes of the launch (register-LUT variant: the visited-count hash set uses all of it)
     int32_t* pqp_counter;    // query dequeue counter (zeroed per call)
+    // device-resident query server (jv_pqw_body.h, SERVE instances): single queries arrive through a ring of slots in pinned
+    // host memory; the workgroups claim tickets [head, published) and answer into the slot
+    unsigned char* serve_ring;   // [serve_slots][serve_slot_bytes], host-visible
+    int32_t serve_slots;         // power of two
+    int32_t serve_slot_bytes;
+    int32_t* serve_dev;          // device words: JV_SV_* below
+    int32_t* serve_host;         // pinned host words: JV_SH_* below
+    int32_t serve_idle_ticks;    // s_memrealtime ticks (100 MHz) without a claim after which the kernel exits
+    int32_t done_all;            // completion words are also set for rows that come back flagged (no later rung in server mode)
+    int32_t* done;           // optional completion words in host-visible memory: 1 once query i's row is final (see jv_pqw_body.h)
     int32_t pqw_lut_off;     // several-waves kernel: LDS byte offset of the table rows kept in LDS ([W][NL][256] floats)
 };
+
+// query-server words and slot layout (shared by jv_abi.cpp and the SERVE kernel instances)
+enum { JV_SV_HEAD = 0, JV_SV_PUBLISHED = 1, JV_SV_LOCK = 2, JV_SV_EXITED = 3, JV_SV_LAST_CLAIM = 4, JV_SV_STOP_SEEN = 5 };
+enum { JV_SH_TAIL = 0, JV_SH_STOP = 1, JV_SH_ALIVE = 2 };
+#define JV_SERVE_TOPK_MAX 64
+struct JvServeSlot {           // header of one ring slot; the query (float[d], zero padded to 16 B) follows at JV_SERVE_QUERY_OFF
+    int32_t topK, rk, visit_limit;
+    float rerank_floor;
+    int32_t done;              // 0 while pending; 1 once the row below is final
+    int32_t count, flags;
+    int32_t stats[4];
+    int32_t pad[5];
+    int32_t nodes[JV_SERVE_TOPK_MAX];
+    int32_t docs[JV_SERVE_TOPK_MAX];
+    float scores[JV_SERVE_TOPK_MAX];
+};
+#define JV_SERVE_QUERY_OFF ((int)sizeof(JvServeSlot))
 
 #define JV_FLAG_OVERFLOW 0x80000000u /* on-chip scratch overflow: query must be re-run on the big path */
 #define JV_FLAG_FAILED   0x40000000u /* big path overflowed as well */

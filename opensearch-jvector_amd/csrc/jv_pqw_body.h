@@ -855,6 +855,10 @@ __device__ void search_one_pqw(const JvIndexDev& ix, const JvSearchArgs& a, cons
                 if (o_docs) o_docs[i] = -1;
                 o_scores[i] = 0.0f;
             }
+            if (a.done && (why == 15 || a.done_all)) {  // an early-terminated row is final (a flagged one is redone by a later launch — or, in server mode, by the caller)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+                if (lane == 0) __hip_atomic_store(&a.done[qi], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
         return;
     }
@@ -915,10 +919,109 @@ __device__ void search_one_pqw(const JvIndexDev& ix, const JvSearchArgs& a, cons
         st[3] = expanded;
         a.out_flags[qi] = 0;
     }
+    // completion word (one-query-per-call API): the caller that owns this query is woken as soon as ITS row is final, not
+    // when the slowest query of the combined launch is.  System-scope release: every store of the row precedes the word.
+    if (a.done) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        if (lane == 0) __hip_atomic_store(&a.done[qi], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // Persistent grid: one workgroup (W waves) per resident LDS slot, queries dequeued in order.
 // OCC = waves per SIMD the register budget is sized for (4: 128 VGPRs, 8 workgroups of 2 waves per CU)
+// Device-resident query server: the same search, fed by single queries from a ring of slots in pinned host memory
+// (JvServeSlot) instead of a batch — the reference's calling pattern is one query per call from many searcher threads
+// (J/JVectorReader.java:129-210), and a kernel launch per call (or per small group of calls) runs into the HIP runtime's
+// few hardware queues.  Callers publish slots in ticket order (host word TAIL); workgroups claim tickets with a
+// compare-and-swap on HEAD once PUBLISHED has caught up with TAIL (one workgroup at a time reads the host word), answer into
+// the slot and set its completion word.  The grid leaves when the host says STOP or nothing was claimed for serve_idle_ticks.
+template <int NCHT, int CAPK, int W, int OCC, int NL = 4>
+__global__ __launch_bounds__(JV_WAVE * W, OCC) void jv_serve_pqw_kernel(const JvIndexDev ix, const JvSearchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int32_t* explog = a.pqp_log + (size_t)blockIdx.x * (size_t)a.pqp_log_cap;
+    int* ctrl = (int*)(smem + a.pqp_scratch_off + W * 256);
+#ifdef JV_STAMPS
+    if (threadIdx.x < 16) ((unsigned long long*)(smem + a.pqp_scratch_off + W * 256 + 64))[threadIdx.x] = 0ull;
+#endif
+    for (;;) {
+        if (threadIdx.x == 0) {
+            int ticket = -1;
+            const uint32_t t_idle0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
+            int polls = 0, idle_iters = 0;
+            for (;;) {
+                const int h = __hip_atomic_load(&a.serve_dev[JV_SV_HEAD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int pb = __hip_atomic_load(&a.serve_dev[JV_SV_PUBLISHED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (pb - h <= 0) {
+                    // nothing published that is not claimed: ONE workgroup at a time looks at the host's tail word
+                    // (the host words are read over PCIe: by the lock holder only — hundreds of idle workgroups polling them
+                    //  would queue in front of the working ones' query fetches and row stores)
+                    if (__hip_atomic_load(&a.serve_dev[JV_SV_LOCK], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 &&
+                        atomicCAS(&a.serve_dev[JV_SV_LOCK], 0, 1) == 0) {
+                        const int ht = __hip_atomic_load(&a.serve_host[JV_SH_TAIL], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+                        if (ht - pb > 0) {
+                            atomicMax(&a.serve_dev[JV_SV_PUBLISHED], ht);
+                            pb = ht;
+                        } else if ((++polls & 15) == 0 && __hip_atomic_load(&a.serve_host[JV_SH_STOP], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) {
+                            __hip_atomic_store(&a.serve_dev[JV_SV_STOP_SEEN], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        __hip_atomic_store(&a.serve_dev[JV_SV_LOCK], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    if (pb - h <= 0) {
+                        const uint32_t now = (uint32_t)__builtin_amdgcn_s_memrealtime();
+                        const uint32_t last = (uint32_t)__hip_atomic_load(&a.serve_dev[JV_SV_LAST_CLAIM], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        // (signed differences: another workgroup's claim may carry a later time stamp than `now`)
+                        const bool idle = (int32_t)(now - last) > a.serve_idle_ticks && (int32_t)(now - t_idle0) > a.serve_idle_ticks;
+                        if (idle || __hip_atomic_load(&a.serve_dev[JV_SV_STOP_SEEN], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                        // back off the longer this workgroup has had nothing to do (3 us .. 55 us): hundreds of idle
+                        // workgroups polling at full rate slow the working ones down (one query alone: 9.8 ms instead of 3.2)
+                        idle_iters++;
+                        const int naps = idle_iters < 16 ? 1 : (idle_iters < 128 ? 4 : 16);
+                        for (int z = 0; z < naps; z++) __builtin_amdgcn_s_sleep(127);
+                        continue;
+                    }
+                }
+                if (atomicCAS(&a.serve_dev[JV_SV_HEAD], h, h + 1) == h) {
+                    ticket = h;
+                    __hip_atomic_store(&a.serve_dev[JV_SV_LAST_CLAIM], (int)(uint32_t)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+            ctrl[PQW_QI] = ticket;
+        }
+        __syncthreads();
+        const int ticket = __builtin_amdgcn_readfirstlane(ctrl[PQW_QI]);
+        if (ticket < 0) break;
+        unsigned char* const sp = a.serve_ring + (size_t)(ticket & (a.serve_slots - 1)) * (size_t)a.serve_slot_bytes;
+        JvServeSlot* const slot = (JvServeSlot*)sp;
+        JvSearchArgs aq = a;
+        aq.queries = (const float*)(sp + JV_SERVE_QUERY_OFF);
+        aq.nq = 1;
+        aq.topK = __builtin_amdgcn_readfirstlane(slot->topK);
+        aq.rk = __builtin_amdgcn_readfirstlane(slot->rk);
+        aq.visit_limit = __builtin_amdgcn_readfirstlane(slot->visit_limit);
+        aq.rerank_floor = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(slot->rerank_floor)));
+        aq.cand_cap = aq.rk + 64 + ix.R;  // (the pool a batch launch of this rerankK would use; the LDS plan covers the largest)
+        aq.out_nodes = slot->nodes;
+        aq.out_docs = slot->docs;
+        aq.out_scores = slot->scores;
+        aq.out_count = &slot->count;
+        aq.out_stats = slot->stats;
+        aq.out_flags = &slot->flags;
+        aq.done = &slot->done;
+        aq.done_all = 1;
+        search_one_pqw<NCHT, CAPK, W, NL>(ix, aq, 0, smem, explog);
+        __syncthreads();
+    }
+    // the last workgroup out tells the host that the grid is gone (a caller that finds work pending launches it again)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (atomicAdd(&a.serve_dev[JV_SV_EXITED], 1) == (int)gridDim.x - 1) {
+            __hip_atomic_store(&a.serve_dev[JV_SV_EXITED], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a.serve_host[JV_SH_ALIVE], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 template <int NCHT, int CAPK, int W, int OCC, int NL = 4>
 __global__ __launch_bounds__(JV_WAVE * W, OCC) void jv_search_pqw_kernel(const JvIndexDev ix, const JvSearchArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

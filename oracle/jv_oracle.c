@@ -260,6 +260,29 @@ void jvo_pq_build_norm_lut(const jv_index_desc* ix, float* norm_lut) {
     free(sizes);
 }
 
+/* SIMD mode of the CPU baseline (bench.py cpu_baseline reports both): 0 = the plain C loops (gcc -O3 -mavx2 -mfma
+ * auto-vectorises the 64-partial exact scorer; the ADC is scalar loads), 1 = explicit AVX2: look-up-table reads as
+ * 8-wide gathers, the neighbours' code rows and the rerank rows software-prefetched before they are scored.
+ * The ORDER of every floating-point operation is the same in both modes, so ids, score bits and counters are identical
+ * (tests/test_oracle_units.py::test_simd_mode_changes_nothing). */
+#include <immintrin.h>
+static int g_simd_mode = 0;
+void jvo_set_simd(int mode) { g_simd_mode = mode; }
+int jvo_get_simd(void) { return g_simd_mode; }
+
+static inline float pq_chunk_avx2(const float* lut, const uint8_t* code, int m0) { /* 16 subspaces m0 .. m0 + 15, left to right */
+    float t[16];
+    const __m256i step = _mm256_setr_epi32(0, 256, 512, 768, 1024, 1280, 1536, 1792);
+    for (int h = 0; h < 2; h++) {
+        const __m256i c8 = _mm256_cvtepu8_epi32(_mm_loadl_epi64((const __m128i*)(code + m0 + 8 * h)));
+        const __m256i idx = _mm256_add_epi32(_mm256_add_epi32(c8, step), _mm256_set1_epi32((m0 + 8 * h) * 256));
+        _mm256_storeu_ps(t + 8 * h, _mm256_i32gather_ps(lut, idx, 4));
+    }
+    float s = t[0];
+    for (int i = 1; i < 16; i++) s = s + t[i];
+    return s;
+}
+
 /* raw(n) = sum_m lut[m][code[m]]: 16-subspace chunks summed left to right (one GPU lane each),
  * chunk sums combined by an adjacent-pair tree over next_pow2(#chunks) (missing chunks = +0). */
 float jvo_pq_raw(const float* lut, const uint8_t* code, int M) {
@@ -271,8 +294,12 @@ float jvo_pq_raw(const float* lut, const uint8_t* code, int M) {
         float s = 0.0f;
         if (c < nch) {
             int m0 = c * 16, m1 = m0 + 16 < M ? m0 + 16 : M;
-            s = lut[m0 * 256 + code[m0]];
-            for (int m = m0 + 1; m < m1; m++) s = s + lut[m * 256 + code[m]];
+            if (g_simd_mode && m1 - m0 == 16) {
+                s = pq_chunk_avx2(lut, code, m0);
+            } else {
+                s = lut[m0 * 256 + code[m0]];
+                for (int m = m0 + 1; m < m1; m++) s = s + lut[m * 256 + code[m]];
+            }
         }
         cs[c] = s;
     }
@@ -541,6 +568,13 @@ static void search_one_layer(searcher* s, int rk, float thr, int level, int acce
         if ((accept_all || accept_ord(s, c)) && sc >= thr) add_top_candidate(s, c, sc, rk);
         int stride;
         const int32_t* nb = neighbours(s->ix, level, c, &stride);
+        if (g_simd_mode) { /* the rows the loop below is about to read */
+            for (int i = 0; i < stride; i++) {
+                if (nb[i] < 0) continue;
+                if (s->lut) __builtin_prefetch(s->ix->pq_codes + (size_t)nb[i] * s->ix->pq_M);
+                else __builtin_prefetch(exact_row(s->ix, nb[i]));
+            }
+        }
         for (int i = 0; i < stride; i++) {
             int nn = nb[i];
             if (nn < 0) continue; /* -1 padding */
@@ -704,6 +738,10 @@ int jvo_search(const jv_index_desc* ix, const float* query, int32_t topK, int32_
         for (int i = 1; i <= s.results.size; i++) {
             float a = key_score(s.results.h[i]);
             int take = above > 0 ? (a >= rerankFloor) : (i == best_i);
+            if (g_simd_mode && i + 4 <= s.results.size) { /* the row four entries ahead: its first cache lines */
+                const char* nx = (const char*)exact_row(ix, key_node(s.results.h[i + 4]));
+                for (int o = 0; o < ix->d * 4; o += 256) __builtin_prefetch(nx + o);
+            }
             if (!take) continue;
             int node = key_node(s.results.h[i]);
             fin[nfin++] = jvo_encode_key(node, rerank_fn(&s, node));

@@ -41,6 +41,9 @@ void jvo_pq_sub_layout(int d, int M, const int32_t* sub_sizes, int32_t* sizes, i
 void jvo_pq_build_lut(const jv_index_desc* ix, const float* q, float* lut);
 void jvo_pq_build_norm_lut(const jv_index_desc* ix, float* norm_lut);
 float jvo_pq_raw(const float* lut, const uint8_t* code, int M);
+/* 0 = plain C loops, 1 = explicit AVX2 gathers + software prefetch; results are identical in both modes */
+void jvo_set_simd(int mode);
+int jvo_get_simd(void);
 float jvo_pq_score(const jv_index_desc* ix, const float* lut, const float* norm_lut, float qnorm2, int node);
 
 /* --- NVQ-inline vectors: nvqDequantize restated (J/JVectorIndexQuantization.java:319-361); out has d floats --- */

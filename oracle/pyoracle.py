@@ -52,6 +52,10 @@ def load(desc_type):
         lib.jvo_nvq_dequantize.restype = None
         lib.jvo_parallel_copy.argtypes = [vp, vp, C.c_size_t]
         lib.jvo_parallel_copy.restype = None
+        lib.jvo_set_simd.argtypes = [C.c_int]
+        lib.jvo_set_simd.restype = None
+        lib.jvo_get_simd.argtypes = []
+        lib.jvo_get_simd.restype = C.c_int
         _lib = lib
     return _lib
 

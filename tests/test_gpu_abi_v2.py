@@ -196,3 +196,70 @@ def test_scratch_is_shared_per_device_and_accounted(pkg, small):
     # every handle reports its own contexts + the ONE shared HBM-scratch of the device: far below 0.7 GB per context
     assert max(sb) < 300 * 2**20 and min(sb) > 0, sb
     [h.close() for h in handles]
+
+
+def test_sharded_search_with_global_filter_visit_limit_and_status(pkg, pyoracle):
+    """jv_search_sharded_batch_ex: the doc filter is a bitset over the GLOBAL doc ids (every leaf search of the reference gets
+    its acceptDocs, J/JVectorReader.java:157-163) -> equal to the oracle's merge of the FILTERED shard answers; the visit limit
+    applies per shard search and surfaces as the OR of the shards' EARLY flags; per-query status stays JV_OK."""
+    b, bl, dg = pkg.binding, pkg.builder, pkg.datagen
+    sh = __import__("importlib").import_module("opensearch_jvector_amd.sharding")
+    n_total, d, k, rk, G = 9000, 64, 10, 60, 3
+    q = dg.splitmix_uniform(43, 64, d)
+    rng = np.random.default_rng(17)
+    words = b.accept_words(np.nonzero(rng.random(n_total) < 0.4)[0], n_total)
+    shards, orcs = [], []
+    for g in range(G):
+        lo, hi = sh.shard_range(n_total, G, g)
+        base = dg.splitmix_uniform(42, hi - lo, d, row_offset=lo)
+        ix = bl.build_index_cpu(base, 0, R=32, L=60, pq_M=32, ord2doc=np.arange(lo, hi, dtype=np.int32), max_doc=n_total)
+        shards.append(b.GpuIndex(ix, flags=b.DESC_FUSED_ADC))
+        orcs.append(pyoracle.Oracle(b, ix))
+    grp = b.ShardGroup(shards)
+    for acc in (None, words):
+        kw = dict(accept=acc, accept_num_docs=(n_total if acc is not None else 0))
+        ws = [o.search_batch(q, k, rk, **kw) for o in orcs]
+        od, os_ = pyoracle.merge_topk(b, np.concatenate([w.docs for w in ws], axis=1), np.concatenate([w.scores for w in ws], axis=1), k)
+        got, status, flags, rc = grp.search_batch_ex(q, k, rk, **kw)
+        assert rc == b.JV_OK and (status == 0).all() and (flags == 0).all()
+        assert np.array_equal(got.docs, od) and np.array_equal(got.scores.view(np.uint32), os_.view(np.uint32))
+        assert np.array_equal(got.stats, sum(w.stats for w in ws))
+        if acc is not None:
+            ok = set(np.nonzero(np.unpackbits(acc.view(np.uint8), bitorder="little")[:n_total])[0].tolist())
+            assert all(int(x) in ok for x in got.docs.reshape(-1) if x >= 0)
+        # visit limit: below every shard search's expansion count -> every query is flagged EARLY by some shard
+        lim = int(min(w.stats[:, 2].min() for w in ws))
+        got2, status2, flags2, rc2 = grp.search_batch_ex(q, k, rk, visit_limit=max(1, lim - 1), **kw)
+        assert rc2 == b.JV_OK and (status2 == 0).all() and ((flags2 & b.QFLAG_EARLY_TERMINATED) != 0).all()
+    # plain call == ex call without extras
+    a1 = grp.search_batch(q, k, rk)
+    a2, _, _, _ = grp.search_batch_ex(q, k, rk)
+    assert np.array_equal(a1.docs, a2.docs) and np.array_equal(a1.stats, a2.stats)
+    grp.close()
+    [s.close() for s in shards]
+
+
+def test_shard_group_on_two_devices(pkg, pyoracle):
+    """the gather between DIFFERENT devices (peer copies over xGMI); skipped on one-GPU boxes"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    b, bl, dg = pkg.binding, pkg.builder, pkg.datagen
+    sh = __import__("importlib").import_module("opensearch_jvector_amd.sharding")
+    n_total, d, k, rk, G = 8000, 64, 10, 60, 2
+    q = dg.splitmix_uniform(43, 96, d)
+    shards, ws = [], []
+    for g in range(G):
+        lo, hi = sh.shard_range(n_total, G, g)
+        base = dg.splitmix_uniform(42, hi - lo, d, row_offset=lo)
+        ix = bl.build_index_cpu(base, 0, R=32, L=60, pq_M=32, ord2doc=np.arange(lo, hi, dtype=np.int32), max_doc=n_total)
+        shards.append(b.GpuIndex(ix, flags=b.DESC_FUSED_ADC, device=g))
+        ws.append(pyoracle.Oracle(b, ix).search_batch(q, k, rk))
+    assert shards[0].info().device == 0 and shards[1].info().device == 1
+    grp = b.ShardGroup(shards)
+    od, os_ = pyoracle.merge_topk(b, np.concatenate([w.docs for w in ws], axis=1), np.concatenate([w.scores for w in ws], axis=1), k)
+    for _ in range(3):
+        got = grp.search_batch(q, k, rk)
+        assert np.array_equal(got.docs, od) and np.array_equal(got.scores.view(np.uint32), os_.view(np.uint32))
+    grp.close()
+    [s.close() for s in shards]

@@ -127,3 +127,24 @@ def test_threshold_filters_results(pkg, pyoracle):
     assert (res.scores[0][:c] >= 0.8).all()
     truth, ts = orc.brute_force(q, 10)
     assert set(res.nodes[0][:c].tolist()) <= set(np.asarray(truth[0])[ts[0] >= 0.8].tolist()) | set(res.nodes[0][:c].tolist())
+
+
+def test_simd_mode_changes_nothing(pkg, pyoracle):
+    """the CPU baseline's explicit AVX2 mode (look-up-table gathers, software prefetch; oracle/jv_oracle.c jvo_set_simd)
+    keeps every floating-point operation in the canonical order: ids, score bits and counters equal the plain loops'"""
+    b, bl, dg = pkg.binding, pkg.builder, pkg.datagen
+    base = dg.splitmix_uniform(5, 3000, 64)
+    q = dg.splitmix_uniform(6, 40, 64)
+    for M in (32, 16, 24):
+        ix = bl.build_index_cpu(base, 0, R=16, L=50, pq_M=M)
+        orc = pyoracle.Oracle(b, ix)
+        try:
+            orc.lib.jvo_set_simd(0)
+            a = orc.search_batch(q, 10, 80)
+            orc.lib.jvo_set_simd(1)
+            assert orc.lib.jvo_get_simd() == 1
+            c = orc.search_batch(q, 10, 80)
+        finally:
+            orc.lib.jvo_set_simd(0)
+        assert np.array_equal(a.nodes, c.nodes) and np.array_equal(a.stats, c.stats)
+        assert np.array_equal(a.scores.view(np.uint32), c.scores.view(np.uint32))

@@ -15,8 +15,11 @@ n = int(os.environ.get("N", 2_000_000)); d = 768; M = 32; rk = int(os.environ.ge
 secs = float(os.environ.get("SECS", 3))
 dev = torch.device("cuda", 0)
 zc, Bl, Bg = bench.make_block_generators(torch, d, dev, max(64, min(4096, n // 256)), M=M, per=2)
-base = bench.gen_rows_block(torch, n, d, 42, 0, zc, Bl, Bg, 0.35, 0.1, 0.005, False, dev)
-q = bench.gen_rows_block(torch, NQ, d, 43, 0, zc, Bl, Bg, 0.35, 0.1, 0.005, False, dev)
+if os.environ.get("DIST"):   # bench.py's distributions ("rotated": the headline data, rerankK 1200)
+    base, q = bench.make_pq_data(torch, os.environ["DIST"], n, NQ, d, M, 0, n, False, dev)
+else:
+    base = bench.gen_rows_block(torch, n, d, 42, 0, zc, Bl, Bg, 0.35, 0.1, 0.005, False, dev)
+    q = bench.gen_rows_block(torch, NQ, d, 43, 0, zc, Bl, Bg, 0.35, 0.1, 0.005, False, dev)
 adj, entry = gb.build_graph_gpu(torch, base, 0, R=32, L=100, verbose=False)
 pq = gb.pq_train_encode_gpu(torch, base, M, 0)
 desc, keep = b.make_desc_device(n, d, 32, base.data_ptr(), adj.data_ptr(), entry, 0, pq_M=M, pq_K=pq["K"], pq_codebooks=pq["codebooks"],

@@ -21,7 +21,7 @@ def run(budget, seed0):
         n = int(rng.integers(150, int(os.environ.get("FUZZ_NMAX", 2500))))   # FUZZ_NMAX=9000: pools of the 4 096-entry launches too
         R = int(rng.choice([8, 16, 32]))
         sim = int(rng.integers(0, 3))
-        M = int(rng.choice([2, 4, 16, 32]))
+        M = int(rng.choice([2, 4, 16, 32, 32, 64]))   # (32 and 64: the several-waves kernel)
         d = M * int(rng.integers(1, 4)) if M >= 16 else int(rng.choice([4, 8, 24]))
         ties = rng.random() < 0.4
         if ties:

@@ -43,6 +43,21 @@ def main(src, name):
                   "attributes the main kernel's last ~2 ms — its slowest queries draining — to the dispatch that follows it, "
                   "which is why the no-op retry launch shows ~2 ms here while HIP events put the whole ladder at 0.04 ms, "
                   "tools/pqf_bailouts.py).", ""]
+    # resource usage of the main kernel's instance as dispatched (kernel-trace columns): register / scratch regressions
+    # show up here round to round
+    tpath = os.path.join(src, "jv_kernel_trace.csv")
+    if os.path.exists(tpath):
+        seen = set()
+        lines += ["## resource usage of the dispatched instances", "", "| kernel | workgroup | grid | VGPRs | AGPRs | SGPRs | scratch B/lane | LDS B/workgroup |", "|---|---|---|---|---|---|---|---|"]
+        for r in csv.DictReader(open(tpath)):
+            nm = r.get("Kernel_Name", "")
+            if main_kernel not in nm or nm in seen:
+                continue
+            seen.add(nm)
+            lines.append(f"| `{nm.split('(')[0]}` | {r.get('Workgroup_Size', r.get('Workgroup_Size_X', '?'))} | {r.get('Grid_Size', r.get('Grid_Size_X', '?'))} | "
+                         f"{r.get('VGPR_Count', '?')} | {r.get('Accum_VGPR_Count', '?')} | {r.get('SGPR_Count', '?')} | {r.get('Scratch_Size', r.get('Private_Segment_Size', '?'))} | "
+                         f"{r.get('LDS_Block_Size', r.get('Group_Segment_Size', '?'))} |")
+        lines.append("")
     traffic = {}
     for cname in ("FETCH_SIZE", "WRITE_SIZE"):
         p = os.path.join(src, f"pmc_{cname}.csv")
@@ -50,7 +65,7 @@ def main(src, name):
             continue
         by_name = {}
         for r in csv.DictReader(open(p)):
-            if main_kernel in r["Kernel_Name"] and (r["Grid_Size"] == grid or "pqp" in main_kernel):
+            if main_kernel in r["Kernel_Name"] and (r["Grid_Size"] == grid or "pqp" in main_kernel or "pqw" in main_kernel):
                 by_name.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
         # (the persistent kernel is launched twice per step: the main launch and the wider second launch over the few
         #  flagged queries, a different template instance — the main one is the instance that moves the bytes)
