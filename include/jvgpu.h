@@ -261,6 +261,11 @@ int jv_search_sharded_batch(jv_shard_group* group, const float* queries, int32_t
                             float threshold, float rerankFloor, int32_t* out_docs, float* out_scores,
                             int32_t* out_count, int32_t* out_stats);
 
+/* Group options: "gather" = 0 (default) moves every shard's (doc, score) lists to the first shard's device with one
+ * peer-to-peer copy per shard; = 1 gathers them with ONE RCCL all-gather over xGMI (communicators owned by the group,
+ * librccl opened at run time; every shard must sit on its own device).  The merged answers are identical. */
+int jv_shard_group_set_option(jv_shard_group* group, const char* name, int64_t value);
+
 /* The same with jv_search_params: the doc filter is a bitset over the GLOBAL doc-id space of the group (every shard's
  * ord2doc maps into it; the reference hands every leaf search its acceptDocs, J/JVectorReader.java:157-163), visit_limit
  * applies to every shard's search on its own, out_status[i] (optional) is JV_OK / JV_ENOMEM per query, out_flags[i] (optional)

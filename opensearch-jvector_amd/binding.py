@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "jv_index_create", "jv_index_destroy", "jv_search", "jv_search_batch", "jv_search_batch_device",
     "jv_score_ordinals", "jv_merge_topk_device", "jv_index_get_info", "jv_set_option", "jv_last_error",
     "jv_abi_version", "jv_search_ex", "jv_search_batch_ex", "jv_index_set_option", "jv_index_get_counter", "jv_shard_group_create",
-    "jv_shard_group_destroy", "jv_search_sharded_batch", "jv_search_sharded_batch_ex",
+    "jv_shard_group_destroy", "jv_search_sharded_batch", "jv_search_sharded_batch_ex", "jv_shard_group_set_option",
 ]
 QFLAG_RETRIED_BIG, QFLAG_EARLY_TERMINATED = 0x1, 0x2
 
@@ -259,6 +259,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.jv_search_sharded_batch.restype = C.c_int
     lib.jv_search_sharded_batch_ex.argtypes = [vp, vp, i32, C.POINTER(JvSearchParams), vp, vp, vp, vp, vp, vp]
     lib.jv_search_sharded_batch_ex.restype = C.c_int
+    lib.jv_shard_group_set_option.argtypes = [vp, C.c_char_p, i64]
+    lib.jv_shard_group_set_option.restype = C.c_int
     _lib = lib
     return lib
 
@@ -454,6 +456,10 @@ class ShardGroup:
                                                           docs.ctypes.data, scores.ctypes.data, count.ctypes.data, stats.ctypes.data))
         return SearchResult(docs.copy(), docs, scores, count, stats)
 
+
+    def set_option(self, name: str, value: int):
+        """jv_shard_group_set_option ("gather": 0 peer copies, 1 RCCL all-gather)"""
+        _check(self.lib, self.lib.jv_shard_group_set_option(self.handle, name.encode(), int(value)))
 
     def search_batch_ex(self, queries: np.ndarray, topK: int, rerankK: int, threshold: float = 0.0, rerank_floor: float = 0.0,
                         accept: Optional[np.ndarray] = None, accept_num_docs: int = 0, visit_limit: int = 0):

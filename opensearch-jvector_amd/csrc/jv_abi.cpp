@@ -18,6 +18,7 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
 #include <errno.h>
 #include <sched.h>
 #include <semaphore.h>
@@ -2156,7 +2157,48 @@ struct jv_shard_group {
     int32_t* g_flags = nullptr;  // [G][nq]
     size_t cap_g = 0, cap_m = 0, cap_s = 0;
     hipStream_t merge_stream = nullptr;
+    // optional: the per-shard (doc, score) lists travel by ONE RCCL all-gather over xGMI instead of one peer copy per shard
+    // (jv_shard_group_set_option "gather" = 1; the north star's collective, owned by the library so that a one-JVM-per-node
+    // host gets it without a process per GPU).  librccl is opened at run time: no link-time dependency.
+    int gather_mode = 0;               // 0 peer copies, 1 RCCL all-gather
+    std::vector<void*> comms;          // ncclComm_t per shard
+    std::vector<int32_t*> d_gathered;  // per shard: [G][nq][k] pairs (every rank receives everything)
+    size_t cap_gathered = 0;
 };
+
+namespace {
+// the handful of RCCL entry points the shard group uses, resolved from librccl.so at first use
+struct RcclApi {
+    void* lib = nullptr;
+    int (*CommInitAll)(void** comms, int ndev, const int* devlist) = nullptr;
+    int (*CommDestroy)(void* comm) = nullptr;
+    int (*AllGather)(const void* send, void* recv, size_t count, int dtype, void* comm, hipStream_t stream) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool ok = false;
+};
+RcclApi& rccl_api() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char* name : {"librccl.so.1", "librccl.so"}) {
+            api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (api.lib) break;
+        }
+        if (!api.lib) return;
+        api.CommInitAll = (int (*)(void**, int, const int*))dlsym(api.lib, "ncclCommInitAll");
+        api.CommDestroy = (int (*)(void*))dlsym(api.lib, "ncclCommDestroy");
+        api.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(api.lib, "ncclAllGather");
+        api.GroupStart = (int (*)())dlsym(api.lib, "ncclGroupStart");
+        api.GroupEnd = (int (*)())dlsym(api.lib, "ncclGroupEnd");
+        api.GetErrorString = (const char* (*)(int))dlsym(api.lib, "ncclGetErrorString");
+        api.ok = api.CommInitAll && api.CommDestroy && api.AllGather && api.GroupStart && api.GroupEnd;
+    });
+    return api;
+}
+const int kNcclInt32 = 2;  // rccl.h: ncclInt32
+}  // namespace
 
 namespace {
 template <typename T>
@@ -2235,6 +2277,12 @@ void jv_shard_group_destroy(jv_shard_group* grp) {
         if (p.done) hipEventDestroy(p.done);
         if (p.stream) hipStreamDestroy(p.stream);
     }
+    for (size_t g = 0; g < grp->d_gathered.size(); g++) {
+        hipSetDevice(grp->shards[g]->device);
+        jv_free(grp->d_gathered[g]);
+    }
+    for (void* cm : grp->comms)
+        if (cm && rccl_api().ok) rccl_api().CommDestroy(cm);
     if (!grp->shards.empty()) hipSetDevice(grp->shards[0]->device);
     jv_free(grp->g_docs);
     jv_free(grp->g_scores);
@@ -2244,6 +2292,38 @@ void jv_shard_group_destroy(jv_shard_group* grp) {
     jv_free(grp->g_flags);
     if (grp->merge_stream) hipStreamDestroy(grp->merge_stream);
     delete grp;
+}
+
+int jv_shard_group_set_option(jv_shard_group* grp, const char* name, int64_t value) {
+    if (!grp || !name) return fail(JV_EINVAL, "group/name is NULL");
+    if (strcmp(name, "gather") != 0) return fail(JV_EINVAL, "unknown shard group option '%s'", name);
+    std::lock_guard<std::mutex> lk(grp->mu);
+    if (value == 0) {
+        grp->gather_mode = 0;
+        return JV_OK;
+    }
+    if (value != 1) return fail(JV_EINVAL, "gather must be 0 (peer copies) or 1 (RCCL all-gather)");
+    const int G = (int)grp->shards.size();
+    for (int a = 0; a < G; a++)
+        for (int b2 = a + 1; b2 < G; b2++)
+            if (grp->shards[(size_t)a]->device == grp->shards[(size_t)b2]->device)
+                return fail(JV_EUNSUPPORTED, "RCCL gather needs every shard on its own device (shards %d and %d share device %d)", a, b2,
+                            grp->shards[(size_t)a]->device);
+    RcclApi& api = rccl_api();
+    if (!api.ok) return fail(JV_EUNSUPPORTED, "librccl.so could not be opened: RCCL gather unavailable");
+    if (grp->comms.empty()) {
+        std::vector<int> devs((size_t)G);
+        for (int g = 0; g < G; g++) devs[(size_t)g] = grp->shards[(size_t)g]->device;
+        grp->comms.assign((size_t)G, nullptr);
+        const int r = api.CommInitAll(grp->comms.data(), G, devs.data());
+        if (r != 0) {
+            grp->comms.clear();
+            return fail(JV_EDEVICE, "ncclCommInitAll failed: %s", api.GetErrorString ? api.GetErrorString(r) : "?");
+        }
+        grp->d_gathered.assign((size_t)G, nullptr);
+    }
+    grp->gather_mode = 1;
+    return JV_OK;
 }
 
 int jv_search_sharded_batch(jv_shard_group* grp, const float* queries, int32_t nq, int32_t topK, int32_t rerankK,
@@ -2363,15 +2443,42 @@ int jv_search_sharded_batch_ex(jv_shard_group* grp, const float* queries, int32_
         // 2. gather: this shard's [nq][k] (doc, score) pairs go to slot g of the [G][nq][k] buffer on device 0 in ONE
         //    peer copy over xGMI (+ the counters and flags)
         HIPCHK(jvk_launch_pack_pairs(p.d_docs, p.d_scores, p.d_pairs, (long long)outn, p.stream));
-        HIPCHK(hipMemcpyPeerAsync(grp->g_docs + 2 * (size_t)g * outn, dev0, p.d_pairs, ix->device, outn * 8, p.stream));
+        if (grp->gather_mode == 0)
+            HIPCHK(hipMemcpyPeerAsync(grp->g_docs + 2 * (size_t)g * outn, dev0, p.d_pairs, ix->device, outn * 8, p.stream));
         HIPCHK(hipMemcpyPeerAsync(grp->g_stats + (size_t)g * (size_t)nq * 4, dev0, p.d_stats, ix->device, (size_t)nq * 16, p.stream));
         HIPCHK(hipMemcpyPeerAsync(grp->g_flags + (size_t)g * (size_t)nq, dev0, p.d_flags, ix->device, (size_t)nq * 4, p.stream));
         HIPCHK(hipEventRecord(p.done, p.stream));
     }
+    const int32_t* merge_src = grp->g_docs;
+    if (grp->gather_mode == 1) {
+        // 2b. ONE all-gather of the pair buffers: every device receives [G][nq][k] pairs (device 0's copy is merged)
+        RcclApi& api = rccl_api();
+        if (grp->cap_gathered < 2 * outn * (size_t)G) {
+            for (int g = 0; g < G; g++) {
+                HIPCHK(hipSetDevice(grp->shards[(size_t)g]->device));
+                jv_free(grp->d_gathered[(size_t)g]);
+                grp->d_gathered[(size_t)g] = nullptr;
+                HIPCHK(hipMalloc((void**)&grp->d_gathered[(size_t)g], 2 * outn * (size_t)G * sizeof(int32_t)));
+            }
+            grp->cap_gathered = 2 * outn * (size_t)G;
+        }
+        int r = api.GroupStart();
+        for (int g = 0; g < G && r == 0; g++) {
+            HIPCHK(hipSetDevice(grp->shards[(size_t)g]->device));
+            r = api.AllGather(grp->per[(size_t)g].d_pairs, grp->d_gathered[(size_t)g], 2 * outn, kNcclInt32, grp->comms[(size_t)g], grp->per[(size_t)g].stream);
+        }
+        const int r2 = api.GroupEnd();
+        if (r != 0 || r2 != 0) return fail(JV_EDEVICE, "ncclAllGather failed: %s", api.GetErrorString ? api.GetErrorString(r != 0 ? r : r2) : "?");
+        for (int g = 0; g < G; g++) {
+            HIPCHK(hipSetDevice(grp->shards[(size_t)g]->device));
+            HIPCHK(hipEventRecord(grp->per[(size_t)g].done, grp->per[(size_t)g].stream));
+        }
+        merge_src = grp->d_gathered[0];
+    }
     // 3. merge on device 0 once every shard's lists have arrived
     HIPCHK(hipSetDevice(dev0));
     for (int g = 0; g < G; g++) HIPCHK(hipStreamWaitEvent(grp->merge_stream, grp->per[(size_t)g].done, 0));
-    HIPCHK(jvk_launch_merge_topk_strided(grp->g_docs, grp->g_scores, nq, G, topK, grp->m_docs, grp->m_scores, grp->merge_stream));
+    HIPCHK(jvk_launch_merge_topk_strided(merge_src, grp->g_scores, nq, G, topK, grp->m_docs, grp->m_scores, grp->merge_stream));
     std::vector<int32_t> h_stats((size_t)G * (size_t)nq * 4), h_flags((size_t)G * (size_t)nq);
     HIPCHK(hipMemcpyAsync(out_docs, grp->m_docs, outn * 4, hipMemcpyDeviceToHost, grp->merge_stream));
     HIPCHK(hipMemcpyAsync(out_scores, grp->m_scores, outn * 4, hipMemcpyDeviceToHost, grp->merge_stream));

@@ -258,8 +258,26 @@ def test_shard_group_on_two_devices(pkg, pyoracle):
     assert shards[0].info().device == 0 and shards[1].info().device == 1
     grp = b.ShardGroup(shards)
     od, os_ = pyoracle.merge_topk(b, np.concatenate([w.docs for w in ws], axis=1), np.concatenate([w.scores for w in ws], axis=1), k)
-    for _ in range(3):
-        got = grp.search_batch(q, k, rk)
-        assert np.array_equal(got.docs, od) and np.array_equal(got.scores.view(np.uint32), os_.view(np.uint32))
+    for gather in (0, 1, 0):   # peer copies, ONE RCCL all-gather of the pair buffers, and back
+        grp.set_option("gather", gather)
+        for _ in range(2):
+            got = grp.search_batch(q, k, rk)
+            assert np.array_equal(got.docs, od) and np.array_equal(got.scores.view(np.uint32), os_.view(np.uint32)), gather
     grp.close()
     [s.close() for s in shards]
+
+
+def test_rccl_gather_is_refused_when_shards_share_a_device(pkg):
+    b, bl, dg = pkg.binding, pkg.builder, pkg.datagen
+    base = dg.splitmix_uniform(1, 500, 16)
+    ix = bl.build_index_cpu(base, 0, R=8, L=20)
+    s1, s2 = b.GpuIndex(ix), b.GpuIndex(ix)
+    grp = b.ShardGroup([s1, s2])
+    with pytest.raises(b.JvError):
+        grp.set_option("gather", 1)
+    grp.set_option("gather", 0)
+    with pytest.raises(b.JvError):
+        grp.set_option("no_such_option", 1)
+    grp.close()
+    s1.close()
+    s2.close()
