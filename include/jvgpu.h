@@ -163,7 +163,10 @@ typedef struct jv_search_params {
      * AbstractKnnVectorQuery then DISCARDS the approximate result when that sum reached the limit and runs the exact
      * scan (-> jv_score_ordinals).  With visit_limit > 0 the engine stops such a search as soon as visited + expanded
      * reaches the limit and sets JV_QFLAG_EARLY_TERMINATED instead of finishing work that is going to be thrown away;
-     * searches that stay below the limit are unchanged (same ids, scores, counters).  0 = never stop early. */
+     * searches that stay below the limit are unchanged (same ids, scores, counters).  0 = never stop early.
+     * The fused-PQ pool kernels only know `expanded` while searching (they count `visited` afterwards): they stop once the
+     * expansions alone reach the limit, and a search that finished but whose visited + expanded reaches it is flagged
+     * afterwards — either way every flagged row is empty and every unflagged row has visited + expanded < visit_limit. */
     int64_t visit_limit;
     /* Identity of the filter's CONTENTS for the device-side filter cache (option "filter_cache", per index): a bitset
      * that was uploaded before is served from HBM instead of crossing PCIe again.  0 = the library hashes the words.

@@ -566,6 +566,8 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
         }
     }
 
+    // a search that ended by itself with visited + expanded at or beyond Lucene's visit limit is discarded like the stopped ones
+    if (!st.overflow && !early && a.visit_limit > 0 && st.visited + st.expanded >= a.visit_limit) early = true;
     // NodeQueue.rerank bookkeeping (PQ): how many results reach rerankFloor; if none, the single entry to rescore
     int above = 0, only_node = -1;
     if (PQ && !st.overflow && !early) {
@@ -1294,6 +1296,25 @@ __device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int 
             __syncthreads();
         }
         np = w;
+    }
+    if (!overflow && a.visit_limit > 0 && visited + expanded >= a.visit_limit) {
+        // the search ran to its end, but visited + expanded reaches Lucene's visit limit: discarded like the stopped ones,
+        // with its real counters (include/jvgpu.h, jv_search_params.visit_limit)
+        if (lane == 0) {
+            a.out_flags[qi] = (int32_t)JV_FLAG_EARLY;
+            a.out_count[qi] = 0;
+            int32_t* st = a.out_stats + (size_t)qi * 4;
+            st[0] = visited;
+            st[1] = 0;
+            st[2] = expanded;
+            st[3] = expanded;
+        }
+        for (int i = lane; i < topK; i += JV_WAVE) {
+            o_nodes[i] = -1;
+            if (o_docs) o_docs[i] = -1;
+            o_scores[i] = 0.0f;
+        }
+        return;
     }
     const int nres = np < rk ? np : rk;
     int nfin = 0, reranked = 0;

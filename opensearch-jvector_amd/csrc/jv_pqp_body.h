@@ -781,6 +781,14 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
     }
     STAMP(6)  // visited-count pass
     STAMP_FLUSH
+    // Lucene discards every search whose visited + expanded reached the visit limit (J/JVectorReader.java:202-207 reports the
+    // sum, AbstractKnnVectorQuery tests it).  The loop above stops on expansions alone (visited is only known now): a search
+    // that ran to its end but whose SUM reaches the limit is flagged the same way, with its real counters.
+    int early_vis = -1;
+    if (why == 0 && a.visit_limit > 0 && visited + expanded >= a.visit_limit) {
+        why = 15;
+        early_vis = visited;
+    }
     const int nres = np < rk ? np : rk;
     // ---- rerank scratch (where the LUT / the hash set was): query, todo lists, exact keys ----
     float* q_lds = (float*)smem;
@@ -816,7 +824,7 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
             a.out_count[qi] = 0;
             if (why == 15) {
                 int32_t* st = a.out_stats + (size_t)qi * 4;
-                st[0] = 0;
+                st[0] = early_vis >= 0 ? early_vis : 0;
                 st[1] = 0;
                 st[2] = expanded;
                 st[3] = expanded;

@@ -70,6 +70,9 @@ def test_visit_limit_stops_searches_lucene_would_discard(pkg, pyoracle, small):
                 early = (fl & b.QFLAG_EARLY_TERMINATED) != 0
                 if must_fire:
                     assert early.any(), (limit, int(early.sum()))
+                # every search Lucene would discard is flagged, whichever kernel ran it (the fused-PQ kernels test the sum
+                # once more after they have counted `visited`)
+                assert (work[~early] < limit).all(), (limit, work[~early].max())
                 # untouched searches: identical to the oracle
                 for i in np.nonzero(~early)[0]:
                     assert np.array_equal(res.nodes[i], want.nodes[i]) and np.array_equal(res.stats[i], want.stats[i])

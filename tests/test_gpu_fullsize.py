@@ -213,9 +213,15 @@ def test_c4_shard_12m5_1536_pq64(pkg, pyoracle):
     r2 = _search(torch, gpu, q, k, rk)
     for key in ("nodes", "scores", "stats"):
         assert np.array_equal(r1[key], r2[key]), f"idempotence: {key}"
-    truth = bench.brute_force_topk(torch, base, q[:256], k, 0).cpu().numpy()
-    rec = np.mean([len(set(r1["nodes"][i]) & set(truth[i])) / k for i in range(256)])
-    assert rec >= 0.6, rec
+    truth = bench.brute_force_topk(torch, base, q[:512], k, 0).cpu().numpy()
+    rec = np.mean([len(set(r1["nodes"][i]) & set(truth[i])) / k for i in range(512)])
+    assert rec >= 0.85, rec   # (0.907 measured at rerankK 800, tools/c4_sweep.py)
+    # the metric's recall bar on this shard: rerankK 1200 -> 0.9535, 1600 -> 0.9746 (tools/c4_sweep.py, 512 queries); the
+    # beam that clears 0.95 with a margin is asserted (PQ-64 on 1536 rotated dims loses about as much as PQ-32 on 768)
+    r16 = _search(torch, gpu, q[:512], k, 1600)
+    rec16 = np.mean([len(set(r16["nodes"][i]) & set(truth[i])) / k for i in range(512)])
+    assert rec16 >= 0.95, rec16
+    assert gpu.counter("launches_pqw") > 0, "PQ-64 runs on the four-waves-per-query kernel"
     ids = torch.from_numpy(r1["nodes"][:32].astype(np.int64)).to(dev)
     d2 = ((q[:32, None, :].double() - base[ids].double()) ** 2).sum(-1)
     np.testing.assert_allclose(r1["scores"][:32], (1.0 / (1.0 + d2)).cpu().numpy(), rtol=1e-4)
@@ -225,3 +231,31 @@ def test_c4_shard_12m5_1536_pq64(pkg, pyoracle):
     for key in ("nodes", "scores", "stats"):
         assert np.array_equal(r256[key], r1[key][:256]), f"batch=256 vs batch=2048: {key}"
     gpu.close()
+
+
+def test_mixture_b_recall_is_limited_by_the_codes_not_by_the_graph(pkg):
+    """SURVEY 8(d) distribution B (4 096-centre Gaussian mixture, full rank inside a cluster): 32-byte PQ cannot rank it
+    (bench.py reports recall 0.10 at rerankK 900 on 10M docs).  The same graph searched with the EXACT provider reaches
+    the bar at a small beam, so the loss is the codes', not the traversal's (VERDICT r2 #4b): 1M docs, recall@10 >= 0.95 at
+    rerankK 400 without PQ (0.975 measured), < 0.7 with PQ-32 at the same beam (0.48 measured)."""
+    torch, bench, gb = _setup()
+    b = pkg.binding
+    dev = torch.device("cuda", 0)
+    n, d, M, k, B = 1_000_000, 768, 32, 10, 1024
+    base, q = bench.make_pq_data(torch, "mixtureB", n, B, d, M, 0, n, False, dev)
+    adj, entry = gb.build_graph_gpu(torch, base, 0, R=32, L=100, verbose=False)
+    truth = bench.brute_force_topk(torch, base, q, k, 0).cpu().numpy()
+    desc, keep = b.make_desc_device(n, d, 32, base.data_ptr(), adj.data_ptr(), entry, 0, borrow=True)
+    exact = b.GpuIndex(desc=desc, keepalive=keep, flags=b.DESC_BORROW)
+    r = _search(torch, exact, q, k, 400)
+    rec_exact = np.mean([len(set(r["nodes"][i]) & set(truth[i])) / k for i in range(B)])
+    exact.close()
+    pq = gb.pq_train_encode_gpu(torch, base, M, 0)
+    desc, keep = b.make_desc_device(n, d, 32, base.data_ptr(), adj.data_ptr(), entry, 0, pq_M=M, pq_K=pq["K"], pq_codebooks=pq["codebooks"],
+                                    pq_centroid=pq["centroid"], pq_codes_ptr=pq["codes"].data_ptr(), borrow=True, extra_flags=b.DESC_FUSED_ADC)
+    fused = b.GpuIndex(desc=desc, keepalive=keep, flags=b.DESC_BORROW)
+    r = _search(torch, fused, q, k, 400)
+    rec_pq = np.mean([len(set(r["nodes"][i]) & set(truth[i])) / k for i in range(B)])
+    fused.close()
+    assert rec_exact >= 0.95, rec_exact
+    assert rec_pq < 0.7, rec_pq
