@@ -46,6 +46,9 @@ def _prune_lib():
         lib.jvb_pq_encode_device.argtypes = [vp, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int,
                                              C.c_int, vp]
         lib.jvb_pq_encode_device.restype = C.c_int
+        lib.jvb_pq_train_device.argtypes = [vp, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_longlong, vp, C.c_int,
+                                            vp, vp, vp, vp, vp, C.c_int, vp]
+        lib.jvb_pq_train_device.restype = C.c_int
         _PRUNE_LIB = lib
     return _PRUNE_LIB
 
@@ -301,44 +304,36 @@ def pq_encode_gpu(torch, base, M, K, codebooks_t, centroid_t):
 
 def pq_train_encode_gpu(torch, base, M, sim, K=256, iters=8, max_train=128000, seed=1):
     """ProductQuantization.compute analogue: K = min(256, n) clusters per subspace, global centring iff
-    EUCLIDEAN (J/JVectorIndexQuantization.java:122-131).  Returns dict(codebooks (np), centroid (np|None),
-    codes (uint8 tensor [n][M]), K)."""
+    EUCLIDEAN (J/JVectorIndexQuantization.java:122-131).  Training runs in csrc/jv_build_kernels.hip
+    (jvb_pq_train_device: column mean, sample gather, Lloyd's algorithm with the ENCODER as the assign step and a
+    reduction-tree update, no atomics -> reproducible bit for bit); this function only allocates the buffers and picks the
+    seeded initial centroids.  Returns dict(codebooks (np), centroid (np|None), codes (uint8 tensor [n][M]), K)."""
     n, d = base.shape
     dev = base.device
     K = min(K, n)
     center = sim == 0
-    centroid = None
-    if center:
-        acc = torch.zeros((d,), dtype=torch.float64, device=dev)
-        for s in range(0, n, 1 << 18):
-            acc += base[s:s + (1 << 18)].sum(0, dtype=torch.float64)
-        centroid = (acc / n).to(torch.float32)
     sizes = [d // M + (1 if m < d % M else 0) for m in range(M)]
-    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(int)
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    cb_off = np.concatenate([[0], np.cumsum([K * s_ for s_ in sizes])[:-1]]).astype(np.int64)
     nt = min(n, max_train)
     rows = (torch.arange(nt, device=dev, dtype=torch.int64) * n) // nt
-    X = base[rows]
-    if center:
-        X = X - centroid
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
-    books = []
-    for m in range(M):
-        xm = X[:, offs[m]:offs[m + 1]].contiguous()
-        init = torch.randperm(nt, generator=g, device=dev)[:K]
-        cb = xm[init].clone()
-        for _ in range(iters):
-            dist = (xm * xm).sum(1, keepdim=True) - 2 * xm @ cb.T + (cb * cb).sum(1)[None, :]
-            asg = dist.argmin(1)
-            # cluster sums through a one-hot GEMM (no float atomics: two builds of the same data give the same codebooks)
-            onehot = torch.zeros((K, nt), device=dev, dtype=torch.float32)
-            onehot[asg, torch.arange(nt, device=dev)] = 1.0
-            sums = onehot @ xm
-            cnt = torch.bincount(asg, minlength=K).to(torch.float32)
-            nz = cnt > 0
-            cb[nz] = sums[nz] / cnt[nz, None]
-        books.append(cb)
-    codebooks_t = torch.cat([b_.reshape(-1) for b_ in books]).contiguous()
+    init = torch.stack([torch.randperm(nt, generator=g, device=dev)[:K] for _ in range(M)]).contiguous()   # [M][K] sample positions
+    t_off = torch.from_numpy(offs).to(dev)
+    t_cb = torch.from_numpy(cb_off).to(dev)
+    centroid = torch.empty((d,), dtype=torch.float32, device=dev) if center else None
+    sample = torch.empty((nt, d), dtype=torch.float32, device=dev)
+    sample_codes = torch.empty((nt, M), dtype=torch.uint8, device=dev)
+    partial = torch.empty((64, d), dtype=torch.float64, device=dev)
+    codebooks_t = torch.empty((int(K * d),), dtype=torch.float32, device=dev)
+    lib = _prune_lib()
+    rc = lib.jvb_pq_train_device(base.data_ptr(), n, d, base.stride(0), M, K, t_off.data_ptr(), t_cb.data_ptr(), rows.data_ptr(), nt,
+                                 init.data_ptr(), iters, (centroid.data_ptr() if center else None), sample.data_ptr(),
+                                 sample_codes.data_ptr(), partial.data_ptr(), codebooks_t.data_ptr(), int(max(sizes)),
+                                 torch.cuda.current_stream(dev).cuda_stream)
+    if rc != 0:
+        raise RuntimeError(f"jvb_pq_train_device failed: {rc}")
+    del sample, sample_codes, partial
     codes = pq_encode_gpu(torch, base, M, K, codebooks_t, centroid)
-    codebooks = np.concatenate([b.cpu().numpy().reshape(-1) for b in books]).astype(np.float32)
-    return dict(codebooks=codebooks, centroid=(centroid.cpu().numpy() if center else None), codes=codes, K=K)
+    return dict(codebooks=codebooks_t.cpu().numpy().astype(np.float32), centroid=(centroid.cpu().numpy() if center else None), codes=codes, K=K)

@@ -173,3 +173,118 @@ extern "C" int jvb_pq_encode_device(const float* vectors, long long n, int d, in
                                                                     code_stride);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// PQ training (J/JVectorIndexQuantization.java:114-140: ProductQuantization.compute on a sample of the
+// vectors, K = min(256, n) clusters per subspace, global centring iff EUCLIDEAN).  Lloyd's algorithm with the ASSIGN step
+// = jvb_pq_encode_kernel (the canonical fmaf-chain distance, ties to the lowest index: training and encoding agree on what
+// "nearest" means) and the UPDATE step below: no float atomics anywhere, so two trainings of the same data give the same
+// codebooks bit for bit.
+// ---------------------------------------------------------------------------------------------------------------
+
+// column means in two deterministic steps: per-block partial sums in f64 (fixed row order), then one thread per column
+__global__ __launch_bounds__(256) void jvb_col_partial_kernel(const float* __restrict__ v, long long n, int d, int stride, int slabs,
+                                                              double* __restrict__ partial) {  // [slabs][d]
+    const int slab = blockIdx.y;
+    const long long per = (n + slabs - 1) / slabs, r0 = slab * per, r1 = r0 + per < n ? r0 + per : n;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < d; j += gridDim.x * blockDim.x) {
+        double acc = 0.0;
+        for (long long i = r0; i < r1; i++) acc += (double)v[(size_t)i * (size_t)stride + j];
+        partial[(size_t)slab * d + j] = acc;
+    }
+}
+__global__ void jvb_col_mean_kernel(const double* __restrict__ partial, int slabs, int d, long long n, float* __restrict__ mean) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= d) return;
+    double acc = 0.0;
+    for (int s = 0; s < slabs; s++) acc += partial[(size_t)s * d + j];
+    mean[j] = (float)(acc / (double)n);
+}
+
+// gathers the training sample (rows[i] of the corpus, centred) into a dense [nt][d] matrix
+__global__ __launch_bounds__(256) void jvb_gather_rows_kernel(const float* __restrict__ v, int d, int stride, const long long* __restrict__ rows,
+                                                              long long nt, const float* __restrict__ centroid, float* __restrict__ out) {
+    for (long long i = blockIdx.x; i < nt; i += gridDim.x) {
+        const float* src = v + (size_t)rows[i] * (size_t)stride;
+        for (int j = threadIdx.x; j < d; j += blockDim.x) out[(size_t)i * d + j] = centroid ? src[j] - centroid[j] : src[j];
+    }
+}
+
+// UPDATE: one workgroup per (subspace m, cluster c).  Thread t accumulates the members among rows t, t + 256, ... in row
+// order; the 256 partial vectors meet in a fixed pairwise tree in LDS.  Empty clusters keep their centroid.
+#define PQT_TILE 128  // columns of a subspace summed per pass (wider subspaces take several passes over the members)
+__global__ __launch_bounds__(256) void jvb_pq_update_kernel(const float* __restrict__ x, long long nt, int d, const int32_t* __restrict__ sub_off,
+                                                            const uint8_t* __restrict__ codes, int M, int K, float* __restrict__ codebooks,
+                                                            const long long* __restrict__ cb_off) {
+    extern __shared__ float red[];  // [256][tw + 1] (the last column counts members)
+    const int m = blockIdx.y, c = blockIdx.x;
+    const int d0 = sub_off[m], ds = sub_off[m + 1] - d0;
+    const int t = threadIdx.x;
+    for (int j0 = 0; j0 < ds; j0 += PQT_TILE) {
+        const int tw = ds - j0 < PQT_TILE ? ds - j0 : PQT_TILE;
+        float* mine = red + (size_t)t * (tw + 1);
+        for (int j = 0; j <= tw; j++) mine[j] = 0.0f;
+        for (long long i = t; i < nt; i += 256) {
+            if (codes[(size_t)i * M + m] == (uint8_t)c) {
+                const float* row = x + (size_t)i * d + d0 + j0;
+                for (int j = 0; j < tw; j++) mine[j] += row[j];
+                mine[tw] += 1.0f;
+            }
+        }
+        __syncthreads();
+        for (int w = 128; w >= 1; w >>= 1) {
+            if (t < w) {
+                float* a_ = red + (size_t)t * (tw + 1);
+                const float* b_ = red + (size_t)(t + w) * (tw + 1);
+                for (int j = 0; j <= tw; j++) a_[j] += b_[j];
+            }
+            __syncthreads();
+        }
+        const float cnt = red[tw];
+        if (cnt > 0.0f) {
+            float* cb = codebooks + cb_off[m] + (size_t)c * ds + j0;
+            for (int j = t; j < tw; j += 256) cb[j] = red[j] / cnt;
+        }
+        __syncthreads();
+    }
+}
+
+// codebooks[m][c][:] = x[init[c]][subspace m]
+__global__ void jvb_pq_init_kernel(const float* __restrict__ x, int d, const int32_t* __restrict__ sub_off, const long long* __restrict__ init,
+                                   int M, int K, float* __restrict__ codebooks, const long long* __restrict__ cb_off) {
+    const int m = blockIdx.y, c = blockIdx.x;
+    const int d0 = sub_off[m], ds = sub_off[m + 1] - d0;
+    for (int j = threadIdx.x; j < ds; j += blockDim.x) codebooks[cb_off[m] + (size_t)c * ds + j] = x[(size_t)init[(size_t)m * K + c] * d + d0 + j];
+}
+
+// Trains M codebooks of K centroids on the rows `rows` [nt] of `vectors` (all device pointers; sub_off [M + 1] int32,
+// cb_off [M] int64, init [M][K] int64 = sample positions of the initial centroids; scratch: sample [nt][d] floats,
+// sample_codes [nt][M] bytes, partial [64][d] doubles).  centroid_out (or NULL: no centring) receives the corpus mean.
+extern "C" int jvb_pq_train_device(const float* vectors, long long n, int d, int stride, int M, int K, const int32_t* sub_off,
+                                   const long long* cb_off, const long long* rows, long long nt, const long long* init, int iters,
+                                   float* centroid_out, float* sample, uint8_t* sample_codes, double* partial, float* codebooks,
+                                   int max_ds, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n <= 0 || nt <= 0 || M <= 0 || K <= 0 || K > 256 || max_ds <= 0) return -4;
+    if (centroid_out) {
+        const int slabs = 64;
+        jvb_col_partial_kernel<<<dim3((unsigned)((d + 255) / 256), slabs), 256, 0, stream>>>(vectors, n, d, stride, slabs, partial);
+        jvb_col_mean_kernel<<<(d + 255) / 256, 256, 0, stream>>>(partial, slabs, d, n, centroid_out);
+    }
+    jvb_gather_rows_kernel<<<(unsigned)(nt < 65535 ? nt : 65535), 256, 0, stream>>>(vectors, d, stride, rows, nt, centroid_out, sample);
+    jvb_pq_init_kernel<<<dim3((unsigned)K, (unsigned)M), 64, 0, stream>>>(sample, d, sub_off, init, M, K, codebooks, cb_off);
+    const size_t lds = (size_t)256 * (size_t)((max_ds < PQT_TILE ? max_ds : PQT_TILE) + 1) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)jvb_pq_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -3;
+        attr_set = true;
+    }
+    for (int it = 0; it < iters; it++) {
+        // ASSIGN: the encoder on the (already centred) sample
+        const int rc = jvb_pq_encode_device(sample, nt, d, d, M, K, sub_off, codebooks, cb_off, nullptr, sample_codes, M, max_ds, stream_);
+        if (rc != 0) return rc;
+        jvb_pq_update_kernel<<<dim3((unsigned)K, (unsigned)M), 256, lds, stream>>>(sample, nt, d, sub_off, sample_codes, M, K, codebooks, cb_off);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}

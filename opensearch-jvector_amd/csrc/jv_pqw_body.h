@@ -229,6 +229,8 @@ __device__ void search_one_pqw(const JvIndexDev& ix, const JvSearchArgs& a, cons
     if (wv == 0) PQW_STAMP(7)  // LUT build + entry point
     if (wv == 0) {
         // ================================ wave 0: the pool ================================
+        // (it is the query's critical path: on a SIMD shared with other queries' helper waves it issues first)
+        __builtin_amdgcn_s_setprio(2);
         [&](const int lane) {
         // Two blocks per scoring pass: lanes 0..31 hold the neighbours of the best unexpanded entry, lanes 32..63 those of
         // the runner-up (R <= 32).  The runner-up's scores wait in their lanes: when it is still the best entry one
@@ -625,6 +627,7 @@ __device__ void search_one_pqw(const JvIndexDev& ix, const JvSearchArgs& a, cons
         // the log was written by lane 0 and is read back by every wave: drain the stores (read side: L1-bypassing loads)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         }(opaque_lane());
+        __builtin_amdgcn_s_setprio(0);
     } else {
         // ================================ waves 1 .. W-1: chunk sums ================================
         [&](const int lane) {

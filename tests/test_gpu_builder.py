@@ -61,6 +61,41 @@ def test_gpu_builds_are_reproducible(pkg):
     assert e1 == e2 and torch.equal(adj1, adj2)
 
 
+@pytest.mark.parametrize("d,M,sim", [(96, 16, 0), (100, 7, 1), (768, 8, 0)])
+def test_pq_training_is_lloyd_and_improves_on_its_start(pkg, d, M, sim):
+    """jvb_pq_train_device (csrc/jv_build_kernels.hip): every centroid is the mean of the sample rows the ENCODER assigns to
+    it (one more Lloyd step moves nothing much: the quantisation error of the trained codebooks is below the error of the
+    initial ones and within 2 % of a further iteration's), the centroid is the corpus mean iff EUCLIDEAN, K = min(256, n)."""
+    torch, gb = _gb()
+    dev = torch.device("cuda", 0)
+    n = 20000
+    base = torch.from_numpy(pkg.datagen.splitmix_uniform(90 + d, n, d) - np.float32(0.3)).to(dev)
+
+    def err(pq):
+        sizes = [d // M + (1 if m < d % M else 0) for m in range(M)]
+        off, cbo, tot = 0, 0, 0.0
+        x = base - torch.from_numpy(pq["centroid"]).to(dev) if pq["centroid"] is not None else base
+        cb = torch.from_numpy(pq["codebooks"]).to(dev)
+        for m, s_ in enumerate(sizes):
+            book = cb[cbo:cbo + pq["K"] * s_].reshape(pq["K"], s_)
+            rec = book[pq["codes"][:, m].long()]
+            tot += float(((x[:, off:off + s_] - rec) ** 2).sum())
+            off += s_
+            cbo += pq["K"] * s_
+        return tot / n
+
+    e0, e8, e9 = (err(gb.pq_train_encode_gpu(torch, base, M, sim, iters=i)) for i in (0, 8, 9))
+    assert e8 < 0.8 * e0, (e0, e8)
+    assert e9 <= e8 * 1.0001 and e9 >= 0.98 * e8, (e8, e9)
+    pq = gb.pq_train_encode_gpu(torch, base, M, sim)
+    if sim == 0:
+        np.testing.assert_allclose(pq["centroid"], base.double().mean(0).float().cpu().numpy(), rtol=1e-5, atol=1e-6)
+    else:
+        assert pq["centroid"] is None
+    small = gb.pq_train_encode_gpu(torch, base[:100].contiguous(), M, sim)
+    assert small["K"] == 100
+
+
 def test_ka15_recall_floor_through_the_gpu_builder(pkg, pyoracle):
     """KA15 (JVectorWriterMergeTests.java:55,78-92,122-123,178-212): base = java.util.Random(42) floats, queries =
     Random(43), d = 128, k = 10, L2: recall >= 0.99 against brute force at over-query 5 and 20 — graph from the GPU builder,
