@@ -627,6 +627,18 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
         // wave per chunk.  LDS = [pool | centred query | hash set | rerank scratch] + the waves' exchange rows + ctrl words.
         const bool pqw = !filtered && OPT(ix, OPT_NO_PQW) == 0 && jvk_pqw_ok(&ix->dev, ap.cand_cap) && nq >= OPT(ix, OPT_PQW_MIN_QUERIES);
         if (pqw) jvk_pqw_set_occ3(OPT(ix, OPT_PQW_OCC3) != 0 ? 1 : 0);  // (diagnostic switch, process-wide)
+        if (pqw) {
+            // the first launch keeps what it can: an expansion log four times as long (it lives in HBM) and, where the LDS
+            // budget of the same residency and the same capacity class allow it, 128 instead of 64 boundary-tie slots —
+            // every query it does not have to hand over saves the second launch (whose length is its slowest query's)
+            ap.pqp_log_cap = (12 * rk + 1024 + 3) & ~3;
+            JvSearchArgs wide = ap;
+            wide.cand_cap = ap.cand_cap + 64;
+            const int lds_now = plan_pqw_lds(ix, ap), lds_wide = plan_pqw_lds(ix, wide);
+            auto klass = [](int cap) { return cap <= 512 ? 0 : cap <= 1024 ? 1 : 2; };
+            if (jvk_pqw_ok(&ix->dev, wide.cand_cap) && klass(wide.cand_cap) == klass(ap.cand_cap) && kMaxLds / lds_wide == kMaxLds / lds_now)
+                ap.cand_cap = wide.cand_cap;
+        }
         const int lds = pqw ? plan_pqw_lds(ix, ap) : plan(ap, lutr != 0);
         // second launch for what outgrows the first (more than 63 ties at the rerankK boundary, a longer expansion log):
         // table in LDS, as many tie slots as the largest pool class allows, 4x the log; walks the flag array

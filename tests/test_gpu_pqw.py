@@ -116,11 +116,13 @@ def test_many_queries_per_resident_workgroup_and_visit_limit(pkg, pyoracle):
     gpu, orc = b.GpuIndex(ix, flags=b.DESC_FUSED_ADC), pyoracle.Oracle(b, ix)
     want = orc.search_batch(q, 10, 80)
     _both_kernels(gpu, "6000 queries", lambda: gpu.search_batch(q, 10, 80), want)
-    # visit limit: a query whose search would expand more nodes is flagged early-terminated and returns nothing
-    lim = int(np.median(want.stats[:64, 2]))
+    # visit limit: exactly the searches whose visited + expanded reaches it are flagged early-terminated and return nothing
+    work = want.stats[:64, 0] + want.stats[:64, 2]
+    lim = int(np.median(work))
     got, status, flags, rc = gpu.search_batch_ex(q[:64], 10, 80, visit_limit=lim)
     early = (flags & b.QFLAG_EARLY_TERMINATED) != 0
     assert early.any() and (~early).any()
-    assert np.array_equal(got.nodes[~early], want.nodes[:64][~early])
+    assert np.array_equal(early, work >= lim)
+    assert np.array_equal(got.nodes[~early], want.nodes[:64][~early]) and np.array_equal(got.stats[~early], want.stats[:64][~early])
     assert (got.count[early] == 0).all()
     gpu.close()
