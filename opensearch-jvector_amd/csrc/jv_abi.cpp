@@ -51,10 +51,9 @@ hipError_t jvk_launch_search_pqp(const JvIndexDev* ix, const JvSearchArgs* a, in
 hipError_t jvk_pqw_set_max_lds(int bytes);
 int jvk_pqw_ok(const JvIndexDev* ix, int cap);
 int jvk_pqw_waves(const JvIndexDev* ix);
-int jvk_pqw_lds_rows(void);
-int jvk_pqw_blocks_per_cu(const JvIndexDev* ix, int cap, int lds_bytes);
-hipError_t jvk_launch_search_pqw(const JvIndexDev* ix, const JvSearchArgs* a, int lds_bytes, int blocks, hipStream_t s);
-void jvk_pqw_set_occ3(int on);
+int jvk_pqw_lds_rows(int variant);
+int jvk_pqw_blocks_per_cu(const JvIndexDev* ix, int cap, int lds_bytes, int variant);
+hipError_t jvk_launch_search_pqw(const JvIndexDev* ix, const JvSearchArgs* a, int lds_bytes, int blocks, int variant, hipStream_t s);
 // device-resident query server (jv_kernels_pqs.hip)
 hipError_t jvk_pqs_set_max_lds(int bytes);
 int jvk_pqs_blocks_per_cu(const JvIndexDev* ix, int cap, int lds_bytes);
@@ -90,6 +89,7 @@ int fail(int code, const char* fmt, ...) {
 //   lds_visited_slots / lds_candidates   on-chip scratch geometry of the generic kernels (0 = auto)
 //   force_big_path / force_general_path / no_escalation / no_pqf / no_pqp / no_pqw / no_lutr / pqf_only   rung selection (diagnostics)
 //   pqw_min_queries                      launches with at least this many queries use the several-waves-per-query kernel
+//   pqw_latency_queries                  launches with at most this many queries use its latency variant: whole table in LDS (-1 = 3 per CU)
 //   spill_tables x spill_slots           per-context pool of visited-set spill tables (512 x 8192 x 4 B = 16 MB, allocated on first use)
 //   big_blocks / big_cand_cap / big_budget_mb   HBM-scratch rung: resident blocks (0 = as many as fit the budget), candidate slots
 //   combine / combine_leaders / combine_max_batch   group commit of concurrent jv_search calls
@@ -100,7 +100,7 @@ int fail(int code, const char* fmt, ...) {
 //   direct_completion                    combined one-query calls: rows land in pinned memory, every caller is woken by its own query's completion word
 //   lutr_min_queries                     launches with more queries keep the PQ look-up table in registers (-1 = 4 per CU)
 //   dbg_ptr                              diagnostic build only
-enum OptId { OPT_LDS_VISITED_SLOTS, OPT_LDS_CANDIDATES, OPT_FORCE_BIG, OPT_FORCE_GENERAL, OPT_NO_ESCALATION, OPT_DBG_PTR, OPT_NO_PQF, OPT_NO_PQP, OPT_NO_LUTR, OPT_LUTR_MIN_QUERIES, OPT_PQP_BLOCKS_PER_CU, OPT_NO_PQW, OPT_PQW_MIN_QUERIES, OPT_PQW_OCC3, OPT_PQF_ONLY, OPT_SPILL_TABLES, OPT_SPILL_SLOTS, OPT_BIG_BLOCKS, OPT_BIG_CAND_CAP, OPT_BIG_BUDGET_MB, OPT_COMBINE, OPT_COMBINE_LEADERS, OPT_COMBINE_MAX_BATCH, OPT_MAX_CONTEXTS, OPT_FILTER_CACHE, OPT_DIRECT_COMPLETION, OPT_LAZY_BIG, OPT_SERVE, OPT_SERVE_WGS_PER_CU, OPT_SERVE_IDLE_MS, OPT_COUNT };
+enum OptId { OPT_LDS_VISITED_SLOTS, OPT_LDS_CANDIDATES, OPT_FORCE_BIG, OPT_FORCE_GENERAL, OPT_NO_ESCALATION, OPT_DBG_PTR, OPT_NO_PQF, OPT_NO_PQP, OPT_NO_LUTR, OPT_LUTR_MIN_QUERIES, OPT_PQP_BLOCKS_PER_CU, OPT_NO_PQW, OPT_PQW_MIN_QUERIES, OPT_PQW_LAT_QUERIES, OPT_PQF_ONLY, OPT_SPILL_TABLES, OPT_SPILL_SLOTS, OPT_BIG_BLOCKS, OPT_BIG_CAND_CAP, OPT_BIG_BUDGET_MB, OPT_COMBINE, OPT_COMBINE_LEADERS, OPT_COMBINE_MAX_BATCH, OPT_MAX_CONTEXTS, OPT_FILTER_CACHE, OPT_DIRECT_COMPLETION, OPT_LAZY_BIG, OPT_SERVE, OPT_SERVE_WGS_PER_CU, OPT_SERVE_IDLE_MS, OPT_COUNT };
 struct OptName { const char* name; int64_t def; };
 const OptName kOptNames[OPT_COUNT] = {
     {"lds_visited_slots", 0},
@@ -116,7 +116,7 @@ const OptName kOptNames[OPT_COUNT] = {
     {"pqp_blocks_per_cu", 0},
     {"no_pqw", 0},
     {"pqw_min_queries", 0},
-    {"pqw_occ3", 0},
+    {"pqw_latency_queries", -1},
     {"pqf_only", 0},
     {"spill_tables", 512},
     {"spill_slots", 8192},
@@ -491,13 +491,13 @@ int ensure_spill(jv_index* ix, Ctx* c) {
 
 // LDS plan of the several-waves pool kernel for a pool of x.cand_cap entries:
 // [pool | centred query | table rows | hash set | rerank scratch] + the waves' exchange rows + ctrl words
-int plan_pqw_lds(const jv_index* ix, JvSearchArgs& x) {
+int plan_pqw_lds(const jv_index* ix, JvSearchArgs& x, int variant) {
     const int Wn = jvk_pqw_waves(&ix->dev);
     const int qc_b = ix->dev.nch * 64 * 4;
     const int pool_b = (x.cand_cap + 1) * 8;
     const int rr_b = qc_b + Wn * JV_TODO * 8 + (x.cand_cap + 64) * 8;
     x.pqw_lut_off = (std::max(pool_b, qc_b) + 15) & ~15;  // table rows kept in LDS, behind the pool / the centred query
-    const int lut_end = x.pqw_lut_off + Wn * jvk_pqw_lds_rows() * 1024;
+    const int lut_end = x.pqw_lut_off + Wn * jvk_pqw_lds_rows(variant) * 1024;
     const int front = (std::max(std::max(16384, lut_end), std::max(qc_b, rr_b)) + 15) & ~15;
     x.pqp_pool_off = 0;
     x.pqp_qc_off = 0;
@@ -626,7 +626,10 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
         // Several waves per query (jv_kernels_pqw.hip: PQ-32 / PQ-64, unfiltered): table in registers split by chunk, one
         // wave per chunk.  LDS = [pool | centred query | hash set | rerank scratch] + the waves' exchange rows + ctrl words.
         const bool pqw = !filtered && OPT(ix, OPT_NO_PQW) == 0 && jvk_pqw_ok(&ix->dev, ap.cand_cap) && nq >= OPT(ix, OPT_PQW_MIN_QUERIES);
-        if (pqw) jvk_pqw_set_occ3(OPT(ix, OPT_PQW_OCC3) != 0 ? 1 : 0);  // (diagnostic switch, process-wide)
+        // few queries: every resident query has a CU (almost) to itself and its time is the launch's — the variant with the
+        // whole table in LDS (a third of the scoring pass's instructions, 3 workgroups per CU)
+        const int64_t lat_q = OPT(ix, OPT_PQW_LAT_QUERIES) >= 0 ? OPT(ix, OPT_PQW_LAT_QUERIES) : 3 * (int64_t)ix->cu_count;
+        const int pqw_variant = (pqw && nq <= lat_q) ? 1 : 0;
         if (pqw) {
             // the first launch keeps what it can: an expansion log four times as long (it lives in HBM) and, where the LDS
             // budget of the same residency and the same capacity class allow it, 128 instead of 64 boundary-tie slots —
@@ -634,12 +637,12 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
             ap.pqp_log_cap = (12 * rk + 1024 + 3) & ~3;
             JvSearchArgs wide = ap;
             wide.cand_cap = ap.cand_cap + 64;
-            const int lds_now = plan_pqw_lds(ix, ap), lds_wide = plan_pqw_lds(ix, wide);
+            const int lds_now = plan_pqw_lds(ix, ap, pqw_variant), lds_wide = plan_pqw_lds(ix, wide, pqw_variant);
             auto klass = [](int cap) { return cap <= 512 ? 0 : cap <= 1024 ? 1 : 2; };
             if (jvk_pqw_ok(&ix->dev, wide.cand_cap) && klass(wide.cand_cap) == klass(ap.cand_cap) && kMaxLds / lds_wide == kMaxLds / lds_now)
                 ap.cand_cap = wide.cand_cap;
         }
-        const int lds = pqw ? plan_pqw_lds(ix, ap) : plan(ap, lutr != 0);
+        const int lds = pqw ? plan_pqw_lds(ix, ap, pqw_variant) : plan(ap, lutr != 0);
         // second launch for what outgrows the first (more than 63 ties at the rerankK boundary, a longer expansion log):
         // table in LDS, as many tie slots as the largest pool class allows, 4x the log; walks the flag array
         JvSearchArgs ap2 = ap;
@@ -650,7 +653,7 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
         const int lds2 = plan(ap2, false);
         const bool second = lds2 <= kMaxLds && ap2.cand_cap > ap.cand_cap && OPT(ix, OPT_PQF_ONLY) == 0;
         if (lds <= kMaxLds) {
-            int per_cu = pqw ? jvk_pqw_blocks_per_cu(&ix->dev, ap.cand_cap, lds) : jvk_pqp_blocks_per_cu(&ix->dev, ap.cand_cap, lds, lutr, filtered ? 1 : 0);
+            int per_cu = pqw ? jvk_pqw_blocks_per_cu(&ix->dev, ap.cand_cap, lds, pqw_variant) : jvk_pqp_blocks_per_cu(&ix->dev, ap.cand_cap, lds, lutr, filtered ? 1 : 0);
             if (OPT(ix, OPT_PQP_BLOCKS_PER_CU) > 0) per_cu = (int)std::min<int64_t>(per_cu, OPT(ix, OPT_PQP_BLOCKS_PER_CU));  // diagnostics
             int blocks = ix->cu_count * per_cu;
             if (blocks > nq) blocks = nq;
@@ -668,7 +671,7 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
             }
             ap.pqp_log = c->pqp_log;
             ap.pqp_counter = c->work_counter + 6;
-            if (pqw) HIPCHK(jvk_launch_search_pqw(&ix->dev, &ap, lds, blocks, stream));
+            if (pqw) HIPCHK(jvk_launch_search_pqw(&ix->dev, &ap, lds, blocks, pqw_variant, stream));
             else HIPCHK(jvk_launch_search_pqp(&ix->dev, &ap, lds, blocks, lutr, stream));
             ix->launches[pqw ? LAUNCH_PQW : LAUNCH_PQP]++;
             if (second) {
@@ -914,7 +917,7 @@ Server* server_get(jv_index* ix, int need_cap, int* rc) {
     a.topK = 1;
     a.nq = 1;
     a.pqp_log_cap = (3 * a.rk + 64 + 3) & ~3;
-    sv->lds = plan_pqw_lds(ix, a);
+    sv->lds = plan_pqw_lds(ix, a, 1);
     const int per_cu = std::min<int>(jvk_pqs_blocks_per_cu(&ix->dev, sv->cap_max, sv->lds), (int)std::max<int64_t>(1, OPT(ix, OPT_SERVE_WGS_PER_CU)));
     sv->blocks = ix->cu_count * per_cu;
     sv->slots = next_pow2(std::max(1024, 2 * sv->blocks));

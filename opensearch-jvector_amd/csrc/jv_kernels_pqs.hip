@@ -5,10 +5,11 @@
 typedef void (*pqs_kernel_t)(const JvIndexDev, const JvSearchArgs);
 #define JV_PQS_ROW(CAPK, W, OCC, NL) \
     { jv_serve_pqw_kernel<0, CAPK, W, OCC, NL>, jv_serve_pqw_kernel<2, CAPK, W, OCC, NL>, jv_serve_pqw_kernel<12, CAPK, W, OCC, NL>, jv_serve_pqw_kernel<24, CAPK, W, OCC, NL> }
-// [0 -> two waves per query (PQ-32), 1 -> four (PQ-64)][capacity class 0..2][nch slot]; NL as in jv_kernels_pqw.hip
+// [0 -> two waves per query (PQ-32), 1 -> four (PQ-64)][capacity class 0..2][nch slot]; the latency variant of
+// jv_kernels_pqw.hip (whole table in LDS): a server query's time is its caller's latency
 static const pqs_kernel_t g_pqs_kernels[2][3][4] = {
-    {JV_PQS_ROW(0, 2, 4, 4), JV_PQS_ROW(1, 2, 4, 4), JV_PQS_ROW(2, 2, 4, 4)},
-    {JV_PQS_ROW(0, 4, 4, 4), JV_PQS_ROW(1, 4, 4, 4), JV_PQS_ROW(2, 4, 4, 4)},
+    {JV_PQS_ROW(0, 2, 4, 16), JV_PQS_ROW(1, 2, 4, 16), JV_PQS_ROW(2, 2, 4, 16)},
+    {JV_PQS_ROW(0, 4, 4, 16), JV_PQS_ROW(1, 4, 4, 16), JV_PQS_ROW(2, 4, 4, 16)},
 };
 
 static int pqs_nch_slot(const JvIndexDev* ix) {

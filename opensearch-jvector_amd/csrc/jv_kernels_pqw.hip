@@ -5,14 +5,16 @@
 typedef void (*pqw_kernel_t)(const JvIndexDev, const JvSearchArgs);
 #define JV_PQW_ROW(CAPK, W, OCC, NL) \
     { jv_search_pqw_kernel<0, CAPK, W, OCC, NL>, jv_search_pqw_kernel<2, CAPK, W, OCC, NL>, jv_search_pqw_kernel<12, CAPK, W, OCC, NL>, jv_search_pqw_kernel<24, CAPK, W, OCC, NL> }
-// [0 -> two waves, 1 -> four, 2 -> two waves at 3 waves per SIMD with 8 table rows per wave in LDS (diagnostics)][capacity class 0..2][nch slot]
-static const pqw_kernel_t g_pqw_kernels[3][3][4] = {
+// [variant * 2 + (PQ-64 ? 1 : 0)][capacity class 0..2][nch slot]
+//   variant 0 (throughput): 4 of a wave's 16 table rows in LDS, 12 in registers -> 8 workgroups of two waves per CU;
+//   variant 1 (latency): the whole table in LDS (plain gathers: a third of the scoring pass's instructions) -> 3 workgroups
+//   per CU: launches with few queries, and the device-resident query server
+static const pqw_kernel_t g_pqw_kernels[4][3][4] = {
     {JV_PQW_ROW(0, 2, 4, 4), JV_PQW_ROW(1, 2, 4, 4), JV_PQW_ROW(2, 2, 4, 4)},
     {JV_PQW_ROW(0, 4, 4, 4), JV_PQW_ROW(1, 4, 4, 4), JV_PQW_ROW(2, 4, 4, 4)},
-    {JV_PQW_ROW(0, 2, 3, 8), JV_PQW_ROW(1, 2, 3, 8), JV_PQW_ROW(2, 2, 3, 8)},
+    {JV_PQW_ROW(0, 2, 4, 16), JV_PQW_ROW(1, 2, 4, 16), JV_PQW_ROW(2, 2, 4, 16)},
+    {JV_PQW_ROW(0, 4, 4, 16), JV_PQW_ROW(1, 4, 4, 16), JV_PQW_ROW(2, 4, 4, 16)},
 };
-static int g_pqw_occ3 = 0;
-extern "C" void jvk_pqw_set_occ3(int on) { g_pqw_occ3 = on; }
 
 static int pqw_nch_slot(const JvIndexDev* ix) {
     if (ix->nvq_M > 0) return 0;  // the NVQ decoder lives in the "any d" instances only (score_rows)
@@ -21,17 +23,17 @@ static int pqw_nch_slot(const JvIndexDev* ix) {
 }
 static int pqw_capk(int cap) { return cap <= 512 ? 0 : cap <= 1024 ? 1 : 2; }
 extern "C" int jvk_pqw_waves(const JvIndexDev* ix) { return ix->pq_M / 16; }
-extern "C" int jvk_pqw_lds_rows(void) { return g_pqw_occ3 ? 8 : 4; }  // NL of the instances below: table rows per wave kept in LDS
+extern "C" int jvk_pqw_lds_rows(int variant) { return variant ? 16 : 4; }  // NL of the instances above: table rows per wave kept in LDS
 // shapes this kernel runs: one wave per 16-subspace chunk, one lane per stored neighbour, whole log groups per 64-entry chunk
 extern "C" int jvk_pqw_ok(const JvIndexDev* ix, int cap) {
     if (!(ix->pq_M == 32 || ix->pq_M == 64) || ix->sim == 2 || !ix->pq_fused || ix->num_upper != 0) return 0;
     if (ix->R < 1 || ix->R > JV_WAVE || 64 % ((JV_WAVE / ix->R) * 8) != 0) return 0;
     return cap <= 2048 && ix->n < (1 << 30) ? 1 : 0;
 }
-static pqw_kernel_t pqw_pick(const JvIndexDev* ix, int cap) { return g_pqw_kernels[ix->pq_M == 64 ? 1 : (g_pqw_occ3 ? 2 : 0)][pqw_capk(cap)][pqw_nch_slot(ix)]; }
+static pqw_kernel_t pqw_pick(const JvIndexDev* ix, int cap, int variant) { return g_pqw_kernels[(variant ? 2 : 0) + (ix->pq_M == 64 ? 1 : 0)][pqw_capk(cap)][pqw_nch_slot(ix)]; }
 
 extern "C" hipError_t jvk_pqw_set_max_lds(int bytes) {
-    for (int w = 0; w < 3; w++)
+    for (int w = 0; w < 4; w++)
         for (int c = 0; c < 3; c++)
             for (int s = 0; s < 4; s++) {
                 hipError_t e = hipFuncSetAttribute((const void*)g_pqw_kernels[w][c][s], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -41,15 +43,15 @@ extern "C" hipError_t jvk_pqw_set_max_lds(int bytes) {
 }
 
 // resident workgroups per CU for this index shape, pool capacity and LDS size
-extern "C" int jvk_pqw_blocks_per_cu(const JvIndexDev* ix, int cap, int lds_bytes) {
+extern "C" int jvk_pqw_blocks_per_cu(const JvIndexDev* ix, int cap, int lds_bytes, int variant) {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)pqw_pick(ix, cap), JV_WAVE * jvk_pqw_waves(ix), (size_t)lds_bytes) != hipSuccess) return 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)pqw_pick(ix, cap, variant), JV_WAVE * jvk_pqw_waves(ix), (size_t)lds_bytes) != hipSuccess) return 1;
     return nb < 1 ? 1 : nb;
 }
 
 // blocks = resident workgroups (the host sizes the log scratch to it); a->cand_cap = pool entries
-extern "C" hipError_t jvk_launch_search_pqw(const JvIndexDev* ix, const JvSearchArgs* a, int lds_bytes, int blocks, hipStream_t stream) {
+extern "C" hipError_t jvk_launch_search_pqw(const JvIndexDev* ix, const JvSearchArgs* a, int lds_bytes, int blocks, int variant, hipStream_t stream) {
     if (a->nq <= 0) return hipSuccess;
-    pqw_pick(ix, a->cand_cap)<<<blocks, JV_WAVE * jvk_pqw_waves(ix), lds_bytes, stream>>>(*ix, *a);
+    pqw_pick(ix, a->cand_cap, variant)<<<blocks, JV_WAVE * jvk_pqw_waves(ix), lds_bytes, stream>>>(*ix, *a);
     return hipGetLastError();
 }

@@ -97,7 +97,7 @@ __device__ void search_one_pqw(const JvIndexDev& ix, const JvSearchArgs& a, cons
     }
     __syncthreads();
     float* const lutl = (float*)(smem + a.pqw_lut_off) + wv * NL * 256;  // [NL][256] this wave's LDS rows
-    float lutr[16 - NL][4];  // lutr[i - NL][e], lane l = lut[16 wv + i][4 l + e]
+    float lutr[NL < 16 ? 16 - NL : 1][4];  // lutr[i - NL][e], lane l = lut[16 wv + i][4 l + e] (NL = 16: the whole table is in LDS)
     {
         const bool l2 = ix.sim == 0;
 #pragma unroll
@@ -133,7 +133,7 @@ __device__ void search_one_pqw(const JvIndexDev& ix, const JvSearchArgs& a, cons
                 *(f32x4*)(lutl + i * 256 + 4 * lane) = (f32x4){acc4[0], acc4[1], acc4[2], acc4[3]};
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; e++) lutr[i < NL ? 0 : i - NL][e] = acc4[e];
+                for (int e = 0; e < 4; e++) lutr[(i < NL || NL >= 16) ? 0 : i - NL][e] = acc4[e];
             }
         }
     }
@@ -161,7 +161,7 @@ __device__ void search_one_pqw(const JvIndexDev& ix, const JvSearchArgs& a, cons
                 const int w = (int)cw[i >> 2];
                 const int addr = (int)(((uint32_t)w >> ((i & 3) * 8)) & 0xFFu);  // ds_bpermute reads lane (addr >> 2) & 63 = code >> 2
 #pragma unroll
-                for (int e = 0; e < 4; e++) t[ii][e] = __builtin_amdgcn_ds_bpermute(addr, __float_as_int(lutr[i - NL][e]));
+                for (int e = 0; e < 4; e++) t[ii][e] = __builtin_amdgcn_ds_bpermute(addr, __float_as_int(lutr[NL >= 16 ? 0 : i - NL][e]));
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
