@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define JVGPU_ABI_VERSION 2
+#define JVGPU_ABI_VERSION 3
 
 /* ---- status codes (the Java shim maps them to the reference's exception types,
  *      SURVEY §8(b) "Errors": EINVAL -> IllegalArgumentException, EUNSUPPORTED ->
