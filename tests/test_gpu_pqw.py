@@ -126,3 +126,70 @@ def test_many_queries_per_resident_workgroup_and_visit_limit(pkg, pyoracle):
     assert np.array_equal(got.nodes[~early], want.nodes[:64][~early]) and np.array_equal(got.stats[~early], want.stats[:64][~early])
     assert (got.count[early] == 0).all()
     gpu.close()
+
+
+def test_query_server_under_mixed_traffic(pkg, pyoracle):
+    """The device-resident query server (one-query calls launch nothing: ring of pinned slots, completion word per query)
+    while OTHER traffic on the same handle forces the library through its device-wide synchronisation points: batch calls
+    of growing size (buffers are re-allocated: hipFree waits for every stream, so the server grid is paused first),
+    filtered calls (launch path) and a second index created and destroyed.  Every answer must equal the oracle's and the
+    server must have served the unfiltered one-query calls."""
+    import threading
+    b, bl, dg = pkg.binding, pkg.builder, pkg.datagen
+    n, d = 4000, 64
+    base = dg.splitmix_uniform(31, n, d)
+    q = dg.splitmix_uniform(32, 512, d)
+    ix = bl.build_index_cpu(base, 0, R=32, L=60, pq_M=32)
+    gpu, orc = b.GpuIndex(ix, flags=b.DESC_FUSED_ADC), pyoracle.Oracle(b, ix)
+    want = orc.search_batch(q, 10, 120)
+    rng = np.random.default_rng(4)
+    words = b.accept_words(np.nonzero(rng.random(n) < 0.5)[0], n)
+    want_f = orc.search_batch(q[:64], 10, 120, accept=words, accept_num_docs=n)
+    errors, stop = [], threading.Event()
+
+    def single(tid):
+        i = tid
+        while not stop.is_set():
+            j = i % len(q)
+            r = gpu.search(q[j], 10, 120)
+            if not (np.array_equal(r.nodes[0], want.nodes[j]) and np.array_equal(r.stats[0], want.stats[j]) and
+                    np.array_equal(r.scores[0].view(np.uint32), want.scores[j].view(np.uint32))):
+                errors.append(("single", tid, j))
+                return
+            i += 7
+
+    def batches():
+        sizes = [8, 40, 130, 300, 512, 64, 512]
+        k = 0
+        while not stop.is_set():
+            m = sizes[k % len(sizes)]
+            r = gpu.search_batch(q[:m], 10, 120)
+            if not (np.array_equal(r.nodes, want.nodes[:m]) and np.array_equal(r.stats, want.stats[:m])):
+                errors.append(("batch", m))
+                return
+            rf = gpu.search(q[k % 64], 10, 120, accept=words, accept_num_docs=n)
+            if not np.array_equal(rf.nodes[0], want_f.nodes[k % 64]):
+                errors.append(("filtered", k % 64))
+                return
+            if k % 3 == 0:   # another handle comes and goes on the same device
+                g2 = b.GpuIndex(ix, flags=b.DESC_FUSED_ADC)
+                r2 = g2.search(q[1], 10, 120)
+                if not np.array_equal(r2.nodes[0], want.nodes[1]):
+                    errors.append(("second index",))
+                g2.close()
+            k += 1
+
+    ts = [threading.Thread(target=single, args=(t,)) for t in range(12)] + [threading.Thread(target=batches)]
+    [t.start() for t in ts]
+    import time
+    time.sleep(4.0)
+    stop.set()
+    [t.join(timeout=60) for t in ts]
+    assert not any(t.is_alive() for t in ts), "a caller is stuck"
+    assert not errors, errors[:3]
+    assert gpu.counter("served_queries") > 100 and gpu.counter("launches_serve") >= 1
+    gpu.set_option("serve", 0)   # off: the same call takes the launch path
+    before = gpu.counter("served_queries")
+    r = gpu.search(q[3], 10, 120)
+    assert np.array_equal(r.nodes[0], want.nodes[3]) and gpu.counter("served_queries") == before
+    gpu.close()
