@@ -44,8 +44,11 @@ hipError_t jvk_launch_pack_pairs(const int32_t* d_docs, const float* d_scores, i
 // LDS-pool persistent kernel (jv_kernels_pqp.hip): the headline path
 hipError_t jvk_pqp_set_max_lds(int bytes);
 int jvk_pqp_max_entries(void);
+int jvk_pqp_max_entries_filtered(void);
 int jvk_pqp_blocks_per_cu(const JvIndexDev* ix, int cap, int lds_bytes, int lutr, int filt);
 int jvk_pqp_lutr_ok(const JvIndexDev* ix, int cap);
+int jvk_pqpf_lutr_ok(const JvIndexDev* ix, int cap);
+hipError_t jvk_launch_accept_to_ord(const JvIndexDev* ix, const uint64_t* accept, long long accept_docs, uint64_t* out, hipStream_t stream);
 hipError_t jvk_launch_search_pqp(const JvIndexDev* ix, const JvSearchArgs* a, int lds_bytes, int blocks, int lutr, hipStream_t s);
 // the same search with pq_M / 16 waves per query, the look-up table in registers split by chunk (jv_kernels_pqw.hip)
 hipError_t jvk_pqw_set_max_lds(int bytes);
@@ -167,6 +170,8 @@ struct Ctx {
     size_t nq_cap = 0;
     uint64_t* d_accept = nullptr;
     size_t accept_cap = 0;  // words
+    uint64_t* d_accept_ord = nullptr;  // a batch-wide filter in ordinal space (persistent pool kernel's filtered instances)
+    size_t accept_ord_cap = 0;         // words
     // host-pointer API: one device arena [nodes|docs|scores|count|stats|flags] + one pinned mirror, so a call
     // is one H2D (query) and ONE D2H instead of six staged pageable copies
     uint8_t* d_arena = nullptr;
@@ -330,6 +335,7 @@ void ctx_destroy(Ctx* c) {
     jv_free(c->d_queries);
     jv_free(c->d_flags);
     jv_free(c->d_accept);
+    jv_free(c->d_accept_ord);
     jv_free(c->d_arena);
     if (c->h_arena) hipHostFree(c->h_arena);
     if (c->h_query) hipHostFree(c->h_query);
@@ -589,6 +595,19 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
     if (!force_big && (pqp_plain || pqp_filt) && pqf_index && rk + 64 + ix->dev.R <= jvk_pqp_max_entries() && OPT(ix, OPT_NO_PQF) == 0 &&
         OPT(ix, OPT_NO_PQP) == 0) {
         JvSearchArgs ap = a;
+        if (filtered && a.accept_stride == 0 && ix->dev.ord2doc && nq >= 16) {
+            // one filter for the whole batch over a doc-id mapping: translate it to ordinal space first (jv_kernels_pqpf.hip)
+            const size_t words = ((size_t)ix->dev.n + 63) / 64;
+            if (words > c->accept_ord_cap) {
+                if (c->d_accept_ord) HIPCHK(jv_free(c->d_accept_ord));
+                c->d_accept_ord = nullptr;
+                c->accept_ord_cap = 0;
+                HIPCHK(hipMalloc((void**)&c->d_accept_ord, words * 8));
+                c->accept_ord_cap = words;
+            }
+            HIPCHK(jvk_launch_accept_to_ord(&ix->dev, a.accept, a.accept_docs, c->d_accept_ord, stream));
+            ap.accept_ord = c->d_accept_ord;
+        }
         const int lut_b = ix->dev.pq_M * 256 * 4;
         const int qc_b = ix->dev.nch * 64 * 4;
         ap.cand_cap = filtered ? std::min(2048, std::max(1024, 2 * (rk + 64 + ix->dev.R))) : rk + 64 + ix->dev.R;
@@ -612,6 +631,8 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
                 x.pqp_qc_off = 0;
                 x.pqp_scratch_off = (pool_b + 15) & ~15;
                 lds = std::max(std::max(x.pqp_scratch_off + 768, qc_b), std::max(16384, qc_b + JV_TODO * 8 + pool_b));
+                // (filtered classes 3, 4: the pool stays in LDS and everything after the search lives behind what is left of it)
+                if (x.cand_cap > 2048) lds = x.pqp_scratch_off + 768;
             } else {
                 x.pqp_pool_off = (std::max(lut_b, rerank_b) + 15) & ~15;
                 x.pqp_scratch_off = (x.pqp_pool_off + pool_b + 15) & ~15;
@@ -650,7 +671,9 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
         ap2.pqp_log_cap = filtered ? 3 * ap2.cand_cap : ((12 * rk + 1024 + 3) & ~3);
         ap2.retry_only = 1;
         ap2.retry_counter = c->work_counter + 5;
-        const int lds2 = plan(ap2, false);
+        // (filtered: the later launches keep the table in registers too — twice the resident queries per CU at these pool sizes)
+        const int lutr2 = filtered && OPT(ix, OPT_NO_LUTR) == 0 && jvk_pqpf_lutr_ok(&ix->dev, jvk_pqp_max_entries_filtered()) && nq > lutr_min_q ? 1 : 0;
+        const int lds2 = plan(ap2, lutr2 != 0);
         const bool second = lds2 <= kMaxLds && ap2.cand_cap > ap.cand_cap && OPT(ix, OPT_PQF_ONLY) == 0;
         if (lds <= kMaxLds) {
             int per_cu = pqw ? jvk_pqw_blocks_per_cu(&ix->dev, ap.cand_cap, lds, pqw_variant) : jvk_pqp_blocks_per_cu(&ix->dev, ap.cand_cap, lds, lutr, filtered ? 1 : 0);
@@ -658,10 +681,20 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
             int blocks = ix->cu_count * per_cu;
             if (blocks > nq) blocks = nq;
             // (unfiltered: a handful of flagged queries; filtered: a selective filter sends the whole batch here)
-            const int per_cu2 = filtered && second ? jvk_pqp_blocks_per_cu(&ix->dev, ap2.cand_cap, lds2, 0, 1) : 1;
+            const int per_cu2 = filtered && second ? jvk_pqp_blocks_per_cu(&ix->dev, ap2.cand_cap, lds2, lutr2, 1) : 1;
             const int blocks2 = std::min(ix->cu_count * per_cu2, (nq + 7) / 8);
+            // third launch (filtered only): pools of up to 8 192 entries — a filter of selectivity ~0.2 at rerankK 1 200 —
+            // stay on chip (64 KB pool + 32 KB table: one workgroup per CU) instead of falling to the HBM-scratch rung
+            JvSearchArgs ap3 = ap2;
+            ap3.cand_cap = jvk_pqp_max_entries_filtered();
+            ap3.pqp_log_cap = 3 * ap3.cand_cap;
+            ap3.retry_counter = c->work_counter + 3;
+            const int lds3 = filtered ? plan(ap3, lutr2 != 0) : 0;
+            const bool third = filtered && second && lds3 <= kMaxLds && ap3.cand_cap > ap2.cand_cap;
+            const int blocks3 = third ? std::min(ix->cu_count * jvk_pqp_blocks_per_cu(&ix->dev, ap3.cand_cap, lds3, lutr2, 1), (nq + 7) / 8) : 0;
             size_t need = (size_t)blocks * (size_t)ap.pqp_log_cap;
             if (second) need = std::max(need, (size_t)blocks2 * (size_t)ap2.pqp_log_cap);
+            if (third) need = std::max(need, (size_t)blocks3 * (size_t)ap3.pqp_log_cap);
             if (need > c->pqp_log_ints) {
                 if (c->pqp_log) HIPCHK(jv_free(c->pqp_log));
                 c->pqp_log = nullptr;
@@ -676,7 +709,11 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
             ix->launches[pqw ? LAUNCH_PQW : LAUNCH_PQP]++;
             if (second) {
                 ap2.pqp_log = c->pqp_log;
-                HIPCHK(jvk_launch_search_pqp(&ix->dev, &ap2, lds2, blocks2, 0, stream));
+                HIPCHK(jvk_launch_search_pqp(&ix->dev, &ap2, lds2, blocks2, lutr2, stream));
+            }
+            if (third) {
+                ap3.pqp_log = c->pqp_log;
+                HIPCHK(jvk_launch_search_pqp(&ix->dev, &ap3, lds3, blocks3, lutr2, stream));
             }
             pqf = true;
         }

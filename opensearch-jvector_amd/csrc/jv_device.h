@@ -57,6 +57,7 @@ struct JvSearchArgs {
     const uint64_t* accept;  // doc-space bitset or nullptr
     int64_t accept_docs;
     int64_t accept_stride;   // 64-bit words between consecutive queries' bitsets; 0 = one bitset for the whole batch
+    const uint64_t* accept_ord;  // optional: the SHARED filter translated to ordinal space ([ceil(n/64)] words; jvk_launch_accept_to_ord) — one load per neighbour instead of ord -> doc -> word
     int32_t* out_nodes;
     int32_t* out_docs;
     float* out_scores;

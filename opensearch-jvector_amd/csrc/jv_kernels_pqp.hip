@@ -39,17 +39,21 @@ static int pqp_nch_slot(const JvIndexDev* ix) {
     if (ix->stride != ix->nch * 64) return 0;
     return ix->nch == 2 ? 1 : ix->nch == 12 ? 2 : ix->nch == 24 ? 3 : 0;
 }
-static int pqp_capk(int cap) { return cap <= 512 ? 0 : cap <= 1024 ? 1 : cap <= 2048 ? 2 : 3; }
+static int pqp_capk(int cap) { return cap <= 512 ? 0 : cap <= 1024 ? 1 : cap <= 2048 ? 2 : cap <= 4096 ? 3 : 4; }  // (4: filtered instances only)
 // lutr: look-up table in registers (jvk_pqp_lutr_ok shapes only)
 extern "C" int jvk_pqp_lutr_ok(const JvIndexDev* ix, int cap) {
     return ix->pq_M == 32 && ix->sim != 2 && ix->R * ix->pq_lanes <= JV_WAVE && cap <= 2048 ? 1 : 0;
+}
+// (filtered instances: register-table variants for every pool class)
+extern "C" int jvk_pqpf_lutr_ok(const JvIndexDev* ix, int cap) {
+    return ix->pq_M == 32 && ix->sim != 2 && ix->R * ix->pq_lanes <= JV_WAVE && cap <= 8192 ? 1 : 0;
 }
 extern "C" const void* jvk_pqpf_kernel(int fast, int capk, int nch_slot, int lutr);  // jv_kernels_pqpf.hip
 extern "C" hipError_t jvk_pqpf_set_max_lds(int bytes);
 static pqp_kernel_t pqp_pick(const JvIndexDev* ix, int cap, int lutr, int filt = 0) {
     const int multi = ix->R * ix->pq_lanes > JV_WAVE ? 1 : 0;
     const int fast = (ix->pq_M % 16 == 0 && ix->sim != 2) ? 1 : 0;
-    if (filt) return (pqp_kernel_t)jvk_pqpf_kernel(fast, pqp_capk(cap), pqp_nch_slot(ix), lutr && jvk_pqp_lutr_ok(ix, cap));
+    if (filt) return (pqp_kernel_t)jvk_pqpf_kernel(fast, pqp_capk(cap), pqp_nch_slot(ix), lutr && jvk_pqpf_lutr_ok(ix, cap));
     if (lutr && jvk_pqp_lutr_ok(ix, cap)) return g_pqv_kernels[pqp_capk(cap)][pqp_nch_slot(ix)];
     return g_pqp_kernels[fast * 2 + multi][pqp_capk(cap)][pqp_nch_slot(ix)];
 }
@@ -71,6 +75,7 @@ extern "C" hipError_t jvk_pqp_set_max_lds(int bytes) {
 }
 
 extern "C" int jvk_pqp_max_entries(void) { return 4096; }
+extern "C" int jvk_pqp_max_entries_filtered(void) { return 8192; }
 
 // resident workgroups per CU for this index shape, pool capacity and LDS size
 extern "C" int jvk_pqp_blocks_per_cu(const JvIndexDev* ix, int cap, int lds_bytes, int lutr, int filt) {

@@ -62,7 +62,7 @@ __device__ __forceinline__ int rank_level(const int64_t* pool, int lo, int last,
 // NCHT: row length in 64-float chunks known at compile time (rerank), 0 = any d
 // NP:   fused-block passes (1: R * lanes-per-node <= 64; 4: up to 4 passes)
 // FAST: pq_M % 16 == 0 and not cosine (only the unmasked look-up is compiled)
-// CAPK: pool capacity class: 0 -> <= 512 entries, 1 -> <= 1 024, 2 -> <= 2 048, 3 -> <= 4 096
+// CAPK: pool capacity class: 0 -> <= 512 entries, 1 -> <= 1 024, 2 -> <= 2 048, 3 -> <= 4 096, 4 -> <= 8 192 (filtered instances only)
 // LUTR: the look-up table lives in REGISTERS (PQ-32, FAST, single pass only): lutr[m][e], lane l = lut[m][4 l + e]; a
 //       look-up is ds_bpermute (lane = code >> 2) of the four e-registers + a bit-select by code & 3.  Costs ~3x the
 //       instructions of an LDS gather, but LDS then only holds the pool: 8 resident queries per CU (two waves per SIMD
@@ -85,6 +85,7 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
     float* o_scores = a.out_scores + (size_t)qi * topK;
     const uint64_t* const accw = FILT ? a.accept + (size_t)qi * (size_t)a.accept_stride : nullptr;
     auto accepts = [&](int node) -> bool {  // the reference's acceptOrds lambda
+        if (a.accept_ord) return (a.accept_ord[node >> 6] >> (node & 63)) & 1ull;  // (batch-wide filter, translated by the host's pre-pass)
         const int doc = ix.ord2doc ? ix.ord2doc[node] : node;
         return doc >= 0 && (int64_t)doc < a.accept_docs && ((accw[doc >> 6] >> (doc & 63)) & 1ull);
     };
@@ -355,6 +356,11 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
             }
         }
         STAMP(0)  // find + pool reads
+        // FILT: the neighbours' accept bits are requested BEFORE the runner-up's block — vmcnt retires in order, so a wait for
+        // an accept word issued behind the prefetch would drain the prefetch on every expansion
+        bool accn = true;
+        if (FILT) accn = nnp[0] >= 0 && my_c == 0 ? accepts(nnp[0]) : false;
+        if (FILT) __builtin_amdgcn_sched_barrier(0);
         // start the runner-up's fetch now, UNCONDITIONALLY (clamped indices): a fixed number of younger loads lets the
         // wait for this expansion's block leave them in flight
         pf_node = c2;
@@ -388,9 +394,6 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
         nexp++;
         lo_un = idx + 1;
         STAMP(1)
-        // FILT: the neighbours' accept bits (ord -> doc -> bitset word, two dependent loads) are requested before the ADC
-        bool accn = true;
-        if (FILT) accn = nnp[0] >= 0 && my_c == 0 ? accepts(nnp[0]) : false;
         // ---- ADC of all R stored neighbours; pass ps delivers its scores to the lanes whose chunk index is ps ----
         float score = 0.0f;
         int nn = -1;
@@ -418,10 +421,12 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
         int rold;
         {
             int lo = 0;
+            if (CAPK == 4) lo = rank_level<1024, 8>(pool, lo, cap, v);
             if (CAPK == 3) lo = rank_level<512, 8>(pool, lo, cap, v);
             if (CAPK == 2) lo = rank_level<512, 4>(pool, lo, cap, v);
             if (CAPK == 1) lo = rank_level<256, 4>(pool, lo, cap, v);
             if (CAPK == 1) lo = rank_level<64, 4>(pool, lo, cap, v);
+            else if (CAPK == 4) lo = rank_level<64, 16>(pool, lo, cap, v);
             else lo = rank_level<64, 8>(pool, lo, cap, v);
             lo = rank_level<8, 8>(pool, lo, cap, v);
             int64_t p3[9];
@@ -448,7 +453,18 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
             if (nk == 1) {
                 // the common case: one new key, no ranks among new keys, every entry behind it moves up by one
                 r_min = r_max = __builtin_amdgcn_readlane(rold, __ffsll((long long)km) - 1);
-                for (int t = (np - 1) >> 6; t >= (r_min >> 6); t--) {
+                int t = (np - 1) >> 6;
+                // (four chunks per round trip while whole chunks move: the reads of a batch are issued together — a wide
+                //  filtered pool shifts ~50 chunks per expansion and one dependent LDS round trip per chunk was its cost)
+                for (; t - 3 > (r_min >> 6); t -= 4) {
+                    const int pos = (t << 6) + lane;
+                    const int64_t e0 = pool[min(pos, cap)], e1 = pool[pos - 64], e2 = pool[pos - 128], e3 = pool[pos - 192];
+                    if (pos < np) pool[pos + 1] = e0;
+                    pool[pos - 63] = e1;
+                    pool[pos - 127] = e2;
+                    pool[pos - 191] = e3;
+                }
+                for (; t >= (r_min >> 6); t--) {
                     const int pos = (t << 6) + lane;
                     const int64_t e = pool[min(pos, cap)];
                     if (pos < np && pos >= r_min) pool[pos + 1] = e;
@@ -484,22 +500,35 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
                 // in-place shift, from the last occupied chunk down to the chunk of the first insertion point: an old
                 // entry at position p moves up by the number of new keys that rank ahead of it
                 const int t_mixed = r_max >> 6;  // chunks above it shift uniformly by nk
-                for (int t = (np - 1) >> 6; t >= (r_min >> 6); t--) {
+                // new keys ranked at or before a chunk's first position move the whole chunk; the (few) ranked inside it move
+                // the entries at or behind them — two ballots and a short scalar loop, no LDS round trip
+                auto moved_by = [&](int tt, int pos) -> int {
+                    if (tt > t_mixed) return nk;
+                    const int cs0 = tt << 6;
+                    int cnt = __popcll(__ballot(keep && rold <= cs0));
+                    unsigned long long inm = __ballot(keep && rold > cs0 && rold <= cs0 + 63);
+                    while (inm) {
+                        const int j = __ffsll((long long)inm) - 1;
+                        inm &= inm - 1ull;
+                        cnt += pos >= __builtin_amdgcn_readlane(rold, j) ? 1 : 0;
+                    }
+                    return cnt;
+                };
+                int t = (np - 1) >> 6;
+                // four chunks per LDS round trip (all reads of a batch before its writes; destinations only move up)
+                for (; t - 3 >= (r_min >> 6); t -= 4) {
+                    const int pos = (t << 6) + lane;
+                    const int64_t e0 = pool[min(pos, cap)], e1 = pool[pos - 64], e2 = pool[pos - 128], e3 = pool[pos - 192];
+                    const int c0 = moved_by(t, pos), c1 = moved_by(t - 1, pos - 64), c2 = moved_by(t - 2, pos - 128), c3 = moved_by(t - 3, pos - 192);
+                    if (pos < np && c0 > 0) pool[pos + c0] = e0;
+                    if (c1 > 0) pool[pos - 64 + c1] = e1;
+                    if (c2 > 0) pool[pos - 128 + c2] = e2;
+                    if (c3 > 0) pool[pos - 192 + c3] = e3;
+                }
+                for (; t >= (r_min >> 6); t--) {
                     const int pos = (t << 6) + lane;
                     const int64_t e = pool[min(pos, cap)];
-                    int cnt = nk;
-                    if (t <= t_mixed) {
-                        // new keys ranked at or before the chunk's first position move the whole chunk; the (few) ranked inside
-                        // it move the entries at or behind them — two ballots and a short scalar loop, no LDS round trip
-                        const int cs0 = t << 6;
-                        cnt = __popcll(__ballot(keep && rold <= cs0));
-                        unsigned long long inm = __ballot(keep && rold > cs0 && rold <= cs0 + 63);
-                        while (inm) {
-                            const int j = __ffsll((long long)inm) - 1;
-                            inm &= inm - 1ull;
-                            cnt += pos >= __builtin_amdgcn_readlane(rold, j) ? 1 : 0;
-                        }
-                    }
+                    const int cnt = moved_by(t, pos);
                     if (pos < np && cnt > 0) pool[pos + cnt] = e;
                 }
             }
@@ -638,9 +667,17 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
         np -= carry;
     }
 
-    // LUTR: the pool moves to registers so that the whole LDS allocation can serve as the visited-count hash set
+    // LUTR: the pool moves to registers so that the whole LDS allocation can serve as the visited-count hash set.  Capacity
+    // classes 3 and 4 (filtered instances; up to 8 192 entries do not fit the registers): the pool STAYS — by now it only holds
+    // the result queue (~rerankK entries) — and the hash set, then the rerank scratch, take the LDS behind it.
+    constexpr bool STAY = LUTR && CAPK >= 3;
+    const int free_off = STAY ? ((a.pqp_pool_off + (np + 1) * 8 + 15) & ~15) : 0;
+    if (STAY && why == 0) {
+        const int rerank_need = ix.nch * 64 * 4 + JV_TODO * 8 + ((rk + 1) & ~1) * 8;
+        if (a.pqp_lds_bytes - free_off < (rerank_need > 4096 ? rerank_need : 4096)) why = 4;  // (a boundary tie storm: next rung)
+    }
     i32x32 PL, PH;
-    if (LUTR && why == 0) {
+    if (LUTR && !STAY && why == 0) {
 #pragma unroll
         for (int t = 0; t < 32; t++) {
             PL[t] = 0;
@@ -658,8 +695,8 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
         // ---- jvector's visitedCount: distinct neighbours of the expanded nodes, entry point excluded.  The hash set
         // lives where the LUT was; node ids are split into `parts` hash classes counted one after the other when one
         // table cannot hold them all (adjacency rows are re-read once per class). ----
-        uint32_t* vh = (uint32_t*)smem;
-        const int hash_bytes = LUTR ? a.pqp_lds_bytes : lut_bytes;
+        uint32_t* vh = (uint32_t*)(smem + free_off);
+        const int hash_bytes = LUTR ? a.pqp_lds_bytes - free_off : lut_bytes;
         int vslots = 1;
         while (vslots * 2 * 4 <= hash_bytes) vslots <<= 1;
         const uint32_t vmask = (uint32_t)vslots - 1u;
@@ -791,15 +828,15 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
     }
     const int nres = np < rk ? np : rk;
     // ---- rerank scratch (where the LUT / the hash set was): query, todo lists, exact keys ----
-    float* q_lds = (float*)smem;
-    size_t roff = (size_t)ix.nch * 64 * sizeof(float);
+    float* q_lds = (float*)(smem + free_off);
+    size_t roff = (size_t)free_off + (size_t)ix.nch * 64 * sizeof(float);
     float* todo_score = (float*)(smem + roff);
     roff += JV_TODO * sizeof(float);
     int32_t* todo = (int32_t*)(smem + roff);
     roff += JV_TODO * sizeof(int32_t);
     int64_t* fin = (int64_t*)(smem + roff);  // [rk]
     const int64_t* rpool = pool;
-    if (LUTR && why == 0) {
+    if (LUTR && !STAY && why == 0) {
         // the pool returns from the registers; the exact keys overwrite it in place (entry i is written only after
         // the 64-entry batch containing position i has been read)
         int64_t* wp = (int64_t*)(smem + roff);

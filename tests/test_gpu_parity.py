@@ -547,6 +547,31 @@ def test_filtered_persistent_kernel_parity(pkg, pyoracle, small_sets, sim):
         gpu.close()
 
 
+def test_filtered_wide_pool_rung_parity(pkg, pyoracle, small_sets):
+    """Selective filters at wide beams: pools of 4 097 .. 8 192 entries (selectivity ~0.2 at rerankK 1 000 - 1 200) are
+    answered by the third filtered launch (capacity class 4, one workgroup per CU) and must not reach the HBM-scratch rung."""
+    b, bl = pkg.binding, pkg.builder
+    rng = np.random.default_rng(91)
+    n, d = 24000, 64
+    centers = rng.standard_normal((64, d)).astype(np.float32)
+    base = (centers[rng.integers(0, 64, n)] + 0.6 * rng.standard_normal((n, d))).astype(np.float32)
+    q = (centers[rng.integers(0, 64, 32)] + 0.6 * rng.standard_normal((32, d))).astype(np.float32)
+    for pq_M in (16, 32):
+        ix = bl.build_index_cpu(base, 0, R=32, L=80, pq_M=pq_M)
+        gpu = b.GpuIndex(ix, flags=b.DESC_FUSED_ADC)
+        gpu.set_option("lutr_min_queries", 0)
+        orc = pyoracle.Oracle(b, ix)
+        for frac, k, rk in ((0.2, 10, 1000), (0.18, 10, 1200), (0.25, 20, 1200), (0.12, 10, 700)):
+            words = b.accept_words(np.nonzero(rng.random(n) < frac)[0], n)
+            want = orc.search_batch(q, k, rk, accept=words, accept_num_docs=n)
+            got, _, flags, rc = gpu.search_batch_ex(q, k, rk, accept=words, accept_num_docs=n)
+            assert rc == 0
+            _assert_same(got, want, f"M={pq_M} frac={frac} k={k} rk={rk}")
+            big = int((np.asarray(flags).astype(np.uint32) & 1).sum())
+            assert big <= 2, f"M={pq_M} frac={frac} rk={rk}: {big} of {len(q)} queries fell to the HBM-scratch rung"
+        gpu.close()
+
+
 @pytest.mark.parametrize("seed", [21, 22])
 def test_filtered_tie_storm_parity(pkg, pyoracle, seed):
     """Grid-valued vectors (every comparison is a tie) + doc filters on the fused-PQ path: strict admission into a

@@ -30,12 +30,19 @@ for fused in (1,):
     o = [torch.empty((B, 10), dtype=torch.int32, device=dev), torch.empty((B, 10), dtype=torch.int32, device=dev),
          torch.empty((B, 10), dtype=torch.float32, device=dev), torch.empty((B,), dtype=torch.int32, device=dev),
          torch.empty((B, 4), dtype=torch.int32, device=dev), torch.empty((B,), dtype=torch.int32, device=dev)]
+    acc_ptr = 0
+    if os.environ.get("SEL"):   # shared doc filter of this selectivity
+        bits = np.random.default_rng(5).random(n) < float(os.environ["SEL"])
+        words = np.packbits(bits, bitorder="little")
+        words = np.concatenate([words, np.zeros((-len(words)) % 8, np.uint8)]).view(np.uint64)
+        acc = torch.from_numpy(words.view(np.int64)).to(dev)
+        acc_ptr = acc.data_ptr()
     for it in range(2):
         dbg.zero_()
         ix.set_option("dbg_ptr", dbg.data_ptr())
         torch.cuda.synchronize(); t = time.time()
         ix.search_batch_device(q.data_ptr(), B, 10, rk, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(),
-                               o[4].data_ptr(), o[5].data_ptr())
+                               o[4].data_ptr(), o[5].data_ptr(), d_accept=acc_ptr, accept_num_docs=(n if acc_ptr else 0))
         torch.cuda.synchronize(); dt = time.time() - t
     ix.set_option("dbg_ptr", 0)
     v = dbg.cpu().numpy().astype(np.float64)
