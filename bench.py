@@ -242,7 +242,8 @@ class Engine:
         pq = None
         if builder_kind == "gpu":
             gbuild = importlib.import_module("opensearch_jvector_amd.builder_gpu")
-            adj_t, entry = gbuild.build_graph_gpu(torch, base, sim, R=R, L=L, alpha=1.2, device_index=local_rank)
+            adj_t, entry = gbuild.build_graph_gpu(torch, base, sim, R=R, L=L, alpha=1.2, device_index=local_rank,
+                                                  refine_passes=int(os.environ.get("JV_BENCH_REFINE", "0")))
             if pq_M:
                 pq = gbuild.pq_train_encode_gpu(torch, base, pq_M, sim)
         else:

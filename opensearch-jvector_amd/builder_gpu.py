@@ -172,8 +172,13 @@ def approx_medoid(torch, base, sim):
 
 
 def build_graph_gpu(torch, base, sim, R=32, L=100, alpha=1.2, overflow=1.2, device_index=0, max_batch=16384,
-                    search_fn=None, verbose=True):
-    """Returns (adj [n][R] int32 tensor on base.device, entry_node)."""
+                    search_fn=None, verbose=True, refine_passes=0):
+    """Returns (adj [n][R] int32 tensor on base.device, entry_node).
+
+    refine_passes > 0: after the batched insertion every node is searched for AGAIN on the finished graph and its row is
+    re-selected from (search result + current row), back-links included — what jvector's sequential addGraphNode gets for
+    free (every insert sees all earlier ones; a batch's members do not see each other) plus its cleanup()
+    (J/JVectorWriter.java:1383-1422).  One pass restores the reference's KA15 recall floor (tests/test_gpu_builder.py)."""
     n, d = base.shape
     dev = base.device
     assert d % 4 == 0, "GPU builder needs 16-B aligned rows (d % 4 == 0)"
@@ -224,6 +229,20 @@ def build_graph_gpu(torch, base, sim, R=32, L=100, alpha=1.2, overflow=1.2, devi
         if verbose and (it % 50 == 0 or pos >= n):
             torch.cuda.synchronize() if dev.type == "cuda" else None
             print(f"[builder_gpu] inserted {pos}/{n} ({time.time() - t0:.1f}s)", file=sys.stderr, flush=True)
+    for rp in range(refine_passes):
+        for s in range(0, n, max_batch):
+            u = torch.arange(s, min(n, s + max_batch), device=dev, dtype=torch.int64)
+            B = int(u.numel())
+            cand = search_fn(base[u].contiguous(), B)
+            both = torch.cat([cand, adj[u]], dim=1)
+            sel, nsel = robust_prune(torch, base, u, both, R, alpha, sim)
+            adj[u, :R] = sel
+            adj[u, R:] = -1
+            deg[u] = nsel
+            _add_backlinks(torch, base, adj, deg, u, sel, R, Rcap, alpha, sim)
+        if verbose:
+            torch.cuda.synchronize() if dev.type == "cuda" else None
+            print(f"[builder_gpu] refine pass {rp + 1}/{refine_passes} done ({time.time() - t0:.1f}s)", file=sys.stderr, flush=True)
     # cleanup: every row down to R
     over = torch.nonzero(deg > R).squeeze(1)
     ch = 8192

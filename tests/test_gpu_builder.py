@@ -98,21 +98,49 @@ def test_pq_training_is_lloyd_and_improves_on_its_start(pkg, d, M, sim):
 
 def test_ka15_recall_floor_through_the_gpu_builder(pkg, pyoracle):
     """KA15 (JVectorWriterMergeTests.java:55,78-92,122-123,178-212): base = java.util.Random(42) floats, queries =
-    Random(43), d = 128, k = 10, L2: recall >= 0.99 against brute force at over-query 5 and 20 — graph from the GPU builder,
-    search through the C ABI."""
+    Random(43), d = 128, k = 10, L2, recall against brute force on the reference's 10 queries — graph from the GPU builder
+    (insertion + one refine pass), search through the C ABI.  Floors = the reference's own: 1.0 at the default over-query
+    factor 5 for its 100 / 300 / 601-vector scenarios (:246-268), and at over-query 20 for its ~1 500-vector scenario
+    (:276-286, "can't achieve 1.0 recall otherwise"); at 1 500 vectors / over-query 5 the 0.99 the scenario default asks."""
     torch, gb = _gb()
     b = pkg.binding
     dev = torch.device("cuda", 0)
-    for n in (500, 1500):   # (the reference's merge scenarios hold 100 .. 1 500 vectors)
+    for n in (100, 300, 601, 1500):
         base = pkg.datagen.java_random_vectors(42, n, 128)
         q = pkg.datagen.java_random_vectors(43, 10, 128)
-        adj, entry = gb.build_graph_gpu(torch, torch.from_numpy(base).to(dev), 0, R=32, L=100, verbose=False)
+        adj, entry = gb.build_graph_gpu(torch, torch.from_numpy(base).to(dev), 0, R=32, L=100, verbose=False, refine_passes=1)
         ix = b.IndexData(vectors=base, adj=adj.cpu().numpy(), entry_node=entry, similarity=0)
         gpu = b.GpuIndex(ix)
         truth, _ = pyoracle.Oracle(b, ix).brute_force(q, 10)
         for oqf in (5, 20):
             got = gpu.search_batch(q, 10, 10 * oqf)
             rec = np.mean([len(set(got.nodes[i]) & set(truth[i])) / 10 for i in range(10)])
-            # the reference's floor (0.99) at its own sizes / over-query factors; beyond them this builder's own floor
-            assert rec >= (0.99 if (n <= 500 or oqf == 20) else 0.95), (n, oqf, rec)
+            assert rec >= (0.99 if (n == 1500 and oqf == 5) else 1.0), (n, oqf, rec)
         gpu.close()
+
+
+def test_gpu_builder_matches_sequential_insertion_quality(pkg):
+    """The batched GPU build + one refine pass against SEQUENTIAL insertion (libjvbuild.so: every insert sees all earlier
+    ones, like jvector's addGraphNode, J/JVectorWriter.java:1383-1422) on the KA15 data at 20 000 vectors, 200 queries: the
+    same recall@10 within 0.02 at over-query 5 and 20.  (Uniform 128-d noise is hard for ANY degree-32 graph at this size:
+    both builders sit near 0.62 / 0.91 — which is why the reference's scenarios stop at ~3 000 vectors.)"""
+    torch, gb = _gb()
+    b, bl = pkg.binding, pkg.builder
+    dev = torch.device("cuda", 0)
+    n, nq = 20000, 200
+    base = pkg.datagen.java_random_vectors(42, n, 128)
+    q = pkg.datagen.java_random_vectors(43, nq, 128)
+    bt, qt = torch.from_numpy(base).to(dev), torch.from_numpy(q).to(dev)
+    d2 = (qt * qt).sum(1)[:, None] + (bt * bt).sum(1)[None, :] - 2 * qt @ bt.T
+    truth = torch.topk(-d2, 10, dim=1).indices.cpu().numpy()
+    recs = {}
+    adj, entry = gb.build_graph_gpu(torch, bt, 0, R=32, L=100, verbose=False, refine_passes=1)
+    for name, ix in (("gpu", b.IndexData(vectors=base, adj=adj.cpu().numpy(), entry_node=entry, similarity=0)),
+                     ("sequential", bl.build_index_cpu(base, 0, R=32, L=100))):
+        gpu = b.GpuIndex(ix)
+        for oqf in (5, 20):
+            got = gpu.search_batch(q, 10, 10 * oqf)
+            recs[name, oqf] = float(np.mean([len(set(got.nodes[i]) & set(truth[i])) / 10 for i in range(nq)]))
+        gpu.close()
+    for oqf in (5, 20):
+        assert recs["gpu", oqf] >= recs["sequential", oqf] - 0.02, recs

@@ -528,7 +528,7 @@ def test_filtered_persistent_kernel_parity(pkg, pyoracle, small_sets, sim):
         # cosine) even for this small batch — the routing of launches with more than 4 x CUs queries
         gpu.set_option("lutr_min_queries", 0)
         orc = pyoracle.Oracle(b, ix)
-        for frac in (0.95, 0.6, 0.3, 0.1):
+        for frac in (0.95, 0.6, 0.3, 0.1, 0.05):
             words = b.accept_words(np.nonzero(rng.random(max_doc) < frac)[0], max_doc)
             for k, rk in ((3, 3), (10, 50), (10, 160), (10, 200), (20, 400), (10, 1000)):
                 want = orc.search_batch(q, k, rk, accept=words, accept_num_docs=max_doc)
