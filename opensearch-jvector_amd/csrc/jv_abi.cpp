@@ -184,7 +184,7 @@ struct Ctx {
     uint8_t* h_direct = nullptr;
     size_t direct_cap = 0;
     hipEvent_t ev_direct = nullptr;
-    int32_t* work_counter = nullptr;  // [0] big-path dequeue, [1] spill-table allocator, [2..] rung counters
+    int32_t* work_counter = nullptr;  // 16 words: [0] big-path dequeue, [1] spill-table allocator, [2..7] rung counters, [8..15] filtered pool rungs
     // pool of visited-set spill tables of the generic kernels (allocated on the first launch that can use it)
     uint32_t* spill = nullptr;
     int spill_tables = 0, spill_slots = 0;
@@ -320,7 +320,7 @@ int ctx_create(jv_index* ix, Ctx** out) {
     Ctx* c = new Ctx();
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->last_use, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipMalloc((void**)&c->work_counter, 8 * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&c->work_counter, 16 * sizeof(int32_t));
     if (e != hipSuccess) {
         delete c;
         return fail(JV_EDEVICE, "context creation failed: %s", hipGetErrorString(e));
@@ -562,7 +562,7 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
     a.retry_counter = c->work_counter + 2;
     a.dbg = (int64_t*)(uintptr_t)OPT(ix, OPT_DBG_PTR);  // always 0 unless a diagnostic run set it
     const bool force_big = OPT(ix, OPT_FORCE_BIG) != 0 || !g.fast_ok;
-    HIPCHK(hipMemsetAsync(c->work_counter, 0, 8 * sizeof(int32_t), stream));
+    HIPCHK(hipMemsetAsync(c->work_counter, 0, 16 * sizeof(int32_t), stream));
     if (phase != 2) {
     // headline path: PQ + fused layout + single pool + flat graph -> specialised kernel without an in-loop
     // visited set (jv_kernels.hip "PQF"); anything it cannot hold is flagged and falls through to the ladder
@@ -683,18 +683,50 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
             // (unfiltered: a handful of flagged queries; filtered: a selective filter sends the whole batch here)
             const int per_cu2 = filtered && second ? jvk_pqp_blocks_per_cu(&ix->dev, ap2.cand_cap, lds2, lutr2, 1) : 1;
             const int blocks2 = std::min(ix->cu_count * per_cu2, (nq + 7) / 8);
-            // third launch (filtered only): pools of up to 8 192 entries — a filter of selectivity ~0.2 at rerankK 1 200 —
-            // stay on chip (64 KB pool + 32 KB table: one workgroup per CU) instead of falling to the HBM-scratch rung
-            JvSearchArgs ap3 = ap2;
-            ap3.cand_cap = jvk_pqp_max_entries_filtered();
-            ap3.pqp_log_cap = 3 * ap3.cand_cap;
-            ap3.retry_counter = c->work_counter + 3;
-            const int lds3 = filtered ? plan(ap3, lutr2 != 0) : 0;
-            const bool third = filtered && second && lds3 <= kMaxLds && ap3.cand_cap > ap2.cand_cap;
-            const int blocks3 = third ? std::min(ix->cu_count * jvk_pqp_blocks_per_cu(&ix->dev, ap3.cand_cap, lds3, lutr2, 1), (nq + 7) / 8) : 0;
+            // Filtered searches: a pool of ~ rerankK / selectivity entries.  What a launch costs is decided by how many of its
+            // queries a CU keeps resident, and that is LDS / (pool bytes + fixed part).  Behind the second launch (twice the
+            // first's pool) the rungs are therefore the LARGEST pools that still fit 4, 3, 2 (, 1) workgroups per CU — each
+            // query runs on the first rung its estimated pool fits (the kernel's selectivity estimate skips the others at
+            // once), e.g. selectivity 0.2 at rerankK 1 200 with three resident queries per CU instead of the 8 192-entry
+            // rung's two.  (More than 4 per CU is not offered: the visited-count hash set lives in what LDS the final
+            // compaction frees, and pools that small leave it too few slots — measured slower; and the wide-pool instances
+            // are compiled for one wave per SIMD so that nothing spills to scratch.)
+            struct Rung { JvSearchArgs a; int lds, blocks; };
+            Rung rungs[8];
+            int nrungs = 0;
+            if (filtered && second) {
+                Rung r0;
+                r0.a = ap2;
+                r0.lds = lds2;
+                r0.blocks = std::min(ix->cu_count * per_cu2, (nq + 1) / 2);
+                rungs[nrungs++] = r0;
+                JvSearchArgs probe = ap2;
+                probe.cand_cap = 4096;
+                const int fixed = plan(probe, lutr2 != 0) - 4097 * 8;  // LDS bytes besides the pool (class 3 / 4 layout)
+                int prev = ap2.cand_cap;
+                for (int per = 4; per >= 1 && nrungs < 8; per--) {  // (these instances take 512 registers: one wave per SIMD)
+                    // (measured with tools/lds_residency.hip: workgroups of 7 x 23 040 B and 3 x 53 248 B are resident together on a
+                    //  gfx950 CU, 5 x 32 768 B, 10 x 16 384 B and 3 x 54 528 B are NOT although the occupancy API says so: what
+                    //  several workgroups can share is a little less than 160 KB — budget 157.5 KB)
+                    const int share = ((161280 / per) & ~255);
+                    int cap = std::min(((share - fixed) / 8 - 1) & ~63, jvk_pqp_max_entries_filtered());
+                    if (cap < prev + 512 || cap < rk + 64 + ix->dev.R) continue;  // (not worth a launch of its own)
+                    Rung r;
+                    r.a = ap2;
+                    r.a.cand_cap = cap;
+                    r.lds = plan(r.a, lutr2 != 0);
+                    if (r.lds > kMaxLds) continue;
+                    r.a.pqp_log_cap = 3 * cap;
+                    r.a.retry_counter = c->work_counter + 8 + nrungs;
+                    r.blocks = std::min(ix->cu_count * std::min(per, jvk_pqp_blocks_per_cu(&ix->dev, cap, r.lds, lutr2, 1)), (nq + 1) / 2);
+                    rungs[nrungs++] = r;
+                    prev = cap;
+                    if (cap >= jvk_pqp_max_entries_filtered()) break;
+                }
+            }
             size_t need = (size_t)blocks * (size_t)ap.pqp_log_cap;
-            if (second) need = std::max(need, (size_t)blocks2 * (size_t)ap2.pqp_log_cap);
-            if (third) need = std::max(need, (size_t)blocks3 * (size_t)ap3.pqp_log_cap);
+            if (second && nrungs == 0) need = std::max(need, (size_t)blocks2 * (size_t)ap2.pqp_log_cap);
+            for (int i = 0; i < nrungs; i++) need = std::max(need, (size_t)rungs[i].blocks * (size_t)rungs[i].a.pqp_log_cap);
             if (need > c->pqp_log_ints) {
                 if (c->pqp_log) HIPCHK(jv_free(c->pqp_log));
                 c->pqp_log = nullptr;
@@ -707,13 +739,13 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
             if (pqw) HIPCHK(jvk_launch_search_pqw(&ix->dev, &ap, lds, blocks, pqw_variant, stream));
             else HIPCHK(jvk_launch_search_pqp(&ix->dev, &ap, lds, blocks, lutr, stream));
             ix->launches[pqw ? LAUNCH_PQW : LAUNCH_PQP]++;
-            if (second) {
+            if (second && nrungs == 0) {
                 ap2.pqp_log = c->pqp_log;
                 HIPCHK(jvk_launch_search_pqp(&ix->dev, &ap2, lds2, blocks2, lutr2, stream));
             }
-            if (third) {
-                ap3.pqp_log = c->pqp_log;
-                HIPCHK(jvk_launch_search_pqp(&ix->dev, &ap3, lds3, blocks3, lutr2, stream));
+            for (int i = 0; i < nrungs; i++) {
+                rungs[i].a.pqp_log = c->pqp_log;
+                HIPCHK(jvk_launch_search_pqp(&ix->dev, &rungs[i].a, rungs[i].lds, rungs[i].blocks, lutr2, stream));
             }
             pqf = true;
         }

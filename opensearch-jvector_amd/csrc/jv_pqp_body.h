@@ -90,18 +90,21 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
         return doc >= 0 && (int64_t)doc < a.accept_docs && ((accw[doc >> 6] >> (doc & 63)) & 1ull);
     };
     if (FILT) {
-        // Rung choice only (never results): estimate the filter's selectivity from 64 sampled words; a pool of
-        // ~ rerankK / selectivity entries that cannot fit this launch's capacity is handed on right away instead of
-        // after a wasted search.
+        // Rung choice only (never results): estimate the filter's selectivity from 256 sampled words (16 384 bits: +-0.003 at
+        // selectivity 0.2 — the rungs are 20-30 % apart); a pool of ~ rerankK / selectivity entries that cannot fit this
+        // launch's capacity is handed on right away instead of after a wasted search.
         const int64_t nwords = (a.accept_docs + 63) >> 6;
         int bits = 0;
         if (nwords > 0) {
-            const uint64_t h = ((uint64_t)(lane + 1) * 0x9E3779B97F4A7C15ull) >> 20;
-            bits = __popcll(accw[nwords <= JV_WAVE ? (int64_t)(lane % (int)nwords) : (int64_t)(h % (uint64_t)nwords)]);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint64_t h = ((uint64_t)(u * JV_WAVE + lane + 1) * 0x9E3779B97F4A7C15ull) >> 20;
+                bits += __popcll(accw[nwords <= 4 * JV_WAVE ? (int64_t)((u * JV_WAVE + lane) % (int)nwords) : (int64_t)(h % (uint64_t)nwords)]);
+            }
         }
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) bits += __shfl_xor(bits, o, JV_WAVE);
-        const float sel = fmaxf((float)bits, 1.0f) * (1.0f / 4096.0f);
+        const float sel = fmaxf((float)bits, 1.0f) * (1.0f / 16384.0f);
         const float need = (float)rk / sel * 1.05f + 64.0f + (float)R;
         if (need > (float)a.cand_cap && a.cand_cap < 8 * rk + 256) {
             if (lane == 0) {
@@ -935,20 +938,24 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
 
 // Persistent grid: one workgroup per resident LDS slot, queries dequeued in order.
 template <int NCHT, int NP, bool FAST, int CAPK, bool LUTR = false, bool FILT = false>
-__global__ __launch_bounds__(JV_WAVE, LUTR ? 2 : 1) void jv_search_pqp_kernel(const JvIndexDev ix, const JvSearchArgs a) {
+__global__ __launch_bounds__(JV_WAVE, (LUTR && CAPK < 3) ? 2 : 1) void jv_search_pqp_kernel(const JvIndexDev ix, const JvSearchArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int32_t* explog = a.pqp_log + (size_t)blockIdx.x * (size_t)a.pqp_log_cap;
-    // second launch (a.retry_only: wider pool, longer log): only the queries the first one flagged, found 8 flags at a time
+    // later launches (a.retry_only: wider pool, longer log): only the queries an earlier one flagged, found up to 8 flags at a
+    // time.  (Unfiltered: a handful of 65 536 flags are set and a chunk rarely holds two.  Filtered: a whole batch can land on
+    // one rung with tens of milliseconds per query — chunks of 8 then left a third of the grid idle behind the last round, so
+    // the chunk shrinks with the number of flags per workgroup.)
+    const int chunk = max(1, min(8, a.nq / ((int)gridDim.x * 8)));
     int base = 0;
     unsigned long long todo = 0ull;
     for (;;) {
         int qi = 0;
         if (a.retry_only) {
             while (!todo) {
-                if (threadIdx.x == 0) base = atomicAdd(a.retry_counter, 8);  // (small chunks: two flagged queries rarely share one)
+                if (threadIdx.x == 0) base = atomicAdd(a.retry_counter, chunk);
                 base = __builtin_amdgcn_readfirstlane(base);
                 if (base >= a.nq) return;
-                const int qf = (threadIdx.x < 8 && base + (int)threadIdx.x < a.nq) ? a.out_flags[base + threadIdx.x] : 0;
+                const int qf = ((int)threadIdx.x < chunk && base + (int)threadIdx.x < a.nq) ? a.out_flags[base + threadIdx.x] : 0;
                 todo = __ballot(((uint32_t)qf & JV_FLAG_OVERFLOW) != 0);
             }
             qi = base + __ffsll((long long)todo) - 1;
