@@ -172,13 +172,16 @@ def approx_medoid(torch, base, sim):
 
 
 def build_graph_gpu(torch, base, sim, R=32, L=100, alpha=1.2, overflow=1.2, device_index=0, max_batch=16384,
-                    search_fn=None, verbose=True, refine_passes=0):
+                    search_fn=None, verbose=True, refine_passes=0, initial_adj=None, initial_entry=None):
     """Returns (adj [n][R] int32 tensor on base.device, entry_node).
 
     refine_passes > 0: after the batched insertion every node is searched for AGAIN on the finished graph and its row is
     re-selected from (search result + current row), back-links included — what jvector's sequential addGraphNode gets for
     free (every insert sees all earlier ones; a batch's members do not see each other) plus its cleanup()
-    (J/JVectorWriter.java:1383-1422).  One pass restores the reference's KA15 recall floor (tests/test_gpu_builder.py)."""
+    (J/JVectorWriter.java:1383-1422).  One pass restores the reference's KA15 recall floor (tests/test_gpu_builder.py).
+
+    initial_adj [n0][R] (+ initial_entry): rows 0..n0-1 of `base` already have a graph (a leading segment's,
+    merge_leading_segment_gpu); only rows n0.. are inserted, into it."""
     n, d = base.shape
     dev = base.device
     assert d % 4 == 0, "GPU builder needs 16-B aligned rows (d % 4 == 0)"
@@ -188,10 +191,18 @@ def build_graph_gpu(torch, base, sim, R=32, L=100, alpha=1.2, overflow=1.2, devi
     deg = torch.zeros((n,), dtype=torch.int32, device=dev)
     if n == 0:
         return adj[:, :R].contiguous(), -1
-    entry = approx_medoid(torch, base, sim)
     order = torch.arange(n, device=dev, dtype=torch.int64)
-    if entry != 0:
-        order[0], order[entry] = entry, 0
+    n0 = 1
+    if initial_adj is not None:
+        n0 = int(initial_adj.shape[0])
+        assert 0 < n0 <= n and initial_adj.shape[1] == R and initial_entry is not None and 0 <= initial_entry < n0
+        adj[:n0, :R] = initial_adj.to(device=dev, dtype=torch.int32)
+        deg[:n0] = (adj[:n0] >= 0).sum(1).to(torch.int32)
+        entry = int(initial_entry)
+    else:
+        entry = approx_medoid(torch, base, sim)
+        if entry != 0:
+            order[0], order[entry] = entry, 0
     index = None
     if search_fn is None:
         desc, keep = binding.make_desc_device(n, d, Rcap, base.data_ptr(), adj.data_ptr(), entry, sim,
@@ -212,7 +223,7 @@ def build_graph_gpu(torch, base, sim, R=32, L=100, alpha=1.2, overflow=1.2, devi
             return o_nodes[:B]
 
     t0 = time.time()
-    pos = 1
+    pos = n0
     it = 0
     while pos < n:
         B = min(max_batch, max(1, pos // 2), n - pos)
@@ -230,7 +241,7 @@ def build_graph_gpu(torch, base, sim, R=32, L=100, alpha=1.2, overflow=1.2, devi
             torch.cuda.synchronize() if dev.type == "cuda" else None
             print(f"[builder_gpu] inserted {pos}/{n} ({time.time() - t0:.1f}s)", file=sys.stderr, flush=True)
     for rp in range(refine_passes):
-        for s in range(0, n, max_batch):
+        for s in range(0 if initial_adj is None else n0, n, max_batch):  # (a merge refines what it inserted)
             u = torch.arange(s, min(n, s + max_batch), device=dev, dtype=torch.int64)
             B = int(u.numel())
             cand = search_fn(base[u].contiguous(), B)
@@ -257,6 +268,62 @@ def build_graph_gpu(torch, base, sim, R=32, L=100, alpha=1.2, overflow=1.2, devi
         torch.cuda.synchronize()
         index.close()
     return out, entry
+
+
+def merge_leading_segment_gpu(torch, base, lead_adj, lead_entry, lead_live, sim, R=32, L=100, alpha=1.2, refine_passes=1,
+                              max_repair_rows=4, **kw):
+    """Incremental merge into the LEADING segment's graph (J/JVectorWriter.java:1166-1341, tryLeadingSegmentMerge): instead
+    of rebuilding the merged field from scratch, the largest segment's graph is loaded, the other segments' live vectors are
+    inserted into it (addGraphNode), the leading segment's deleted nodes are removed (markNodeDeleted + cleanup: a live
+    node that pointed at a deleted one re-selects its row from its live neighbours and the deleted neighbours' live
+    neighbours), and the ordinals are compacted in order.
+
+    base [n][d]: rows 0..n0-1 = the leading segment's vectors in its ordinal order (deleted ones included: they stay
+    traversable until the cleanup, as in jvector), rows n0.. = the other segments' live vectors ("mid" ordinals).
+    lead_adj [n0][R], lead_entry, lead_live [n0] bool.
+    Returns (adj [n_live][R] int32, entry, final_to_mid [n_live] int64): compact, order-preserving "final" ordinals."""
+    dev = base.device
+    n = int(base.shape[0])
+    n0 = int(lead_adj.shape[0])
+    live = torch.ones((n,), dtype=torch.bool, device=dev)
+    live[:n0] = lead_live.to(device=dev, dtype=torch.bool)
+    adj, entry = build_graph_gpu(torch, base, sim, R=R, L=L, alpha=alpha, refine_passes=refine_passes,
+                                 initial_adj=lead_adj, initial_entry=lead_entry, **kw)
+    adj = adj.clone()
+    dead = ~live
+    if bool(dead.any()):
+        nb = adj.long().clamp_min(0)
+        nb_dead = (adj >= 0) & dead[nb]                                   # [n][R] edges into deleted nodes
+        touched = torch.nonzero(nb_dead.any(1) & live).squeeze(1)         # live nodes that lose a neighbour
+        for s in range(0, touched.numel(), 8192):
+            u = touched[s:s + 8192]
+            rows = adj[u]
+            rd = nb_dead[u]
+            # the first `max_repair_rows` deleted neighbours of every row lend their own rows as candidates
+            rank = torch.cumsum(rd.to(torch.int32), 1) - 1
+            extra = torch.full((u.numel(), max_repair_rows, R), -1, dtype=torch.int32, device=dev)
+            for k in range(max_repair_rows):
+                pick = rd & (rank == k)
+                has = pick.any(1)
+                src = (rows.long().clamp_min(0) * pick).sum(1)            # the k-th deleted neighbour (0 where none)
+                extra[:, k] = torch.where(has[:, None], adj[src], torch.full_like(adj[src], -1))
+            cand = torch.cat([rows, extra.reshape(u.numel(), -1)], 1)
+            cand = torch.where((cand >= 0) & live[cand.long().clamp_min(0)], cand, torch.full_like(cand, -1))
+            sel, _ = robust_prune(torch, base, u, cand, R, alpha, sim)
+            adj[u] = sel
+    final_to_mid = torch.nonzero(live).squeeze(1)
+    mid_to_final = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    mid_to_final[final_to_mid] = torch.arange(final_to_mid.numel(), dtype=torch.int32, device=dev)
+    out = adj[final_to_mid]
+    out = torch.where(out >= 0, mid_to_final[out.long().clamp_min(0)], out)
+    # (rows keep jvector's "no holes" form: valid neighbours first)
+    order = torch.argsort((out < 0).to(torch.int8), dim=1, stable=True)
+    out = torch.gather(out, 1, order).contiguous()
+    if not bool(live[entry]):
+        entry_mid = int(final_to_mid[approx_medoid(torch, base[final_to_mid], sim)])
+    else:
+        entry_mid = entry
+    return out, int(mid_to_final[entry_mid]), final_to_mid
 
 
 def _add_backlinks(torch, base, adj, deg, u, sel, R, Rcap, alpha, sim):
