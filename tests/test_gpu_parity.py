@@ -428,7 +428,9 @@ def test_combined_single_query_calls_match_oracle(pkg, pyoracle):
     accept[::2] = np.uint64(0xFFFFFFFFFFFFFFFF)
     accept_b = np.full_like(accept, np.uint64(0x0F0F0F0F0F0F0F0F))   # a different filter, batched with the first one
     params = [(5, 20, 0.0, 0.0, None), (10, 40, 0.0, 0.0, None), (5, 20, 0.0, 0.55, None), (3, 3, 0.0, 0.0, None),
-              (5, 25, 0.0, 0.0, accept), (5, 25, 0.0, 0.0, accept_b)]
+              (5, 25, 0.0, 0.0, accept), (5, 25, 0.0, 0.0, accept_b),
+              # wide beams: the persistent pool kernel's filtered instances with every query's OWN filter in one launch
+              (10, 300, 0.0, 0.0, accept), (10, 300, 0.0, 0.0, accept_b)]
     want = [orc.search_batch(queries, k, rk, threshold=th, rerank_floor=fl, accept=acc, accept_num_docs=(4000 if acc is not None else 0))
             for k, rk, th, fl, acc in params]
     for flags, combine in ((b.DESC_FUSED_ADC, 1), (0, 1), (b.DESC_FUSED_ADC, 0)):
@@ -538,6 +540,10 @@ def test_filtered_persistent_kernel_parity(pkg, pyoracle, small_sets, sim):
         want = orc.search_batch(q, 10, 300, rerank_floor=0.6, accept=words, accept_num_docs=max_doc)
         got = gpu.search_batch(q, 10, 300, rerank_floor=0.6, accept=words, accept_num_docs=max_doc)
         _assert_same(got, want, f"sim={sim} M={pq_M} filter + rerankFloor")
+        # a batch too small for the ordinal-space pre-pass: the accept bit is read through ord2doc (two dependent loads)
+        want = orc.search_batch(q[:5], 10, 400, accept=words, accept_num_docs=max_doc)
+        got = gpu.search_batch(q[:5], 10, 400, accept=words, accept_num_docs=max_doc)
+        _assert_same(got, want, f"sim={sim} M={pq_M} small filtered batch")
         # the answers above must come from the persistent kernel itself, not from the ladder behind it: with the ladder
         # switched off a mild filter still answers (nearly) every query
         gpu.set_option("pqf_only", 1)
