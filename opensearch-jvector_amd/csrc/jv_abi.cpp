@@ -723,6 +723,7 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
                     prev = cap;
                     if (cap >= jvk_pqp_max_entries_filtered()) break;
                 }
+                rungs[nrungs - 1].a.retry_only = 2;  // the last on-chip rung never skips on the selectivity estimate
             }
             size_t need = (size_t)blocks * (size_t)ap.pqp_log_cap;
             if (second && nrungs == 0) need = std::max(need, (size_t)blocks2 * (size_t)ap2.pqp_log_cap);

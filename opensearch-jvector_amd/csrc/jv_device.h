@@ -74,7 +74,7 @@ struct JvSearchArgs {
     int32_t big_cand_cap;
     int32_t* work_counter;   // big path: dynamic query dequeue
     int32_t visit_limit;     // > 0: stop (flag EARLY) once visited + expanded reaches it (Lucene KnnCollector.visitLimit)
-    int32_t retry_only;      // filtered PQF kernel: 1 = walk the flag array and redo pool/log overflows only
+    int32_t retry_only;      // later launches: 1 = walk the flag array and redo pool/log overflows only; 2 = the same, last on-chip rung (filtered: never skips on the selectivity estimate)
     int32_t* retry_counter;  // escalation launches: flag-chunk dequeue counter (zeroed per call, one per rung)
     // two-level visited set: pool of per-query spill tables in HBM (taken with spill_counter)
     uint32_t* spill;

@@ -39,14 +39,14 @@ static int pqp_nch_slot(const JvIndexDev* ix) {
     if (ix->stride != ix->nch * 64) return 0;
     return ix->nch == 2 ? 1 : ix->nch == 12 ? 2 : ix->nch == 24 ? 3 : 0;
 }
-static int pqp_capk(int cap) { return cap <= 512 ? 0 : cap <= 1024 ? 1 : cap <= 2048 ? 2 : cap <= 4096 ? 3 : 4; }  // (4: filtered instances only)
+static int pqp_capk(int cap) { return cap <= 512 ? 0 : cap <= 1024 ? 1 : cap <= 2048 ? 2 : cap <= 4096 ? 3 : cap <= 8192 ? 4 : 5; }  // (4, 5: filtered instances only)
 // lutr: look-up table in registers (jvk_pqp_lutr_ok shapes only)
 extern "C" int jvk_pqp_lutr_ok(const JvIndexDev* ix, int cap) {
     return ix->pq_M == 32 && ix->sim != 2 && ix->R * ix->pq_lanes <= JV_WAVE && cap <= 2048 ? 1 : 0;
 }
 // (filtered instances: register-table variants for every pool class)
 extern "C" int jvk_pqpf_lutr_ok(const JvIndexDev* ix, int cap) {
-    return ix->pq_M == 32 && ix->sim != 2 && ix->R * ix->pq_lanes <= JV_WAVE && cap <= 8192 ? 1 : 0;
+    return ix->pq_M == 32 && ix->sim != 2 && ix->R * ix->pq_lanes <= JV_WAVE && cap <= 16384 ? 1 : 0;
 }
 extern "C" const void* jvk_pqpf_kernel(int fast, int capk, int nch_slot, int lutr);  // jv_kernels_pqpf.hip
 extern "C" hipError_t jvk_pqpf_set_max_lds(int bytes);
@@ -75,7 +75,7 @@ extern "C" hipError_t jvk_pqp_set_max_lds(int bytes) {
 }
 
 extern "C" int jvk_pqp_max_entries(void) { return 4096; }
-extern "C" int jvk_pqp_max_entries_filtered(void) { return 8192; }
+extern "C" int jvk_pqp_max_entries_filtered(void) { return 16384; }
 
 // resident workgroups per CU for this index shape, pool capacity and LDS size
 extern "C" int jvk_pqp_blocks_per_cu(const JvIndexDev* ix, int cap, int lds_bytes, int lutr, int filt) {

@@ -8,16 +8,16 @@ typedef void (*pqp_kernel_t)(const JvIndexDev, const JvSearchArgs);
 #define JV_PQPF_ROW(FAST, CAPK) \
     { jv_search_pqp_kernel<0, 1, FAST, CAPK, false, true>, jv_search_pqp_kernel<2, 1, FAST, CAPK, false, true>, \
       jv_search_pqp_kernel<12, 1, FAST, CAPK, false, true>, jv_search_pqp_kernel<24, 1, FAST, CAPK, false, true> }
-// [FAST][capacity class 1..4][nch slot]  (class 4 = up to 8 192 entries: selective filters at wide beams, one workgroup per CU)
-static const pqp_kernel_t g_pqpf_kernels[2][4][4] = {{JV_PQPF_ROW(false, 1), JV_PQPF_ROW(false, 2), JV_PQPF_ROW(false, 3), JV_PQPF_ROW(false, 4)},
-                                                     {JV_PQPF_ROW(true, 1), JV_PQPF_ROW(true, 2), JV_PQPF_ROW(true, 3), JV_PQPF_ROW(true, 4)}};
-// register-table variants (PQ-32, FAST): [capacity class 1..4][nch slot]  (classes 3, 4: the pool stays in LDS after the search)
+// [FAST][capacity class 1..5][nch slot]  (classes 4, 5 = up to 8 192 / 16 384 entries: selective filters at wide beams, 2 / 1 workgroups per CU)
+static const pqp_kernel_t g_pqpf_kernels[2][5][4] = {{JV_PQPF_ROW(false, 1), JV_PQPF_ROW(false, 2), JV_PQPF_ROW(false, 3), JV_PQPF_ROW(false, 4), JV_PQPF_ROW(false, 5)},
+                                                     {JV_PQPF_ROW(true, 1), JV_PQPF_ROW(true, 2), JV_PQPF_ROW(true, 3), JV_PQPF_ROW(true, 4), JV_PQPF_ROW(true, 5)}};
+// register-table variants (PQ-32, FAST): [capacity class 1..5][nch slot]  (classes 3..5: the pool stays in LDS after the search)
 #define JV_PQVF_ROW(CAPK) \
     { jv_search_pqp_kernel<0, 1, true, CAPK, true, true>, jv_search_pqp_kernel<2, 1, true, CAPK, true, true>, \
       jv_search_pqp_kernel<12, 1, true, CAPK, true, true>, jv_search_pqp_kernel<24, 1, true, CAPK, true, true> }
-static const pqp_kernel_t g_pqvf_kernels[4][4] = {JV_PQVF_ROW(1), JV_PQVF_ROW(2), JV_PQVF_ROW(3), JV_PQVF_ROW(4)};
+static const pqp_kernel_t g_pqvf_kernels[5][4] = {JV_PQVF_ROW(1), JV_PQVF_ROW(2), JV_PQVF_ROW(3), JV_PQVF_ROW(4), JV_PQVF_ROW(5)};
 
-// fast: pq_M % 16 == 0 and not cosine; capk: capacity class (0..4, class 0 runs on class 1's instance); lutr: table in registers
+// fast: pq_M % 16 == 0 and not cosine; capk: capacity class (0..5, class 0 runs on class 1's instance); lutr: table in registers
 extern "C" const void* jvk_pqpf_kernel(int fast, int capk, int nch_slot, int lutr) {
     if (capk < 1) capk = 1;
     if (lutr && fast) return (const void*)g_pqvf_kernels[capk - 1][nch_slot];
@@ -26,7 +26,7 @@ extern "C" const void* jvk_pqpf_kernel(int fast, int capk, int nch_slot, int lut
 
 extern "C" hipError_t jvk_pqpf_set_max_lds(int bytes) {
     for (int f = 0; f < 2; f++)
-        for (int c = 0; c < 4; c++)
+        for (int c = 0; c < 5; c++)
             for (int s = 0; s < 4; s++) {
                 hipError_t e = hipFuncSetAttribute((const void*)g_pqpf_kernels[f][c][s], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
                 if (e == hipSuccess && f == 0)

@@ -62,7 +62,7 @@ __device__ __forceinline__ int rank_level(const int64_t* pool, int lo, int last,
 // NCHT: row length in 64-float chunks known at compile time (rerank), 0 = any d
 // NP:   fused-block passes (1: R * lanes-per-node <= 64; 4: up to 4 passes)
 // FAST: pq_M % 16 == 0 and not cosine (only the unmasked look-up is compiled)
-// CAPK: pool capacity class: 0 -> <= 512 entries, 1 -> <= 1 024, 2 -> <= 2 048, 3 -> <= 4 096, 4 -> <= 8 192 (filtered instances only)
+// CAPK: pool capacity class: 0 -> <= 512 entries, 1 -> <= 1 024, 2 -> <= 2 048, 3 -> <= 4 096, 4 -> <= 8 192, 5 -> <= 16 384 (4, 5: filtered instances only)
 // LUTR: the look-up table lives in REGISTERS (PQ-32, FAST, single pass only): lutr[m][e], lane l = lut[m][4 l + e]; a
 //       look-up is ds_bpermute (lane = code >> 2) of the four e-registers + a bit-select by code & 3.  Costs ~3x the
 //       instructions of an LDS gather, but LDS then only holds the pool: 8 resident queries per CU (two waves per SIMD
@@ -106,7 +106,9 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
         for (int o = 32; o >= 1; o >>= 1) bits += __shfl_xor(bits, o, JV_WAVE);
         const float sel = fmaxf((float)bits, 1.0f) * (1.0f / 16384.0f);
         const float need = (float)rk / sel * 1.05f + 64.0f + (float)R;
-        if (need > (float)a.cand_cap && a.cand_cap < 8 * rk + 256) {
+        // (first launch: pools beyond 8 rerankK are not worth predicting; later rungs: skip whenever a wider one follows —
+        //  retry_only = 2 marks the last on-chip rung, which takes whatever reaches it)
+        if (need > (float)a.cand_cap && (a.retry_only == 1 || (a.retry_only == 0 && a.cand_cap < 8 * rk + 256))) {
             if (lane == 0) {
                 a.out_flags[qi] = (int32_t)(JV_FLAG_OVERFLOW | (3u << 8));
                 a.out_count[qi] = 0;
@@ -424,14 +426,17 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
         int rold;
         {
             int lo = 0;
+            if (CAPK == 5) lo = rank_level<2048, 8>(pool, lo, cap, v);
+            if (CAPK == 5) lo = rank_level<128, 16>(pool, lo, cap, v);
             if (CAPK == 4) lo = rank_level<1024, 8>(pool, lo, cap, v);
             if (CAPK == 3) lo = rank_level<512, 8>(pool, lo, cap, v);
             if (CAPK == 2) lo = rank_level<512, 4>(pool, lo, cap, v);
             if (CAPK == 1) lo = rank_level<256, 4>(pool, lo, cap, v);
             if (CAPK == 1) lo = rank_level<64, 4>(pool, lo, cap, v);
             else if (CAPK == 4) lo = rank_level<64, 16>(pool, lo, cap, v);
-            else lo = rank_level<64, 8>(pool, lo, cap, v);
-            lo = rank_level<8, 8>(pool, lo, cap, v);
+            else if (CAPK != 5) lo = rank_level<64, 8>(pool, lo, cap, v);
+            if (CAPK == 5) lo = rank_level<8, 16>(pool, lo, cap, v);
+            else lo = rank_level<8, 8>(pool, lo, cap, v);
             int64_t p3[9];
 #pragma unroll
             for (int k2 = 0; k2 < 9; k2++) p3[k2] = pool[min(lo + k2, cap)];

@@ -554,8 +554,9 @@ def test_filtered_persistent_kernel_parity(pkg, pyoracle, small_sets, sim):
 
 
 def test_filtered_wide_pool_rung_parity(pkg, pyoracle, small_sets):
-    """Selective filters at wide beams: pools of 4 097 .. 8 192 entries (selectivity ~0.2 at rerankK 1 000 - 1 200) are
-    answered by the third filtered launch (capacity class 4, one workgroup per CU) and must not reach the HBM-scratch rung."""
+    """Selective filters at wide beams: pools of 4 097 .. 16 384 entries (selectivity 0.25 .. 0.08 at rerankK 700 - 1 200)
+    are answered by the residency-sized rungs of the filtered pool kernel (capacity classes 4 and 5: 3, 2 and 1 workgroups
+    per CU) and must not reach the HBM-scratch rung."""
     b, bl = pkg.binding, pkg.builder
     rng = np.random.default_rng(91)
     n, d = 24000, 64
@@ -567,7 +568,7 @@ def test_filtered_wide_pool_rung_parity(pkg, pyoracle, small_sets):
         gpu = b.GpuIndex(ix, flags=b.DESC_FUSED_ADC)
         gpu.set_option("lutr_min_queries", 0)
         orc = pyoracle.Oracle(b, ix)
-        for frac, k, rk in ((0.2, 10, 1000), (0.18, 10, 1200), (0.25, 20, 1200), (0.12, 10, 700)):
+        for frac, k, rk in ((0.2, 10, 1000), (0.18, 10, 1200), (0.25, 20, 1200), (0.12, 10, 700), (0.1, 10, 1200), (0.08, 10, 1000)):
             words = b.accept_words(np.nonzero(rng.random(n) < frac)[0], n)
             want = orc.search_batch(q, k, rk, accept=words, accept_num_docs=n)
             got, _, flags, rc = gpu.search_batch_ex(q, k, rk, accept=words, accept_num_docs=n)
