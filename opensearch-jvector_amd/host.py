@@ -46,6 +46,7 @@ def load_library(path: str = LIB_PATH):
         lib.jvh_similarity_ord_to_dist_func.argtypes = [i32, vp]
         lib.jvh_similarity_dist_func_to_ord.argtypes = [i32]
         lib.jvh_concurrent_search_bench.argtypes = [vp, vp, i32, i32, i32, i32, i32, C.c_double, vp, vp]
+        lib.jvh_concurrent_search_bench_filtered.argtypes = [vp, vp, i32, i32, i32, i32, i32, C.c_double, vp, vp, C.c_int64, C.c_uint64, vp]
         lib.jvh_meta_write.argtypes = [vp, C.c_char_p, i32, vp, i32, vp, C.c_int64, vp]
         lib.jvh_meta_read.argtypes = [vp, C.c_int64, vp, C.c_char_p, vp, i32, vp, vp, vp, C.c_int64]
         _lib = lib
@@ -148,15 +149,18 @@ class JVectorReader:
 
 
 def concurrent_search_bench(index: "binding.GpuIndex", queries: np.ndarray, topK: int, rerankK: int, threads: int,
-                            seconds: float, check_nodes: np.ndarray | None = None) -> dict:
+                            seconds: float, check_nodes: np.ndarray | None = None, accept: np.ndarray | None = None,
+                            accept_num_docs: int = 0, accept_key: int = 0) -> dict:
     """`threads` native threads each issuing one jv_search at a time on the same handle — the reference's calling
     pattern (T/index/engine/JVectorConcurrentQueryTests.java:78-138)."""
     lib = load_library()
     q = np.ascontiguousarray(queries, dtype=np.float32)
     chk = None if check_nodes is None else np.ascontiguousarray(check_nodes, dtype=np.int32)
     out = np.zeros(5, dtype=np.float64)
-    _check(lib, lib.jvh_concurrent_search_bench(index.handle, q.ctypes.data, q.shape[0], q.shape[1], topK, rerankK, threads,
-                                                float(seconds), None if chk is None else chk.ctypes.data, out.ctypes.data))
+    acc = None if accept is None else np.ascontiguousarray(accept, dtype=np.uint64)
+    _check(lib, lib.jvh_concurrent_search_bench_filtered(
+        index.handle, q.ctypes.data, q.shape[0], q.shape[1], topK, rerankK, threads, float(seconds),
+        None if chk is None else chk.ctypes.data, None if acc is None else acc.ctypes.data, accept_num_docs, accept_key, out.ctypes.data))
     return {"threads": threads, "qps": float(out[0]), "p50_ms": float(out[1]), "p99_ms": float(out[2]),
             "completed": int(out[3]), "mismatches": int(out[4])}
 

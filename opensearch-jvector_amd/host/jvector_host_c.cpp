@@ -154,8 +154,11 @@ int jvh_similarity_dist_func_to_ord(int lucene_similarity) {
 // out[0] = completed queries/s, out[1] = p50 ms, out[2] = p99 ms, out[3] = completed queries.
 // When `check_nodes` is given ([nq][topK], e.g. from a batch call) every answer is compared with it and the
 // number of mismatching queries is returned in out[4].
-int jvh_concurrent_search_bench(jv_index* index, const float* queries, int nq, int dim, int topK, int rerankK,
-                                int threads, double seconds, const int32_t* check_nodes, double out[5]) {
+// `accept_words` (optional): one doc filter handed to every call, as a filtered k-NN query's leaf searches do
+// (J/JVectorReader.java:157-163); `accept_key` != 0 names it for the library's filter cache (jv_search_ex).
+int jvh_concurrent_search_bench_filtered(jv_index* index, const float* queries, int nq, int dim, int topK, int rerankK,
+                                         int threads, double seconds, const int32_t* check_nodes, const uint64_t* accept_words,
+                                         int64_t accept_num_docs, uint64_t accept_key, double out[5]) {
     if (!index || !queries || nq <= 0 || threads <= 0 || topK <= 0) {
         g_err = "bad argument";
         return -1;
@@ -175,8 +178,21 @@ int jvh_concurrent_search_bench(jv_index* index, const float* queries, int nq, i
             l.reserve(1 << 16);
             for (int qi = t % nq; !stop.load(std::memory_order_relaxed); qi = (qi + threads) % nq) {
                 const auto a = std::chrono::steady_clock::now();
-                int rc = jv_search(index, queries + (size_t)qi * dim, topK, rerankK, 0.0f, 0.0f, nullptr, 0, nodes.data(),
-                                   docs.data(), scores.data(), &count, stats);
+                int rc;
+                if (accept_words && accept_key) {
+                    jv_search_params p{};
+                    p.struct_size = sizeof(p);
+                    p.topK = topK;
+                    p.rerankK = rerankK;
+                    p.accept_doc_words = accept_words;
+                    p.accept_num_docs = accept_num_docs;
+                    p.accept_key = accept_key;
+                    int32_t qflags = 0;
+                    rc = jv_search_ex(index, queries + (size_t)qi * dim, &p, nodes.data(), docs.data(), scores.data(), &count, stats, &qflags);
+                } else {
+                    rc = jv_search(index, queries + (size_t)qi * dim, topK, rerankK, 0.0f, 0.0f, accept_words, accept_words ? accept_num_docs : 0,
+                                   nodes.data(), docs.data(), scores.data(), &count, stats);
+                }
                 const auto b = std::chrono::steady_clock::now();
                 if (rc != 0) {
                     failed.store(rc);
@@ -205,6 +221,11 @@ int jvh_concurrent_search_bench(jv_index* index, const float* queries, int nq, i
     out[3] = (double)all.size();
     out[4] = (double)mismatches.load();
     return 0;
+}
+
+int jvh_concurrent_search_bench(jv_index* index, const float* queries, int nq, int dim, int topK, int rerankK,
+                                int threads, double seconds, const int32_t* check_nodes, double out[5]) {
+    return jvh_concurrent_search_bench_filtered(index, queries, nq, dim, topK, rerankK, threads, seconds, check_nodes, nullptr, 0, 0, out);
 }
 
 

@@ -26,7 +26,11 @@ desc, keep = b.make_desc_device(n, d, 32, base.data_ptr(), adj.data_ptr(), entry
                                 pq_centroid=pq["centroid"], pq_codes_ptr=pq["codes"].data_ptr(), borrow=True, extra_flags=b.DESC_FUSED_ADC)
 ix = b.GpuIndex(desc=desc, keepalive=keep, flags=b.DESC_BORROW)
 qh = q.cpu().numpy()
-want = ix.search_batch(qh, 10, rk).nodes
+acc, acc_key = None, 0
+if os.environ.get("SEL"):   # one doc filter of this selectivity on every call (KEY=1: named for the filter cache)
+    acc = b.accept_words(np.nonzero(np.random.default_rng(5).random(n) < float(os.environ["SEL"]))[0], n)
+    acc_key = 77 if os.environ.get("KEY") == "1" else 0
+want = ix.search_batch(qh, 10, rk, accept=acc, accept_num_docs=(n if acc is not None else 0)).nodes
 for opt in os.environ.get("JV_OPTS", "").split(","):
     if "=" in opt:
         k_, v_ = opt.split("=")
@@ -44,7 +48,7 @@ if os.environ.get("BIG_FIRST"):  # diagnostic: a large device-API launch first, 
     ix.search_batch(qh[:4096], 10, rk)
 rows = []
 for T in [int(x) for x in os.environ.get("THREADS", "1,8,32,64,128,256").split(",")]:
-    r = host.concurrent_search_bench(ix, qh, 10, rk, T, secs, want)
+    r = host.concurrent_search_bench(ix, qh, 10, rk, T, secs, want, accept=acc, accept_num_docs=(n if acc is not None else 0), accept_key=acc_key)
     rows.append(r)
     print(json.dumps(r), flush=True)
     assert r["mismatches"] == 0, "single-query answers differ from the batch API's"
