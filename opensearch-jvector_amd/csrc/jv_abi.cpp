@@ -61,6 +61,10 @@ hipError_t jvk_launch_search_pqw(const JvIndexDev* ix, const JvSearchArgs* a, in
 hipError_t jvk_pqs_set_max_lds(int bytes);
 int jvk_pqs_blocks_per_cu(const JvIndexDev* ix, int cap, int lds_bytes);
 hipError_t jvk_launch_serve_pqw(const JvIndexDev* ix, const JvSearchArgs* a, int lds_bytes, int blocks, hipStream_t s);
+int jvk_pqsf_max_entries(void);
+hipError_t jvk_pqsf_set_max_lds(int bytes);
+int jvk_pqsf_blocks_per_cu(const JvIndexDev* ix, int lds_bytes, int lutr);
+hipError_t jvk_launch_serve_pqpf(const JvIndexDev* ix, const JvSearchArgs* a, int lds_bytes, int blocks, int lutr, hipStream_t s);
 }
 
 namespace {
@@ -249,6 +253,7 @@ struct FilterEntry {
     size_t cap_words = 0;
     uint64_t stamp = 0;
     int users = 0;  // launches in flight that read it
+    int no_serve_rk = 0;  // > 0: the filtered query server's pool cannot hold this filter at rerankK >= this (its kernel said so): such calls skip the ring
     hipEvent_t ready = nullptr;  // recorded after the upload: consumers on other streams wait for it
     std::vector<uint64_t> host;  // the cached bits: a hit is served only after a memcmp against the caller's bitset (the key —
                                  // a 64-bit content hash or a caller-supplied number — only finds the candidate entry)
@@ -280,6 +285,7 @@ struct jv_index {
     // launches per kernel family since creation (jv_index_get_counter): which rung served a call is observable
     std::atomic<int64_t> launches[8] = {};
     struct JvQueryServer* server = nullptr;  // device-resident query server (created by the first eligible one-query call)
+    struct JvQueryServer* server_f = nullptr;  // the same for one-query calls WITH a doc filter (one-wave filtered pool kernel)
     std::mutex server_mu;
 };
 enum { LAUNCH_PQW = 0, LAUNCH_PQP, LAUNCH_PQF, LAUNCH_LDS, LAUNCH_BIG, LAUNCH_SERVE, SERVED_QUERIES };
@@ -512,6 +518,44 @@ int plan_pqw_lds(const jv_index* ix, JvSearchArgs& x, int variant) {
     return x.pqp_lds_bytes;
 }
 
+// Resident query-server grids hold their LDS for as long as they live; a launch whose workgroups need more than what they
+// leave free on a CU would not start before the grids idle out (serve_idle_ms) — or never, under steady one-query traffic.
+// Such a launch asks the grids to leave first (they come back with the next one-query call).  Defined with the servers below.
+void servers_yield_lds(int device, int lds_needed);
+
+// LDS plan of one launch of the one-wave pool kernel (jv_kernels_pqp.hip / jv_kernels_pqpf.hip / jv_kernels_pqsf.hip): offsets
+// into the workgroup's LDS for a pool of x.cand_cap entries and beams of up to `rk`; regs = look-up table in registers
+int plan_pqp_lds(const jv_index* ix, JvSearchArgs& x, bool regs, int rk) {
+    const int lut_b = ix->dev.pq_M * 256 * 4;
+    const int qc_b = ix->dev.nch * 64 * 4;
+    bool alias = qc_b <= lut_b;
+    const int off_f = ix->dev.pq_M * 256 - ix->dev.nch * 64;
+    for (int m = 0; alias && m + 1 < ix->dev.pq_M; m++)
+        if ((m + 1) * 256 - off_f > ix->pq_sub_off[(size_t)m + 1]) alias = false;
+    const int rerank_b = qc_b + JV_TODO * 8 + ((rk + 1) & ~1) * 8;   // after the search, in front of the pool
+    int lds;
+    const int pool_b = (x.cand_cap + 1) * 8;
+    if (regs) {
+        // table in registers: LDS = the pool while searching, one hash set afterwards (>= 4 096 slots), then the
+        // rerank scratch with the pool written back behind the query and todo lists
+        x.pqp_pool_off = 0;
+        x.pqp_qc_off = 0;
+        x.pqp_scratch_off = (pool_b + 15) & ~15;
+        lds = std::max(std::max(x.pqp_scratch_off + 768, qc_b), std::max(16384, qc_b + JV_TODO * 8 + pool_b));
+        // (filtered classes 3, 4: the pool stays in LDS and everything after the search lives behind what is left of it)
+        if (x.cand_cap > 2048) lds = x.pqp_scratch_off + 768;
+    } else {
+        x.pqp_pool_off = (std::max(lut_b, rerank_b) + 15) & ~15;
+        x.pqp_scratch_off = (x.pqp_pool_off + pool_b + 15) & ~15;
+        lds = x.pqp_scratch_off + 768;
+        x.pqp_qc_off = alias ? lut_b - qc_b : ((lds + 15) & ~15);
+        if (!alias) lds = x.pqp_qc_off + qc_b;
+    }
+    lds = (lds + 15) & ~15;
+    x.pqp_lds_bytes = lds;
+    return lds;
+}
+
 // enqueue one batch on `stream`; all pointers are device pointers
 int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queries, int nq, int topK, int rk,
                   float thr, float floor_, const uint64_t* d_accept, int64_t accept_docs, int32_t* d_nodes,
@@ -608,42 +652,13 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
             HIPCHK(jvk_launch_accept_to_ord(&ix->dev, a.accept, a.accept_docs, c->d_accept_ord, stream));
             ap.accept_ord = c->d_accept_ord;
         }
-        const int lut_b = ix->dev.pq_M * 256 * 4;
-        const int qc_b = ix->dev.nch * 64 * 4;
         ap.cand_cap = filtered ? std::min(2048, std::max(1024, 2 * (rk + 64 + ix->dev.R))) : rk + 64 + ix->dev.R;
         ap.pqp_log_cap = filtered ? 3 * ap.cand_cap : ((3 * rk + 64 + 3) & ~3);
-        bool alias = qc_b <= lut_b;
-        const int off_f = ix->dev.pq_M * 256 - ix->dev.nch * 64;
-        for (int m = 0; alias && m + 1 < ix->dev.pq_M; m++)
-            if ((m + 1) * 256 - off_f > ix->pq_sub_off[(size_t)m + 1]) alias = false;
-        const int rerank_b = qc_b + JV_TODO * 8 + ((rk + 1) & ~1) * 8;   // after the search, in front of the pool
         // Table in registers (8 resident queries per CU, +34 % throughput at rerankK = 1 200, but 1.7x the latency of
         // one query): only when the launch has more queries than the LDS-table variant could keep resident anyway
         const int lutr = (OPT(ix, OPT_NO_LUTR) == 0 && jvk_pqp_lutr_ok(&ix->dev, ap.cand_cap) && nq > lutr_min_q) ? 1 : 0;
         // LDS plan of one launch: offsets into the workgroup's LDS for a pool of x.cand_cap entries
-        auto plan = [&](JvSearchArgs& x, bool regs) {
-            int lds;
-            const int pool_b = (x.cand_cap + 1) * 8;
-            if (regs) {
-                // table in registers: LDS = the pool while searching, one hash set afterwards (>= 4 096 slots), then the
-                // rerank scratch with the pool written back behind the query and todo lists
-                x.pqp_pool_off = 0;
-                x.pqp_qc_off = 0;
-                x.pqp_scratch_off = (pool_b + 15) & ~15;
-                lds = std::max(std::max(x.pqp_scratch_off + 768, qc_b), std::max(16384, qc_b + JV_TODO * 8 + pool_b));
-                // (filtered classes 3, 4: the pool stays in LDS and everything after the search lives behind what is left of it)
-                if (x.cand_cap > 2048) lds = x.pqp_scratch_off + 768;
-            } else {
-                x.pqp_pool_off = (std::max(lut_b, rerank_b) + 15) & ~15;
-                x.pqp_scratch_off = (x.pqp_pool_off + pool_b + 15) & ~15;
-                lds = x.pqp_scratch_off + 768;
-                x.pqp_qc_off = alias ? lut_b - qc_b : ((lds + 15) & ~15);
-                if (!alias) lds = x.pqp_qc_off + qc_b;
-            }
-            lds = (lds + 15) & ~15;
-            x.pqp_lds_bytes = lds;
-            return lds;
-        };
+        auto plan = [&](JvSearchArgs& x, bool regs) { return plan_pqp_lds(ix, x, regs, rk); };
         // Several waves per query (jv_kernels_pqw.hip: PQ-32 / PQ-64, unfiltered): table in registers split by chunk, one
         // wave per chunk.  LDS = [pool | centred query | hash set | rerank scratch] + the waves' exchange rows + ctrl words.
         const bool pqw = !filtered && OPT(ix, OPT_NO_PQW) == 0 && jvk_pqw_ok(&ix->dev, ap.cand_cap) && nq >= OPT(ix, OPT_PQW_MIN_QUERIES);
@@ -737,6 +752,11 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
             }
             ap.pqp_log = c->pqp_log;
             ap.pqp_counter = c->work_counter + 6;
+            {
+                int lds_max = std::max(lds, second ? lds2 : 0);
+                for (int i = 0; i < nrungs; i++) lds_max = std::max(lds_max, rungs[i].lds);
+                servers_yield_lds(ix->device, lds_max);
+            }
             if (pqw) HIPCHK(jvk_launch_search_pqw(&ix->dev, &ap, lds, blocks, pqw_variant, stream));
             else HIPCHK(jvk_launch_search_pqp(&ix->dev, &ap, lds, blocks, lutr, stream));
             ix->launches[pqw ? LAUNCH_PQW : LAUNCH_PQP]++;
@@ -864,6 +884,9 @@ struct JvQueryServer {
     int32_t* d_words = nullptr;     // device: JV_SV_*
     int32_t* log = nullptr;         // device: expansion logs of the resident workgroups
     int slots = 0, slot_bytes = 0, cap_max = 0, blocks = 0, lds = 0;
+    int kind = 0;                   // 0: unfiltered queries on the several-waves kernel; 1: queries with a doc filter (one-wave filtered pool kernel)
+    int lutr = 0;                   // kind 1: look-up table in registers
+    hipStream_t up_stream = nullptr;  // kind 1: filter uploads of cache misses (the grid's own stream never drains)
     JvSearchArgs args{};
     std::atomic<uint32_t> reserve{0};
     std::atomic<uint32_t>* slot_free = nullptr;  // slot i may be filled by the call holding sequence number slot_free[i]
@@ -920,8 +943,22 @@ void free_with_servers_paused(void* p) {
     }
 }
 
-void server_destroy(jv_index* ix) {
-    Server* sv = ix->server;
+void servers_yield_lds(int device, int lds_needed) {
+    std::lock_guard<std::mutex> g(g_servers_mu);
+    int held = 0;  // LDS bytes per CU the live grids on this device occupy
+    for (Server* sv : g_servers)
+        if (sv->ix->device == device && sv->h_words && __atomic_load_n(&sv->h_words[JV_SH_ALIVE], __ATOMIC_ACQUIRE) != 0)
+            held += (sv->blocks / std::max(1, sv->ix->cu_count)) * sv->lds;
+    if (held == 0 || lds_needed <= 161280 - held) return;  // (161 280: what a CU's workgroups can share, tools/lds_residency.hip)
+    for (Server* sv : g_servers)
+        if (sv->ix->device == device) {
+            std::lock_guard<std::mutex> lk(sv->mu);
+            server_stop_locked(sv);
+        }
+}
+
+void server_destroy_one(jv_index* ix, Server*& ref) {
+    Server* sv = ref;
     if (!sv) return;
     {
         std::lock_guard<std::mutex> g(g_servers_mu);
@@ -932,13 +969,18 @@ void server_destroy(jv_index* ix) {
         server_stop_locked(sv);
     }
     if (sv->stream) hipStreamDestroy(sv->stream);
+    if (sv->up_stream) hipStreamDestroy(sv->up_stream);
     if (sv->ring) hipHostFree(sv->ring);
     if (sv->h_words) hipHostFree(sv->h_words);
     hipFree(sv->d_words);
     hipFree(sv->log);
     delete[] sv->slot_free;
     delete sv;
-    ix->server = nullptr;
+    ref = nullptr;
+}
+void server_destroy(jv_index* ix) {
+    server_destroy_one(ix, ix->server);
+    server_destroy_one(ix, ix->server_f);
 }
 
 int server_launch_locked(Server* sv) {  // sv->mu held, grid not alive
@@ -947,7 +989,8 @@ int server_launch_locked(Server* sv) {  // sv->mu held, grid not alive
     // tickets continue where the last grid stopped: HEAD / PUBLISHED stay, the exit count and the idle clock restart
     HIPCHK(hipMemsetAsync(sv->d_words + JV_SV_LOCK, 0, 4 * sizeof(int32_t), sv->stream));  // LOCK, EXITED, LAST_CLAIM, STOP_SEEN
     __atomic_store_n(&sv->h_words[JV_SH_ALIVE], 1, __ATOMIC_RELEASE);
-    hipError_t e = jvk_launch_serve_pqw(&ix->dev, &sv->args, sv->lds, sv->blocks, sv->stream);
+    hipError_t e = sv->kind == 0 ? jvk_launch_serve_pqw(&ix->dev, &sv->args, sv->lds, sv->blocks, sv->stream)
+                                 : jvk_launch_serve_pqpf(&ix->dev, &sv->args, sv->lds, sv->blocks, sv->lutr, sv->stream);
     if (e != hipSuccess) {
         __atomic_store_n(&sv->h_words[JV_SH_ALIVE], 0, __ATOMIC_RELEASE);
         return fail(JV_EDEVICE, "query server launch failed: %s", hipGetErrorString(e));
@@ -957,14 +1000,15 @@ int server_launch_locked(Server* sv) {  // sv->mu held, grid not alive
 }
 
 // the index's server, able to hold pools of `need_cap` entries; nullptr (with *rc set) when it cannot be provided
-Server* server_get(jv_index* ix, int need_cap, int* rc) {
+Server* server_get(jv_index* ix, int kind, int need_cap, int* rc) {
     *rc = JV_OK;
     std::lock_guard<std::mutex> lk(ix->server_mu);
-    if (ix->server && ix->server->cap_max >= need_cap) return ix->server;
-    if (ix->server) {  // a larger beam than the ring was planned for: rebuild it once nothing is in flight
-        Server* old = ix->server;
+    Server*& ref = kind == 0 ? ix->server : ix->server_f;
+    if (ref && ref->cap_max >= need_cap) return ref;
+    if (ref) {  // a larger beam than the ring was planned for: rebuild it once nothing is in flight
+        Server* old = ref;
         while (old->inflight.load() > 0) sched_yield();
-        server_destroy(ix);
+        server_destroy_one(ix, ref);
     }
     if (hipSetDevice(ix->device) != hipSuccess) {
         *rc = fail(JV_EDEVICE, "hipSetDevice failed");
@@ -972,29 +1016,61 @@ Server* server_get(jv_index* ix, int need_cap, int* rc) {
     }
     Server* sv = new Server();
     sv->ix = ix;
+    sv->kind = kind;
     auto bail = [&](const char* what, hipError_t e) -> Server* {
         *rc = fail(e == hipErrorOutOfMemory ? JV_ENOMEM : JV_EDEVICE, "query server: %s: %s", what, hipGetErrorString(e));
-        ix->server = sv;
-        server_destroy(ix);
+        ref = sv;
+        server_destroy_one(ix, ref);
         return nullptr;
     };
     const int R = ix->dev.R;
-    sv->cap_max = std::min(2048, std::max(need_cap, 512));
     JvSearchArgs& a = sv->args;
     a = JvSearchArgs{};
-    a.cand_cap = sv->cap_max;
-    a.rk = sv->cap_max - 64 - R;
     a.topK = 1;
     a.nq = 1;
-    a.pqp_log_cap = (3 * a.rk + 64 + 3) & ~3;
-    sv->lds = plan_pqw_lds(ix, a, 1);
-    const int per_cu = std::min<int>(jvk_pqs_blocks_per_cu(&ix->dev, sv->cap_max, sv->lds), (int)std::max<int64_t>(1, OPT(ix, OPT_SERVE_WGS_PER_CU)));
+    int per_cu;
+    if (kind == 0) {
+        sv->cap_max = std::min(2048, std::max(need_cap, 512));
+        a.cand_cap = sv->cap_max;
+        a.rk = sv->cap_max - 64 - R;
+        a.pqp_log_cap = (3 * a.rk + 64 + 3) & ~3;
+        sv->lds = plan_pqw_lds(ix, a, 1);
+        per_cu = std::min<int>(jvk_pqs_blocks_per_cu(&ix->dev, sv->cap_max, sv->lds), (int)std::max<int64_t>(1, OPT(ix, OPT_SERVE_WGS_PER_CU)));
+    } else {
+        // one pool of the filtered instances' class 4 (~5 800 entries ~ rerankK / selectivity next to a PQ-32 table; what does not
+        // fit comes back flagged and takes the launch path's rungs).  Table in LDS, not in registers: a served query's time is its caller's latency, and
+        // one wave gathers from an LDS table 1.4x faster than it permutes registers (measured: 7.4 vs 10.4 ms per query at
+        // selectivity 0.5, rerankK 1 200) — two resident queries per CU instead of four, which only matters beyond 512 callers
+        sv->lutr = 0;
+        {
+            // the largest pool that keeps TWO queries resident per CU next to this index's table (one if even 4 097 entries do not)
+            JvSearchArgs probe = a;
+            probe.cand_cap = 4097;
+            const int fixed = plan_pqp_lds(ix, probe, false, 4097 - 64 - R) - 4098 * 8;
+            int cap = 0;
+            for (int per = 2; per >= 1 && cap < 4097; per--) cap = std::min(((161280 / per - fixed - 256) / 8 - 1) & ~63, jvk_pqsf_max_entries());
+            sv->cap_max = cap;
+        }
+        a.cand_cap = sv->cap_max;
+        a.rk = sv->cap_max - 64 - R;
+        a.pqp_log_cap = 3 * sv->cap_max;
+        sv->lds = sv->cap_max >= 4097 ? plan_pqp_lds(ix, a, false, a.rk) : kMaxLds + 1;
+        if (sv->lds > kMaxLds) {
+            delete sv;
+            *rc = JV_OK;
+            return nullptr;  // (this PQ shape's table leaves no room for the pool: launch path)
+        }
+        // (what a CU really keeps resident: tools/lds_residency.hip — a little less than 160 KB can be shared)
+        per_cu = std::max(1, std::min<int>(std::min(jvk_pqsf_blocks_per_cu(&ix->dev, sv->lds, sv->lutr), 161280 / sv->lds),
+                                           (int)std::max<int64_t>(1, 2 * OPT(ix, OPT_SERVE_WGS_PER_CU))));  // (one wave per query here: twice the workgroups)
+    }
     sv->blocks = ix->cu_count * per_cu;
     sv->slots = next_pow2(std::max(1024, 2 * sv->blocks));
     const int qbytes = ((ix->dev.nch * 64 * 4) + 255) & ~255;
     sv->slot_bytes = (JV_SERVE_QUERY_OFF + qbytes + 255) & ~255;
     hipError_t e = hipStreamCreateWithFlags(&sv->stream, hipStreamNonBlocking);
     if (e != hipSuccess) return bail("stream", e);
+    if (kind == 1 && (e = hipStreamCreateWithFlags(&sv->up_stream, hipStreamNonBlocking)) != hipSuccess) return bail("upload stream", e);
     if ((e = hipHostMalloc((void**)&sv->ring, (size_t)sv->slots * sv->slot_bytes, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) return bail("ring", e);
     if ((e = hipHostMalloc((void**)&sv->h_words, 64, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) return bail("host words", e);
     memset(sv->h_words, 0, 64);
@@ -1012,7 +1088,7 @@ Server* server_get(jv_index* ix, int need_cap, int* rc) {
     a.serve_host = sv->h_words;
     a.serve_idle_ticks = (int32_t)std::min<int64_t>(2000000000, std::max<int64_t>(1, OPT(ix, OPT_SERVE_IDLE_MS)) * 100000);  // 100 MHz
     a.done_all = 1;
-    ix->server = sv;
+    ref = sv;
     {
         std::lock_guard<std::mutex> g(g_servers_mu);
         g_servers.push_back(sv);
@@ -1022,21 +1098,58 @@ Server* server_get(jv_index* ix, int need_cap, int* rc) {
 
 // one query through the server.  Returns JV_OK with the row filled, a negative code, or +1 when the caller should take the
 // launch path instead (not eligible, or the row came back flagged for the ladder).
+int filter_acquire(jv_index* ix, const uint64_t* words, size_t nwords, uint64_t key, hipStream_t stream, const uint64_t** d_out, int* slot);
+void filter_release(jv_index* ix, int slot);
+
+// accept_words != nullptr: a query with a doc filter (the filtered server; the bits are served from the index's filter cache)
 int serve_query(jv_index* ix, const float* query, int32_t topK, int32_t rerankK, float rerankFloor, int64_t visit_limit,
-                int32_t* out_nodes, int32_t* out_docs, float* out_scores, int32_t* out_count, int32_t* out_stats, int32_t* out_flags) {
+                int32_t* out_nodes, int32_t* out_docs, float* out_scores, int32_t* out_count, int32_t* out_stats, int32_t* out_flags,
+                const uint64_t* accept_words = nullptr, int64_t accept_docs = 0, uint64_t accept_key = 0) {
     const int cap = rerankK + 64 + ix->dev.R;
-    if (OPT(ix, OPT_SERVE) == 0 || OPT(ix, OPT_NO_PQW) != 0 || OPT(ix, OPT_NO_PQF) != 0 || OPT(ix, OPT_NO_PQP) != 0 ||
+    const int kind = accept_words ? 1 : 0;
+    if (OPT(ix, OPT_SERVE) == 0 || OPT(ix, OPT_NO_PQF) != 0 || OPT(ix, OPT_NO_PQP) != 0 ||
         OPT(ix, OPT_FORCE_BIG) != 0 || OPT(ix, OPT_FORCE_GENERAL) != 0 || OPT(ix, OPT_PQF_ONLY) != 0)
         return 1;
-    if (topK < 1 || topK > JV_SERVE_TOPK_MAX || ix->dev.pq_M <= 0 || !ix->dev.pq_fused || !jvk_pqw_ok(&ix->dev, cap) || ix->build_client) return 1;
+    if (topK < 1 || topK > JV_SERVE_TOPK_MAX || ix->dev.pq_M <= 0 || !ix->dev.pq_fused || ix->build_client) return 1;
+    if (kind == 0) {
+        if (OPT(ix, OPT_NO_PQW) != 0 || !jvk_pqw_ok(&ix->dev, cap)) return 1;
+    } else {
+        // the shapes the filtered pool kernel takes (enqueue_batch): single-pass fused blocks, flat graph, ordinals below 2^29
+        const JvIndexDev& dv = ix->dev;
+        if (OPT(ix, OPT_FILTER_CACHE) <= 0 || accept_docs <= 0 || dv.num_upper != 0 || dv.R > JV_WAVE || dv.R * dv.pq_lanes > JV_WAVE ||
+            dv.n >= (1 << 29) || cap > jvk_pqsf_max_entries())
+            return 1;
+        if (ix->server_f && cap > ix->server_f->cap_max) return 1;  // (a beam wider than the server's pool: launch path)
+    }
     int rc = JV_OK;
-    Server* sv = server_get(ix, cap, &rc);
+    Server* sv = server_get(ix, kind, kind == 0 ? cap : 0, &rc);  // (the filtered server has ONE pool size: what the LDS allows)
     if (!sv) return rc != JV_OK ? rc : 1;
+    if (kind == 1 && cap > sv->cap_max) return 1;
     sv->inflight++;
     struct Leave {
         Server* sv;
-        ~Leave() { sv->inflight--; }
-    } leave{sv};
+        jv_index* ix;
+        int fslot;
+        ~Leave() {
+            if (fslot >= 0) filter_release(ix, fslot);
+            sv->inflight--;
+        }
+    } leave{sv, ix, -1};
+    const uint64_t* d_filter = nullptr;
+    if (kind == 1) {
+        // the filter's bits in HBM: from the cache (verified byte for byte), or uploaded now and waited for — the grid reads
+        // them as soon as the slot is published
+        if (hipSetDevice(ix->device) != hipSuccess) return fail(JV_EDEVICE, "hipSetDevice failed");
+        const size_t nwords = ((size_t)accept_docs + 63) / 64;
+        if ((rc = filter_acquire(ix, accept_words, nwords, accept_key, sv->up_stream, &d_filter, &leave.fslot)) != JV_OK) return rc;
+        if (leave.fslot < 0) return 1;  // cache full of filters in use: launch path
+        {
+            std::lock_guard<std::mutex> lk(ix->filter_mu);
+            const int nrk = ix->filters[(size_t)leave.fslot].no_serve_rk;
+            if (nrk > 0 && rerankK >= nrk) return 1;  // (known not to fit the server's pool: straight to the launch path's rungs)
+        }
+        if (hipStreamSynchronize(sv->up_stream) != hipSuccess) return fail(JV_EDEVICE, "filter upload failed");
+    }
     const uint32_t seq = sv->reserve.fetch_add(1);
     const int si = (int)(seq & (uint32_t)(sv->slots - 1));
     for (int spins = 0; sv->slot_free[si].load(std::memory_order_acquire) != seq; spins++) {  // the slot's previous occupant is still reading its row
@@ -1048,6 +1161,8 @@ int serve_query(jv_index* ix, const float* query, int32_t topK, int32_t rerankK,
     slot->rk = rerankK;
     slot->visit_limit = visit_limit > 0 ? (int32_t)std::min<int64_t>(visit_limit, INT32_MAX) : 0;
     slot->rerank_floor = rerankFloor;
+    slot->accept = (uint64_t)(uintptr_t)d_filter;
+    slot->accept_docs = accept_docs;
     slot->done = 0;
     slot->count = 0;
     slot->flags = 0;
@@ -1096,6 +1211,11 @@ int serve_query(jv_index* ix, const float* query, int32_t topK, int32_t rerankK,
     int ret = JV_OK;
     if (f & (JV_FLAG_OVERFLOW | JV_FLAG_FAILED)) {
         ret = 1;  // the ladder's business (boundary ties beyond the first launch's slack, rerankFloor corner, ...): launch path
+        if (kind == 1 && ((f >> 8) & 0xFFu) == 9u) {  // the filter's estimated pool does not fit: remember it with the cached filter
+            std::lock_guard<std::mutex> lk(ix->filter_mu);
+            int& nrk = ix->filters[(size_t)leave.fslot].no_serve_rk;
+            if (nrk == 0 || rerankK < nrk) nrk = rerankK;
+        }
     } else {
         if (out_nodes) memcpy(out_nodes, slot->nodes, sizeof(int32_t) * (size_t)topK);
         if (out_docs) memcpy(out_docs, slot->docs, sizeof(int32_t) * (size_t)topK);
@@ -1409,6 +1529,7 @@ int jv_index_create(const jv_index_desc* desc, jv_index** out) {
         TRYHIP(jvk_pqp_set_max_lds(kMaxLds));
         TRYHIP(jvk_pqw_set_max_lds(kMaxLds));
         TRYHIP(jvk_pqs_set_max_lds(kMaxLds));
+        TRYHIP(jvk_pqsf_set_max_lds(kMaxLds));
         {
             hipDeviceProp_t prop;
             if (hipGetDeviceProperties(&prop, desc->device) == hipSuccess && prop.multiProcessorCount > 0) ix->cu_count = prop.multiProcessorCount;
@@ -1575,6 +1696,7 @@ int filter_acquire(jv_index* ix, const uint64_t* words, size_t nwords, uint64_t 
         f.cap_words = nwords;
     }
     f.key = 0;  // not valid until the copy is enqueued
+    f.no_serve_rk = 0;
     try {
         f.host.assign(words, words + nwords);  // (also the staging source: the caller's buffer may be gone before the copy runs)
     } catch (const std::bad_alloc&) {
@@ -1893,9 +2015,11 @@ int search_single(jv_index* index, const float* query, int32_t topK, int32_t rer
         return search_batch_host(index, query, 1, topK, rerankK, threshold, rerankFloor, accept_doc_words, nullptr,
                                  accept_num_docs, out_nodes, out_docs, out_scores, out_count, out_stats, ex);
     }
-    if (!accept_doc_words && threshold <= 0.0f) {
-        // shapes the several-waves pool kernel runs: no launch at all, the device-resident server answers
-        rc = serve_query(index, query, topK, rerankK, rerankFloor, visit_limit, out_nodes, out_docs, out_scores, out_count, out_stats, out_flags);
+    if (threshold <= 0.0f) {
+        // shapes the pool kernels run: no launch at all, a device-resident server answers (unfiltered: the several-waves kernel;
+        // with a doc filter: the one-wave filtered instances, the bits served from the filter cache)
+        rc = serve_query(index, query, topK, rerankK, rerankFloor, visit_limit, out_nodes, out_docs, out_scores, out_count, out_stats, out_flags,
+                         accept_doc_words, accept_doc_words ? accept_num_docs : 0, accept_key);
         if (rc <= 0) return rc;  // (1 = not eligible / a row for the ladder: the launch path below)
     }
     Combiner& cb = index->combiner;

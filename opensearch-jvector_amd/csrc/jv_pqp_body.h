@@ -110,7 +110,7 @@ __device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, cons
         //  retry_only = 2 marks the last on-chip rung, which takes whatever reaches it)
         if (need > (float)a.cand_cap && (a.retry_only == 1 || (a.retry_only == 0 && a.cand_cap < 8 * rk + 256))) {
             if (lane == 0) {
-                a.out_flags[qi] = (int32_t)(JV_FLAG_OVERFLOW | (3u << 8));
+                a.out_flags[qi] = (int32_t)(JV_FLAG_OVERFLOW | (9u << 8));  // (9: estimated pool beyond this launch's — a property of (filter, rerankK))
                 a.out_count[qi] = 0;
             }
             for (int i = lane; i < topK; i += JV_WAVE) {

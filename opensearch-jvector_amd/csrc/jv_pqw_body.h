@@ -15,6 +15,7 @@
 // 256 VGPRs + 320 B of scratch per lane.
 #pragma once
 #include "jv_pqp_body.h"
+#include "jv_serve_claim.h"
 
 // LDS-only workgroup barrier: waits for this wave's LDS operations, NOT for its global loads (a __syncthreads() would
 // drain the prefetched fused block with vmcnt(0))
@@ -956,47 +957,7 @@ __global__ __launch_bounds__(JV_WAVE * W, OCC) void jv_serve_pqw_kernel(const Jv
 #endif
     for (;;) {
         if (threadIdx.x == 0) {
-            int ticket = -1;
-            const uint32_t t_idle0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
-            int polls = 0, idle_iters = 0;
-            for (;;) {
-                const int h = __hip_atomic_load(&a.serve_dev[JV_SV_HEAD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                int pb = __hip_atomic_load(&a.serve_dev[JV_SV_PUBLISHED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (pb - h <= 0) {
-                    // nothing published that is not claimed: ONE workgroup at a time looks at the host's tail word
-                    // (the host words are read over PCIe: by the lock holder only — hundreds of idle workgroups polling them
-                    //  would queue in front of the working ones' query fetches and row stores)
-                    if (__hip_atomic_load(&a.serve_dev[JV_SV_LOCK], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 &&
-                        atomicCAS(&a.serve_dev[JV_SV_LOCK], 0, 1) == 0) {
-                        const int ht = __hip_atomic_load(&a.serve_host[JV_SH_TAIL], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-                        if (ht - pb > 0) {
-                            atomicMax(&a.serve_dev[JV_SV_PUBLISHED], ht);
-                            pb = ht;
-                        } else if ((++polls & 15) == 0 && __hip_atomic_load(&a.serve_host[JV_SH_STOP], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) {
-                            __hip_atomic_store(&a.serve_dev[JV_SV_STOP_SEEN], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                        __hip_atomic_store(&a.serve_dev[JV_SV_LOCK], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    if (pb - h <= 0) {
-                        const uint32_t now = (uint32_t)__builtin_amdgcn_s_memrealtime();
-                        const uint32_t last = (uint32_t)__hip_atomic_load(&a.serve_dev[JV_SV_LAST_CLAIM], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        // (signed differences: another workgroup's claim may carry a later time stamp than `now`)
-                        const bool idle = (int32_t)(now - last) > a.serve_idle_ticks && (int32_t)(now - t_idle0) > a.serve_idle_ticks;
-                        if (idle || __hip_atomic_load(&a.serve_dev[JV_SV_STOP_SEEN], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-                        // back off the longer this workgroup has had nothing to do (3 us .. 55 us): hundreds of idle
-                        // workgroups polling at full rate slow the working ones down (one query alone: 9.8 ms instead of 3.2)
-                        idle_iters++;
-                        const int naps = idle_iters < 16 ? 1 : (idle_iters < 128 ? 4 : 16);
-                        for (int z = 0; z < naps; z++) __builtin_amdgcn_s_sleep(127);
-                        continue;
-                    }
-                }
-                if (atomicCAS(&a.serve_dev[JV_SV_HEAD], h, h + 1) == h) {
-                    ticket = h;
-                    __hip_atomic_store(&a.serve_dev[JV_SV_LAST_CLAIM], (int)(uint32_t)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-            }
+            const int ticket = jv_serve_claim(a);
             ctrl[PQW_QI] = ticket;
         }
         __syncthreads();
@@ -1023,14 +984,7 @@ __global__ __launch_bounds__(JV_WAVE * W, OCC) void jv_serve_pqw_kernel(const Jv
         search_one_pqw<NCHT, CAPK, W, NL>(ix, aq, 0, smem, explog);
         __syncthreads();
     }
-    // the last workgroup out tells the host that the grid is gone (a caller that finds work pending launches it again)
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (atomicAdd(&a.serve_dev[JV_SV_EXITED], 1) == (int)gridDim.x - 1) {
-            __hip_atomic_store(&a.serve_dev[JV_SV_EXITED], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&a.serve_host[JV_SH_ALIVE], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
+    jv_serve_leave(a);
 }
 
 template <int NCHT, int CAPK, int W, int OCC, int NL = 4>

@@ -193,3 +193,53 @@ def test_query_server_under_mixed_traffic(pkg, pyoracle):
     r = gpu.search(q[3], 10, 120)
     assert np.array_equal(r.nodes[0], want.nodes[3]) and gpu.counter("served_queries") == before
     gpu.close()
+
+
+@pytest.mark.parametrize("sim,pq_M", [(0, 32), (2, 32), (1, 16)])
+def test_filtered_query_server(pkg, pyoracle, sim, pq_M):
+    """One-query calls WITH a doc filter (a filtered k-NN query's leaf search: J/JVectorReader.java:129-210, :157-163) are
+    served by the second device-resident grid (jv_kernels_pqsf.hip: the one-wave filtered pool kernel fed from a ring, the
+    filter's bits held in HBM by the filter cache): many threads, several filters in flight at once (one of them too selective
+    for the server's pool: those queries come back flagged and take the launch path), permuted sparse doc ids with deleted
+    ordinals, rerankFloor.  Every answer equals the oracle's — ids, docs, score bits, counters."""
+    import threading
+    b, bl, dg = pkg.binding, pkg.builder, pkg.datagen
+    n, d = 6000, 64
+    base = dg.splitmix_uniform(41 + sim, n, d)
+    q = dg.splitmix_uniform(42 + sim, 96, d)
+    rng = np.random.default_rng(9 + sim)
+    max_doc = 2 * n
+    ord2doc = rng.permutation(max_doc)[:n].astype(np.int32)
+    ord2doc[rng.random(n) < 0.03] = -1
+    ix = bl.build_index_cpu(base, sim, R=32, L=60, pq_M=pq_M, ord2doc=ord2doc, max_doc=max_doc)
+    gpu, orc = b.GpuIndex(ix, flags=b.DESC_FUSED_ADC), pyoracle.Oracle(b, ix)
+    filters = [b.accept_words(np.nonzero(rng.random(max_doc) < f)[0], max_doc) for f in (0.6, 0.3, 0.04)]
+    cases = [(10, 120, 0.0), (10, 300, 0.0), (5, 40, 0.55)]     # (topK, rerankK, rerankFloor)
+    want = {(fi, ci): orc.search_batch(q, k, rk, rerank_floor=fl, accept=filters[fi], accept_num_docs=max_doc)
+            for fi in range(len(filters)) for ci, (k, rk, fl) in enumerate(cases)}
+    errors = []
+
+    def worker(tid):
+        r = np.random.default_rng(tid)
+        for it in range(40):
+            fi, ci, j = int(r.integers(0, len(filters))), int(r.integers(0, len(cases))), int(r.integers(0, len(q)))
+            k, rk, fl = cases[ci]
+            got = gpu.search(q[j], k, rk, rerank_floor=fl, accept=filters[fi], accept_num_docs=max_doc)
+            w = want[fi, ci]
+            if not (np.array_equal(got.nodes[0], w.nodes[j]) and np.array_equal(got.docs[0], w.docs[j]) and
+                    np.array_equal(got.scores[0].view(np.uint32), w.scores[j].view(np.uint32)) and
+                    got.count[0] == w.count[j] and np.array_equal(got.stats[0], w.stats[j])):
+                errors.append((tid, fi, ci, j))
+                return
+
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(16)]
+    [t.start() for t in ts]
+    [t.join(timeout=120) for t in ts]
+    assert not any(t.is_alive() for t in ts), "a caller is stuck"
+    assert not errors, errors[:4]
+    served = gpu.counter("served_queries")
+    assert served > 200, served          # (the two mild filters' queries; the selective one's are redone on the launch path)
+    gpu.set_option("serve", 0)           # off: the same calls take the launch path and give the same answers
+    got = gpu.search(q[3], 10, 120, accept=filters[0], accept_num_docs=max_doc)
+    assert np.array_equal(got.nodes[0], want[0, 0].nodes[3]) and gpu.counter("served_queries") == served
+    gpu.close()
