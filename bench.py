@@ -414,15 +414,24 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         import socket
         import subprocess
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
         env = dict(os.environ)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        log("launching " + " ".join(cmd))
-        raise SystemExit(subprocess.call(cmd, env=env))
+        code = 1
+        for attempt in range(2):
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+            log("launching " + " ".join(cmd))
+            t_launch = time.time()
+            code = subprocess.call(cmd, env=env)
+            # a launcher that dies within seconds never got its ranks together (the probed port was taken in between, a
+            # rendezvous hiccup): one more try on a fresh port; anything later is the benchmark's own failure
+            if code == 0 or time.time() - t_launch > 20.0:
+                break
+            log(f"launcher exited with {code} after {time.time() - t_launch:.1f} s: retrying once on a new port")
+        raise SystemExit(code)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
