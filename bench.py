@@ -585,6 +585,21 @@ def main():
                                     "p99_ms": round(r["p99_ms"], 4)})
         except Exception as e:  # pragma: no cover - reported, never fatal for the headline number
             caller_rows = f"unavailable: {e!r}"
+    # the same pattern WITH a doc filter (a filtered k-NN query: J/JVectorReader.java:157-163): one bitset of selectivity 0.5
+    # over the doc ids on every call, every answer compared with the batch API's
+    filtered_rows = None
+    if not args.profile_mode and world == 1 and fused and isinstance(caller_rows, list):
+        try:
+            acc = binding.accept_words(np.nonzero(np.random.default_rng(5).random(eng.n) < 0.5)[0], eng.n)
+            hqf = queries[:1024].cpu().numpy()
+            want = index.search_batch(hqf, k, rk, accept=acc, accept_num_docs=eng.n).nodes
+            filtered_rows = []
+            for T in (1, 256):
+                r = hostmod.concurrent_search_bench(index, hqf, k, rk, T, 1.5, want, accept=acc, accept_num_docs=eng.n)
+                filtered_rows.append({"selectivity": 0.5, "caller_threads": T, "qps": round(r["qps"], 1), "p50_ms": round(r["p50_ms"], 4),
+                                      "p99_ms": round(r["p99_ms"], 4), "answers_differing_from_batch_api": r["mismatches"]})
+        except Exception as e:  # pragma: no cover
+            filtered_rows = f"unavailable: {e!r}"
 
     # the kernel that carries the step (csrc/jv_abi.cpp enqueue_batch): the persistent jv_search_pqp_kernel for pools beyond
     # 256 entries and wherever its register-table variant applies (PQ-32, not cosine, more than 4 x CUs queries per launch),
@@ -630,6 +645,7 @@ def main():
         "p50_latency_ms": (None if p50 is None else round(p50, 4)),
         "host_api_qps_pcie_inclusive": pcie_qps,
         "single_query_api": caller_rows,
+        "single_query_api_filtered": filtered_rows,
         "per_query": {"visited": round(t["visited"] / total_queries, 1), "expanded": round(t["expanded"] / total_queries, 1),
                       "reranked": round(t["reranked"] / total_queries, 1),
                       "algorithmic_bytes": round(bytes_total / total_queries, 1)},

@@ -102,7 +102,7 @@ int fail(int code, const char* fmt, ...) {
 //   combine / combine_leaders / combine_max_batch   group commit of concurrent jv_search calls
 //   max_contexts                         cap of per-index launch contexts (callers beyond it wait)
 //   filter_cache                         device-resident doc-filter bitsets kept per index (0 = off)
-//   serve / serve_wgs_per_cu / serve_idle_ms   device-resident query server for one-query calls (resident workgroups per CU, idle time before it leaves)
+//   serve / serve_wgs_per_cu / serve_idle_ms   device-resident query servers for one-query calls — one grid for unfiltered calls, one for calls with a doc filter (resident workgroups per CU, idle time before they leave)
 //   lazy_big_rung                        host-pointer calls enqueue the HBM-scratch rung only when a row came back flagged (it serialises batches otherwise)
 //   direct_completion                    combined one-query calls: rows land in pinned memory, every caller is woken by its own query's completion word
 //   lutr_min_queries                     launches with more queries keep the PQ look-up table in registers (-1 = 4 per CU)
