@@ -34,6 +34,7 @@ hipError_t jvk_launch_search_lds(const JvIndexDev* ix, const JvSearchArgs* a, in
 hipError_t jvk_launch_search_pqf(const JvIndexDev* ix, const JvSearchArgs* a, int lds_bytes, hipStream_t s);
 hipError_t jvk_launch_search_big(const JvIndexDev* ix, const JvSearchArgs* a, int pq, int blocks, int lds_bytes,
                                  int force_all, int qlds, hipStream_t s);
+hipError_t jvk_launch_search_big_lutg(const JvIndexDev* ix, const JvSearchArgs* a, int blocks, int lds_bytes, int force_all, hipStream_t stream);
 hipError_t jvk_launch_score_ordinals(const JvIndexDev* ix, const float* d_query, const int32_t* d_ordinals,
                                      int count, float* d_out, hipStream_t s);
 hipError_t jvk_launch_merge_topk(const int32_t* d_docs, const float* d_scores, int nq, int lists, int k,
@@ -239,6 +240,8 @@ struct DeviceScratch {
     uint32_t* big_visited = nullptr;  // every index carves [its blocks][its ceil(n / 32) words] out of this arena
     int64_t* big_cand = nullptr;      // ... and [its blocks][its candidate slots] out of this one
     size_t vis_bytes = 0, cand_bytes = 0;
+    float* lut = nullptr;             // PQ tables too large for LDS: [blocks][pq_M][256] of the launch in flight
+    size_t lut_bytes = 0;
     std::atomic<int64_t> bytes{0};
 };
 DeviceScratch g_scratch[64];
@@ -402,6 +405,7 @@ struct Geometry {
     int lds_fast, lds_big;
     bool fast_ok;
     bool pool;
+    bool lutg;  // the PQ look-up table does not fit LDS: HBM-scratch rung only, table in HBM scratch too
 };
 
 // LDS carve of the fast path (must mirror search_one in jv_kernels.hip)
@@ -410,6 +414,10 @@ Geometry plan_geometry(const jv_index* ix, int rk, bool pool_ok, int force_slots
     const JvIndexDev& d = ix->dev;
     const bool pq = d.pq_M > 0;
     int fixed = d.nch * 64 * 4 + JV_TODO * 16 + (pq ? d.pq_M * 256 * 4 + d.nch * 64 * 4 : 0) + (tracker ? JV_TRACKER_LDS : 0);
+    // pq_M KB of table beyond the LDS (the reference's default for d >= 768 is 192 subspaces, J/JVectorIndexQuantization.java:428-446):
+    // the HBM-scratch rung keeps the table in HBM scratch as well
+    g.lutg = pq && fixed > kMaxLds;
+    if (g.lutg) fixed -= d.pq_M * 256 * 4;
     g.lds_big = fixed;
     int64_t hs = OPT(ix, OPT_LDS_VISITED_SLOTS);
     int64_t cc = OPT(ix, OPT_LDS_CANDIDATES);
@@ -437,7 +445,7 @@ Geometry plan_geometry(const jv_index* ix, int rk, bool pool_ok, int force_slots
         g.hash_slots >>= 1;
         if (!g.pool && cc <= 0) g.cand_cap = std::max(rk, (g.hash_slots / 4) * 3) & ~1;
     }
-    g.fast_ok = total() <= kMaxLds && fixed <= kMaxLds;
+    g.fast_ok = !g.lutg && total() <= kMaxLds && fixed <= kMaxLds;
     g.lds_fast = (int)total();
     return g;
 }
@@ -849,6 +857,24 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
         a.big_cand = sc.big_cand;
         a.big_cand_cap = my_cap;
         a.res_cap = (rk + 1) & ~1;  // the rung runs the two-queue form: rerankK results, the rest of my_cap are candidates
+        if (g.lutg) {
+            // the table in HBM scratch: 1 KB per subspace per resident workgroup (at most 256 of them: 48 MB at pq_M = 192)
+            my_blocks = std::min(my_blocks, 256);
+            const size_t need = (size_t)my_blocks * (size_t)ix->dev.pq_M * 256 * sizeof(float);
+            if (need > sc.lut_bytes) {
+                HIPCHK(hipEventSynchronize(sc.last_use));
+                if (sc.lut) HIPCHK(jv_free(sc.lut));
+                sc.lut = nullptr;
+                sc.lut_bytes = 0;
+                HIPCHK(hipMalloc((void**)&sc.lut, need));
+                sc.lut_bytes = need;
+            }
+            a.lut_scratch = sc.lut;
+            HIPCHK(hipStreamWaitEvent(stream, sc.last_use, 0));
+            HIPCHK(jvk_launch_search_big_lutg(&ix->dev, &a, my_blocks, (g.lds_big + 15) & ~15, force_big ? 1 : 0, stream));
+            HIPCHK(hipEventRecord(sc.last_use, stream));
+            return JV_OK;
+        }
         HIPCHK(hipStreamWaitEvent(stream, sc.last_use, 0));
         // first with both queues in LDS (every slot the workgroup's LDS has left; the visited set is the HBM bitset) ...
         const int fixed_lds = (g.lds_big + 15) & ~15;

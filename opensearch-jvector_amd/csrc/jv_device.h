@@ -73,6 +73,7 @@ struct JvSearchArgs {
     int64_t* big_cand;       // [blocks][big_cand_cap]
     int32_t big_cand_cap;
     int32_t* work_counter;   // big path: dynamic query dequeue
+    float* lut_scratch;      // big path, PQ tables too large for LDS (the reference's default 192 subspaces at d >= 768): [blocks][pq_M][256] in HBM
     int32_t visit_limit;     // > 0: stop (flag EARLY) once visited + expanded reaches it (Lucene KnnCollector.visitLimit)
     int32_t retry_only;      // later launches: 1 = walk the flag array and redo pool/log overflows only; 2 = the same, last on-chip rung (filtered: never skips on the selectivity estimate)
     int32_t* retry_counter;  // escalation launches: flag-chunk dequeue counter (zeroed per call, one per rung)

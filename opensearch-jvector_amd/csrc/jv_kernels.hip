@@ -28,7 +28,9 @@
 // BIG: visited set = bitset in HBM scratch (exact whatever the search touches).  QLDS (with BIG): both queues still live
 // in LDS (as many candidate slots as the workgroup's LDS holds) — a pop is an arg-max scan over the queue, so on-chip
 // queues are ~20x faster than the HBM ones; only a query that outgrows them as well takes the HBM-queue form.
-template <bool PQ, bool BIG, bool POOL, int NCHT, bool QLDS = false>
+// LUTG: the PQ look-up table lives in this workgroup's HBM scratch instead of LDS (pq_M * 1 KB beyond the LDS: the reference's
+// default 192 subspaces for d >= 768, J/JVectorIndexQuantization.java:428-446) — same arithmetic, gathers served by L1 / L2
+template <bool PQ, bool BIG, bool POOL, int NCHT, bool QLDS = false, bool LUTG = false>
 __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, unsigned char* smem,
                            int64_t* big_cand, uint32_t* big_bits) {
     const int lane = threadIdx.x;
@@ -57,8 +59,12 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
     float* lut = nullptr;
     float* qc_lds = nullptr;  // PQ: the centred query q' = q - globalCentroid
     if (PQ) {
-        lut = (float*)(smem + off);
-        off += (size_t)ix.pq_M * 256 * sizeof(float);
+        if (LUTG) {
+            lut = a.lut_scratch + (size_t)blockIdx.x * (size_t)ix.pq_M * 256;
+        } else {
+            lut = (float*)(smem + off);
+            off += (size_t)ix.pq_M * 256 * sizeof(float);
+        }
         qc_lds = (float*)(smem + off);
         off += (size_t)ix.nch * 64 * sizeof(float);
     }
@@ -112,6 +118,11 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
         }
         __syncthreads();
         build_lut<16>(ix, qc_lds, lut, lane);
+        if (LUTG) {
+            // the table was written through to L2; the L1 may still hold lines of the PREVIOUS query's table at these addresses
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
         __syncthreads();
     }
     // exact-provider path carries the Lucene MIP x2 wrap (J/JVectorReader.java:220-239,359-364);
@@ -1477,7 +1488,7 @@ __global__ __launch_bounds__(JV_WAVE) void jv_build_search_kernel(const JvIndexD
 
 // Big path: queues and visited bitset in HBM scratch; each resident workgroup dequeues the queries the
 // fast path flagged as overflowed.  Exact in all cases the fast path cannot hold on chip.
-template <bool PQ, int NCHT, bool QLDS = false>
+template <bool PQ, int NCHT, bool QLDS = false, bool LUTG = false>
 __global__ __launch_bounds__(JV_WAVE) void jv_search_big_kernel(const JvIndexDev ix, const JvSearchArgs a,
                                                                  const int force_all) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1496,7 +1507,7 @@ __global__ __launch_bounds__(JV_WAVE) void jv_search_big_kernel(const JvIndexDev
         while (m) {
             const int j = __ffsll((long long)m) - 1;
             m &= m - 1ull;
-            search_one<PQ, true, false, NCHT, QLDS>(ix, a, base + j, smem, my_cand, my_bits);
+            search_one<PQ, true, false, NCHT, QLDS, LUTG>(ix, a, base + j, smem, my_cand, my_bits);
             __syncthreads();
         }
     }
@@ -1635,6 +1646,9 @@ static const lds_kernel_t g_pqff_kernels[2][2][4] = {{JV_PQFF_ROW(8, false), JV_
 static const big_kernel_t g_big_kernels[2][4] = {JV_ROW(jv_search_big_kernel, false), JV_ROW(jv_search_big_kernel, true)};
 #define JV_BIGQ_ROW(PQ) { jv_search_big_kernel<PQ, 0, true>, jv_search_big_kernel<PQ, 2, true>, jv_search_big_kernel<PQ, 12, true>, jv_search_big_kernel<PQ, 24, true> }
 static const big_kernel_t g_bigq_kernels[2][4] = {JV_BIGQ_ROW(false), JV_BIGQ_ROW(true)};  // queues in LDS, visited bitset in HBM
+// PQ look-up table in HBM scratch (queues and visited bitset in HBM too): pq_M beyond what LDS holds
+static const big_kernel_t g_bigg_kernels[4] = {jv_search_big_kernel<true, 0, false, true>, jv_search_big_kernel<true, 2, false, true>,
+                                               jv_search_big_kernel<true, 12, false, true>, jv_search_big_kernel<true, 24, false, true>};
 
 static int nch_slot(const JvIndexDev* ix) {
     if (ix->nvq_M > 0) return 0;  // the NVQ decoder lives in the "any d" instances only (score_rows)
@@ -1709,6 +1723,12 @@ extern "C" hipError_t jvk_launch_search_big(const JvIndexDev* ix, const JvSearch
                                             int lds_bytes, int force_all, int qlds, hipStream_t stream) {
     if (a->nq <= 0) return hipSuccess;
     (qlds ? g_bigq_kernels : g_big_kernels)[pq ? 1 : 0][nch_slot(ix)]<<<blocks, JV_WAVE, lds_bytes, stream>>>(*ix, *a, force_all);
+    return hipGetLastError();
+}
+extern "C" hipError_t jvk_launch_search_big_lutg(const JvIndexDev* ix, const JvSearchArgs* a, int blocks, int lds_bytes, int force_all,
+                                                 hipStream_t stream) {
+    if (a->nq <= 0) return hipSuccess;
+    g_bigg_kernels[nch_slot(ix)]<<<blocks, JV_WAVE, lds_bytes, stream>>>(*ix, *a, force_all);
     return hipGetLastError();
 }
 

@@ -668,3 +668,31 @@ def test_rerank_floor_above_all_scores_with_tied_best(pkg, pyoracle, seed):
             want = orc.search_batch(q2, k, rk, rerank_floor=50.0)
             _assert_same(gpu.search_batch(q2, k, rk, rerank_floor=50.0), want, f"dups flags={flags} k={k} rk={rk}")
         gpu.close()
+
+
+@pytest.mark.parametrize("sim", [0, 1, 2])
+def test_reference_default_subspaces_768d(pkg, pyoracle, sim):
+    """The reference's DEFAULT product quantisation for 768-d fields is 192 subspaces (J/JVectorIndexQuantization.java:428-446:
+    d * 0.25): a 192 KB look-up table per query, more than a workgroup's LDS.  Such fields run on the HBM-scratch rung with
+    the table in HBM scratch as well (jv_search_big_kernel<.., LUTG>) — ids, score bits and counters still equal the oracle's,
+    with and without a doc filter, with rerankFloor."""
+    b, bl, dg = pkg.binding, pkg.builder, pkg.datagen
+    n, d, M = 1200, 768, 192
+    base = dg.splitmix_uniform(61 + sim, n, d)
+    q = dg.splitmix_uniform(62 + sim, 12, d)
+    ix = bl.build_index_cpu(base, sim, R=16, L=40, pq_M=M)
+    assert ix.pq_M == M
+    orc = pyoracle.Oracle(b, ix)
+    rng = np.random.default_rng(sim)
+    words = b.accept_words(np.nonzero(rng.random(n) < 0.5)[0], n)
+    for flags in (0, b.DESC_FUSED_ADC):
+        gpu = b.GpuIndex(ix, flags=flags)
+        for k, rk in ((10, 40), (5, 5), (10, 150)):
+            _assert_same(gpu.search_batch(q, k, rk), orc.search_batch(q, k, rk), f"sim={sim} flags={flags} k={k} rk={rk}")
+        _assert_same(gpu.search_batch(q, 10, 60, accept=words, accept_num_docs=n),
+                     orc.search_batch(q, 10, 60, accept=words, accept_num_docs=n), f"sim={sim} flags={flags} filtered")
+        _assert_same(gpu.search_batch(q, 10, 50, rerank_floor=0.55), orc.search_batch(q, 10, 50, rerank_floor=0.55), f"sim={sim} flags={flags} floor")
+        one = gpu.search(q[0], 10, 40)
+        want = orc.search_batch(q[:1], 10, 40)
+        assert np.array_equal(one.nodes[0], want.nodes[0]) and np.array_equal(one.stats[0], want.stats[0])
+        gpu.close()
