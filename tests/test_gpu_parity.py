@@ -670,14 +670,15 @@ def test_rerank_floor_above_all_scores_with_tied_best(pkg, pyoracle, seed):
         gpu.close()
 
 
-@pytest.mark.parametrize("sim", [0, 1, 2])
-def test_reference_default_subspaces_768d(pkg, pyoracle, sim):
+@pytest.mark.parametrize("sim,d,M", [(0, 768, 192), (1, 768, 192), (2, 768, 192), (0, 256, 100), (2, 320, 100)])
+def test_reference_default_subspaces_768d(pkg, pyoracle, sim, d, M):
     """The reference's DEFAULT product quantisation for 768-d fields is 192 subspaces (J/JVectorIndexQuantization.java:428-446:
     d * 0.25): a 192 KB look-up table per query, more than a workgroup's LDS.  Such fields run on the HBM-scratch rung with
     the table in HBM scratch as well (jv_search_big_kernel<.., LUTG>) — ids, score bits and counters still equal the oracle's,
     with and without a doc filter, with rerankFloor."""
     b, bl, dg = pkg.binding, pkg.builder, pkg.datagen
-    n, d, M = 1200, 768, 192
+    # (256 < d <= 400 defaults to 100 subspaces of uneven width: a 100 KB table that still fits LDS, R x 8 lanes per block)
+    n = 1200
     base = dg.splitmix_uniform(61 + sim, n, d)
     q = dg.splitmix_uniform(62 + sim, 12, d)
     ix = bl.build_index_cpu(base, sim, R=16, L=40, pq_M=M)
