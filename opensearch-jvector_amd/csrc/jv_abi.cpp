@@ -34,7 +34,7 @@ hipError_t jvk_launch_search_lds(const JvIndexDev* ix, const JvSearchArgs* a, in
 hipError_t jvk_launch_search_pqf(const JvIndexDev* ix, const JvSearchArgs* a, int lds_bytes, hipStream_t s);
 hipError_t jvk_launch_search_big(const JvIndexDev* ix, const JvSearchArgs* a, int pq, int blocks, int lds_bytes,
                                  int force_all, int qlds, hipStream_t s);
-hipError_t jvk_launch_search_big_lutg(const JvIndexDev* ix, const JvSearchArgs* a, int blocks, int lds_bytes, int force_all, hipStream_t stream);
+hipError_t jvk_launch_search_big_lutg(const JvIndexDev* ix, const JvSearchArgs* a, int blocks, int lds_bytes, int force_all, int qlds, hipStream_t stream);
 hipError_t jvk_launch_score_ordinals(const JvIndexDev* ix, const float* d_query, const int32_t* d_ordinals,
                                      int count, float* d_out, hipStream_t s);
 hipError_t jvk_launch_merge_topk(const int32_t* d_docs, const float* d_scores, int nq, int lists, int k,
@@ -858,8 +858,8 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
         a.big_cand_cap = my_cap;
         a.res_cap = (rk + 1) & ~1;  // the rung runs the two-queue form: rerankK results, the rest of my_cap are candidates
         if (g.lutg) {
-            // the table in HBM scratch: 1 KB per subspace per resident workgroup (at most 256 of them: 48 MB at pq_M = 192)
-            my_blocks = std::min(my_blocks, 256);
+            // the table in HBM scratch: 1 KB per subspace per resident workgroup (at most 1 024 of them: 192 MB at pq_M = 192)
+            my_blocks = std::min(my_blocks, 1024);
             const size_t need = (size_t)my_blocks * (size_t)ix->dev.pq_M * 256 * sizeof(float);
             if (need > sc.lut_bytes) {
                 HIPCHK(hipEventSynchronize(sc.last_use));
@@ -871,7 +871,19 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
             }
             a.lut_scratch = sc.lut;
             HIPCHK(hipStreamWaitEvent(stream, sc.last_use, 0));
-            HIPCHK(jvk_launch_search_big_lutg(&ix->dev, &a, my_blocks, (g.lds_big + 15) & ~15, force_big ? 1 : 0, stream));
+            // as below: first with both queues in LDS (the table is not there, so nearly all of it is free: four resident
+            // queries per CU), then in HBM for what outgrew them
+            const int fixed_g = (g.lds_big + 15) & ~15;
+            const int qslots_g = (kMaxLds / 4 - fixed_g - 256) / 8;
+            if (qslots_g >= a.res_cap + 4 * rk + 256 && OPT(ix, OPT_NO_ESCALATION) == 0) {
+                JvSearchArgs aq = a;
+                aq.cand_cap = qslots_g - aq.res_cap;
+                aq.work_counter = c->work_counter + 7;
+                HIPCHK(jvk_launch_search_big_lutg(&ix->dev, &aq, my_blocks, fixed_g + qslots_g * 8, force_big ? 1 : 0, 1, stream));
+                HIPCHK(jvk_launch_search_big_lutg(&ix->dev, &a, my_blocks, fixed_g, 0, 0, stream));
+            } else {
+                HIPCHK(jvk_launch_search_big_lutg(&ix->dev, &a, my_blocks, fixed_g, force_big ? 1 : 0, 0, stream));
+            }
             HIPCHK(hipEventRecord(sc.last_use, stream));
             return JV_OK;
         }

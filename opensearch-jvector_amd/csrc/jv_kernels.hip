@@ -1647,8 +1647,10 @@ static const big_kernel_t g_big_kernels[2][4] = {JV_ROW(jv_search_big_kernel, fa
 #define JV_BIGQ_ROW(PQ) { jv_search_big_kernel<PQ, 0, true>, jv_search_big_kernel<PQ, 2, true>, jv_search_big_kernel<PQ, 12, true>, jv_search_big_kernel<PQ, 24, true> }
 static const big_kernel_t g_bigq_kernels[2][4] = {JV_BIGQ_ROW(false), JV_BIGQ_ROW(true)};  // queues in LDS, visited bitset in HBM
 // PQ look-up table in HBM scratch (queues and visited bitset in HBM too): pq_M beyond what LDS holds
-static const big_kernel_t g_bigg_kernels[4] = {jv_search_big_kernel<true, 0, false, true>, jv_search_big_kernel<true, 2, false, true>,
-                                               jv_search_big_kernel<true, 12, false, true>, jv_search_big_kernel<true, 24, false, true>};
+static const big_kernel_t g_bigg_kernels[2][4] = {{jv_search_big_kernel<true, 0, false, true>, jv_search_big_kernel<true, 2, false, true>,
+                                                   jv_search_big_kernel<true, 12, false, true>, jv_search_big_kernel<true, 24, false, true>},
+                                                  {jv_search_big_kernel<true, 0, true, true>, jv_search_big_kernel<true, 2, true, true>,
+                                                   jv_search_big_kernel<true, 12, true, true>, jv_search_big_kernel<true, 24, true, true>}};  // [queues in LDS]
 
 static int nch_slot(const JvIndexDev* ix) {
     if (ix->nvq_M > 0) return 0;  // the NVQ decoder lives in the "any d" instances only (score_rows)
@@ -1678,6 +1680,8 @@ extern "C" hipError_t jvk_set_max_lds(int bytes) {
                 e = hipFuncSetAttribute((const void*)g_big_kernels[a][s], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             if (e == hipSuccess)
                 e = hipFuncSetAttribute((const void*)g_bigq_kernels[a][s], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute((const void*)g_bigg_kernels[a][s], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             if (e != hipSuccess) return e;
         }
     }
@@ -1726,9 +1730,9 @@ extern "C" hipError_t jvk_launch_search_big(const JvIndexDev* ix, const JvSearch
     return hipGetLastError();
 }
 extern "C" hipError_t jvk_launch_search_big_lutg(const JvIndexDev* ix, const JvSearchArgs* a, int blocks, int lds_bytes, int force_all,
-                                                 hipStream_t stream) {
+                                                 int qlds, hipStream_t stream) {
     if (a->nq <= 0) return hipSuccess;
-    g_bigg_kernels[nch_slot(ix)]<<<blocks, JV_WAVE, lds_bytes, stream>>>(*ix, *a, force_all);
+    g_bigg_kernels[qlds ? 1 : 0][nch_slot(ix)]<<<blocks, JV_WAVE, lds_bytes, stream>>>(*ix, *a, force_all);
     return hipGetLastError();
 }
 
