@@ -55,7 +55,7 @@ hipError_t jvk_launch_search_pqp(const JvIndexDev* ix, const JvSearchArgs* a, in
 hipError_t jvk_pqw_set_max_lds(int bytes);
 int jvk_pqw_ok(const JvIndexDev* ix, int cap);
 int jvk_pqw_waves(const JvIndexDev* ix);
-int jvk_pqw_lds_rows(int variant);
+int jvk_pqw_lds_rows(const JvIndexDev* ix, int variant);
 int jvk_pqw_blocks_per_cu(const JvIndexDev* ix, int cap, int lds_bytes, int variant);
 hipError_t jvk_launch_search_pqw(const JvIndexDev* ix, const JvSearchArgs* a, int lds_bytes, int blocks, int variant, hipStream_t s);
 // device-resident query server (jv_kernels_pqs.hip)
@@ -517,12 +517,12 @@ int plan_pqw_lds(const jv_index* ix, JvSearchArgs& x, int variant) {
     const int pool_b = (x.cand_cap + 1) * 8;
     const int rr_b = qc_b + Wn * JV_TODO * 8 + (x.cand_cap + 64) * 8;
     x.pqw_lut_off = (std::max(pool_b, qc_b) + 15) & ~15;  // table rows kept in LDS, behind the pool / the centred query
-    const int lut_end = x.pqw_lut_off + Wn * jvk_pqw_lds_rows(variant) * 1024;
+    const int lut_end = x.pqw_lut_off + Wn * jvk_pqw_lds_rows(&ix->dev, variant) * 1024;
     const int front = (std::max(std::max(16384, lut_end), std::max(qc_b, rr_b)) + 15) & ~15;
     x.pqp_pool_off = 0;
     x.pqp_qc_off = 0;
     x.pqp_scratch_off = front;
-    x.pqp_lds_bytes = front + Wn * 256 + 64 + 128;  // (+ the diagnostic build's phase accumulators)
+    x.pqp_lds_bytes = front + Wn * 256 + 64 + 128 + 64;  // (ctrl words, the diagnostic build's phase accumulators, the waves' visited counts)
     return x.pqp_lds_bytes;
 }
 
@@ -615,7 +615,36 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
     a.dbg = (int64_t*)(uintptr_t)OPT(ix, OPT_DBG_PTR);  // always 0 unless a diagnostic run set it
     const bool force_big = OPT(ix, OPT_FORCE_BIG) != 0 || !g.fast_ok;
     HIPCHK(hipMemsetAsync(c->work_counter, 0, 16 * sizeof(int32_t), stream));
-    if (phase != 2) {
+    // PQ tables beyond the LDS (g.lutg: the reference's default 192 subspaces): on the fused layout the several-waves kernel
+    // takes them first — twelve waves hold the table in registers + LDS rows — and the HBM-scratch rung (table in HBM) only
+    // redoes what comes back flagged; everything else about such shapes (filters, thresholds, cosine) is that rung's alone
+    bool wide_first = false;
+    if (phase != 2 && g.lutg && OPT(ix, OPT_FORCE_BIG) == 0 && OPT(ix, OPT_NO_PQW) == 0 && OPT(ix, OPT_NO_PQF) == 0 && OPT(ix, OPT_NO_PQP) == 0 &&
+        d_accept == nullptr && thr <= 0.0f && !ix->build_client && jvk_pqw_ok(&ix->dev, rk + 64 + ix->dev.R) && nq >= OPT(ix, OPT_PQW_MIN_QUERIES)) {
+        JvSearchArgs ap = a;
+        ap.cand_cap = rk + 64 + ix->dev.R;
+        ap.pqp_log_cap = (12 * rk + 1024 + 3) & ~3;
+        const int lds = plan_pqw_lds(ix, ap, 0);
+        if (lds <= kMaxLds) {
+            int blocks = ix->cu_count * jvk_pqw_blocks_per_cu(&ix->dev, ap.cand_cap, lds, 0);
+            if (blocks > nq) blocks = nq;
+            const size_t need = (size_t)blocks * (size_t)ap.pqp_log_cap;
+            if (need > c->pqp_log_ints) {
+                if (c->pqp_log) HIPCHK(jv_free(c->pqp_log));
+                c->pqp_log = nullptr;
+                c->pqp_log_ints = 0;
+                HIPCHK(hipMalloc((void**)&c->pqp_log, need * sizeof(int32_t)));
+                c->pqp_log_ints = need;
+            }
+            ap.pqp_log = c->pqp_log;
+            ap.pqp_counter = c->work_counter + 6;
+            servers_yield_lds(ix->device, lds);
+            HIPCHK(jvk_launch_search_pqw(&ix->dev, &ap, lds, blocks, 0, stream));
+            ix->launches[LAUNCH_PQW]++;
+            wide_first = true;
+        }
+    }
+    if (phase != 2 && !wide_first) {
     // headline path: PQ + fused layout + single pool + flat graph -> specialised kernel without an in-loop
     // visited set (jv_kernels.hip "PQF"); anything it cannot hold is flagged and falls through to the ladder
     bool pqf = false;
@@ -842,7 +871,7 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
         }
     }
     }
-    if (phase == 1 && !force_big) {
+    if (phase == 1 && (!force_big || wide_first)) {
         if (big_deferred) *big_deferred = true;
         return JV_OK;
     }
@@ -879,10 +908,11 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
                 JvSearchArgs aq = a;
                 aq.cand_cap = qslots_g - aq.res_cap;
                 aq.work_counter = c->work_counter + 7;
-                HIPCHK(jvk_launch_search_big_lutg(&ix->dev, &aq, my_blocks, fixed_g + qslots_g * 8, force_big ? 1 : 0, 1, stream));
+                const int all = (force_big && !wide_first && phase != 2) ? 1 : 0;  // (after the several-waves launch, or in phase 2: flagged rows only)
+                HIPCHK(jvk_launch_search_big_lutg(&ix->dev, &aq, my_blocks, fixed_g + qslots_g * 8, all, 1, stream));
                 HIPCHK(jvk_launch_search_big_lutg(&ix->dev, &a, my_blocks, fixed_g, 0, 0, stream));
             } else {
-                HIPCHK(jvk_launch_search_big_lutg(&ix->dev, &a, my_blocks, fixed_g, force_big ? 1 : 0, 0, stream));
+                HIPCHK(jvk_launch_search_big_lutg(&ix->dev, &a, my_blocks, fixed_g, (force_big && !wide_first && phase != 2) ? 1 : 0, 0, stream));
             }
             HIPCHK(hipEventRecord(sc.last_use, stream));
             return JV_OK;
@@ -1150,7 +1180,7 @@ int serve_query(jv_index* ix, const float* query, int32_t topK, int32_t rerankK,
         return 1;
     if (topK < 1 || topK > JV_SERVE_TOPK_MAX || ix->dev.pq_M <= 0 || !ix->dev.pq_fused || ix->build_client) return 1;
     if (kind == 0) {
-        if (OPT(ix, OPT_NO_PQW) != 0 || !jvk_pqw_ok(&ix->dev, cap)) return 1;
+        if (OPT(ix, OPT_NO_PQW) != 0 || !jvk_pqw_ok(&ix->dev, cap) || !(ix->dev.pq_M == 32 || ix->dev.pq_M == 64)) return 1;  // (server instances: two / four waves)
     } else {
         // the shapes the filtered pool kernel takes (enqueue_batch): single-pass fused blocks, flat graph, ordinals below 2^29
         const JvIndexDev& dv = ix->dev;

@@ -68,11 +68,11 @@ __device__ __forceinline__ int64_t pqw_key_min() {
 }
 
 // ctrl words (ints) behind the exchange area
-enum { PQW_C = 0, PQW_C2 = 1, PQW_WHY = 2, PQW_NP = 3, PQW_NEXP = 4, PQW_EXPANDED = 5, PQW_QI = 6, PQW_AGAIN = 7, PQW_CNT = 8 /* [W <= 4] */, PQW_C3 = 12, PQW_C4 = 13 };
+enum { PQW_C = 0, PQW_C2 = 1, PQW_WHY = 2, PQW_NP = 3, PQW_NEXP = 4, PQW_EXPANDED = 5, PQW_QI = 6, PQW_AGAIN = 7, PQW_C3 = 12, PQW_C4 = 13, PQW_CNT = 48 /* [W <= 16]: behind the diagnostic build's accumulators */ };
 
 // NCHT: row length in 64-float chunks known at compile time (rerank), 0 = any d
 // CAPK: pool capacity class: 0 -> <= 512 entries, 1 -> <= 1 024, 2 -> <= 2 048
-// W:    waves per query = pq_M / 16 (1, 2 or 4)
+// W:    waves per query = pq_M / 16 (2, 4; 12 = the reference's default 192 subspaces for 768-d .. 1 536-d fields)
 // NL:   the first NL of a wave's 16 subspaces keep their table rows in LDS (plain gathers) instead of registers: every
 //       look-up served from LDS saves four ds_bpermute — the LDS unit is this kernel's busiest resource — and four VGPRs
 template <int NCHT, int CAPK, int W, int NL>
@@ -181,11 +181,18 @@ __device__ void search_one_pqw(const JvIndexDev& ix, const JvSearchArgs& a, cons
     // chunk sums of lane l's node -> raw distance / dot product: adjacent-pair tree over the W chunks (lanes_tree_sum)
     auto combine = [&](float s0, int l) -> float {
         if (W == 1) return s0;
-        const float c1 = xchg[64 + l];
-        if (W == 2) return s0 + c1;
-        const float c2 = xchg[128 + l];
-        const float c3 = W == 4 ? xchg[192 + l] : 0.0f;
-        return (s0 + c1) + (c2 + c3);
+        // the W chunk sums padded with +0.0f to the next power of two, adjacent pairs first — what lanes_tree_sum does over
+        // next_pow2(W) lanes (the padding adds are kept: x + 0.0f is not x for x = -0.0f)
+        constexpr int PW = W <= 2 ? 2 : W <= 4 ? 4 : W <= 8 ? 8 : 16;
+        float c[PW];
+        c[0] = s0;
+#pragma unroll
+        for (int w = 1; w < PW; w++) c[w] = w < W ? xchg[w * 64 + l] : 0.0f;
+#pragma unroll
+        for (int span = 1; span < PW; span <<= 1)
+#pragma unroll
+            for (int w = 0; w < PW; w += 2 * span) c[w] = c[w] + c[w + span];
+        return c[0];
     };
 
     // ---- the pool: sorted descending; bit 0 of a key = "not expanded yet"; slots [np, cap] hold the minimum key ----
@@ -677,7 +684,7 @@ __device__ void search_one_pqw(const JvIndexDev& ix, const JvSearchArgs& a, cons
     expanded = __builtin_amdgcn_readfirstlane(ctrl[PQW_EXPANDED]);
 
     // the pool moves to registers (chunk t to wave t % W) so that the whole LDS allocation can serve as the hash set
-    constexpr int PCH = 32 / W;
+    constexpr int PCH = (32 + W - 1) / W;
     int PL[PCH], PH[PCH];
     if (why == 0) {
 #pragma unroll
