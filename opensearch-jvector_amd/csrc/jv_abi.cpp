@@ -644,6 +644,7 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
             wide_first = true;
         }
     }
+    bool first_ran = wide_first;  // a pool kernel has run: the rungs below redo flagged rows only
     if (phase != 2 && !wide_first) {
     // headline path: PQ + fused layout + single pool + flat graph -> specialised kernel without an in-loop
     // visited set (jv_kernels.hip "PQF"); anything it cannot hold is flagged and falls through to the ladder
@@ -673,7 +674,9 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
     //  kernel 1.33 M / 0.90 M / 0.27 M / 37 k QPS, this kernel's register-table variant 1.64 M / 1.07 M / 0.68 M / 227 k)
     const bool pqp_filt = filtered && pqf_shape && ix->dev.n < (1 << 29) &&
                           (rk + 64 + ix->dev.R > 256 || OPT(ix, OPT_LUTR_MIN_QUERIES) == 0 || lutr_applies);
-    if (!force_big && (pqp_plain || pqp_filt) && pqf_index && rk + 64 + ix->dev.R <= jvk_pqp_max_entries() && OPT(ix, OPT_NO_PQF) == 0 &&
+    // (shapes whose table leaves the GENERIC kernel no room — g.fast_ok false, e.g. PQ-128 at wide beams — still run the
+    //  several-waves kernel, which keeps the table in registers + LDS rows)
+    if ((!force_big || (OPT(ix, OPT_FORCE_BIG) == 0 && !g.lutg && pqw_applies)) && (pqp_plain || pqp_filt) && pqf_index && rk + 64 + ix->dev.R <= jvk_pqp_max_entries() && OPT(ix, OPT_NO_PQF) == 0 &&
         OPT(ix, OPT_NO_PQP) == 0) {
         JvSearchArgs ap = a;
         if (filtered && a.accept_stride == 0 && ix->dev.ord2doc && nq >= 16) {
@@ -849,6 +852,7 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
         }
     }
     if (pqf && OPT(ix, OPT_PQF_ONLY) != 0) return JV_OK;
+    first_ran = first_ran || pqf;
     if (!force_big) {
         if (!pqf) {
             HIPCHK(jvk_launch_search_lds(&ix->dev, &a, pq ? 1 : 0, g.pool ? 1 : 0, ix->build_client ? 2 : 0, g.lds_fast, stream));
@@ -871,7 +875,7 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
         }
     }
     }
-    if (phase == 1 && (!force_big || wide_first)) {
+    if (phase == 1 && (!force_big || first_ran)) {
         if (big_deferred) *big_deferred = true;
         return JV_OK;
     }
@@ -908,16 +912,19 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
                 JvSearchArgs aq = a;
                 aq.cand_cap = qslots_g - aq.res_cap;
                 aq.work_counter = c->work_counter + 7;
-                const int all = (force_big && !wide_first && phase != 2) ? 1 : 0;  // (after the several-waves launch, or in phase 2: flagged rows only)
+                const int all = (force_big && !first_ran && phase != 2) ? 1 : 0;  // (after the several-waves launch, or in phase 2: flagged rows only)
                 HIPCHK(jvk_launch_search_big_lutg(&ix->dev, &aq, my_blocks, fixed_g + qslots_g * 8, all, 1, stream));
                 HIPCHK(jvk_launch_search_big_lutg(&ix->dev, &a, my_blocks, fixed_g, 0, 0, stream));
             } else {
-                HIPCHK(jvk_launch_search_big_lutg(&ix->dev, &a, my_blocks, fixed_g, (force_big && !wide_first && phase != 2) ? 1 : 0, 0, stream));
+                HIPCHK(jvk_launch_search_big_lutg(&ix->dev, &a, my_blocks, fixed_g, (force_big && !first_ran && phase != 2) ? 1 : 0, 0, stream));
             }
             HIPCHK(hipEventRecord(sc.last_use, stream));
             return JV_OK;
         }
         HIPCHK(hipStreamWaitEvent(stream, sc.last_use, 0));
+        // (every row when nothing ran before this rung; flagged rows only behind a pool kernel, and in phase 2 — whose phase 1
+        //  either ran one or, forced here, did everything itself)
+        const int all_rows = (force_big && !first_ran && phase != 2) ? 1 : 0;
         // first with both queues in LDS (every slot the workgroup's LDS has left; the visited set is the HBM bitset) ...
         const int fixed_lds = (g.lds_big + 15) & ~15;
         const int qslots = (kMaxLds - fixed_lds) / 8;
@@ -925,11 +932,11 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
             JvSearchArgs aq = a;
             aq.cand_cap = qslots - aq.res_cap;
             aq.work_counter = c->work_counter + 7;
-            HIPCHK(jvk_launch_search_big(&ix->dev, &aq, pq ? 1 : 0, my_blocks, kMaxLds, force_big ? 1 : 0, 1, stream));
+            HIPCHK(jvk_launch_search_big(&ix->dev, &aq, pq ? 1 : 0, my_blocks, kMaxLds, all_rows, 1, stream));
             // ... then, for what outgrew them (and for the rerankFloor corner that needs the admission log), in HBM
             HIPCHK(jvk_launch_search_big(&ix->dev, &a, pq ? 1 : 0, my_blocks, g.lds_big, 0, 0, stream));
         } else {
-            HIPCHK(jvk_launch_search_big(&ix->dev, &a, pq ? 1 : 0, my_blocks, g.lds_big, force_big ? 1 : 0, 0, stream));
+            HIPCHK(jvk_launch_search_big(&ix->dev, &a, pq ? 1 : 0, my_blocks, g.lds_big, all_rows, 0, stream));
         }
         HIPCHK(hipEventRecord(sc.last_use, stream));
     }

@@ -23,18 +23,18 @@ static int pqw_nch_slot(const JvIndexDev* ix) {
 }
 static int pqw_capk(int cap) { return cap <= 512 ? 0 : cap <= 1024 ? 1 : 2; }
 extern "C" int jvk_pqw_waves(const JvIndexDev* ix) { return ix->pq_M / 16; }
-extern "C" const void* jvk_pqw12_kernel(int capk, int nch_slot);  // jv_kernels_pqw12.hip: twelve waves per query (PQ-192)
+extern "C" const void* jvk_pqw12_kernel(int waves, int capk, int nch_slot);  // jv_kernels_pqw12.hip: twelve / eight waves per query (PQ-192 / PQ-128)
 extern "C" hipError_t jvk_pqw12_set_max_lds(int bytes);
 // NL of the instances: table rows per wave kept in LDS (PQ-192: eight, both variants)
-extern "C" int jvk_pqw_lds_rows(const JvIndexDev* ix, int variant) { return ix->pq_M == 192 ? 8 : (variant ? 16 : 4); }
+extern "C" int jvk_pqw_lds_rows(const JvIndexDev* ix, int variant) { return ix->pq_M >= 128 ? 8 : (variant ? 16 : 4); }
 // shapes this kernel runs: one wave per 16-subspace chunk, one lane per stored neighbour, whole log groups per 64-entry chunk
 extern "C" int jvk_pqw_ok(const JvIndexDev* ix, int cap) {
-    if (!(ix->pq_M == 32 || ix->pq_M == 64 || ix->pq_M == 192) || ix->sim == 2 || !ix->pq_fused || ix->num_upper != 0) return 0;
+    if (!(ix->pq_M == 32 || ix->pq_M == 64 || ix->pq_M == 128 || ix->pq_M == 192) || ix->sim == 2 || !ix->pq_fused || ix->num_upper != 0) return 0;
     if (ix->R < 1 || ix->R > JV_WAVE || 64 % ((JV_WAVE / ix->R) * 8) != 0) return 0;
     return cap <= 2048 && ix->n < (1 << 30) ? 1 : 0;
 }
 static pqw_kernel_t pqw_pick(const JvIndexDev* ix, int cap, int variant) {
-    if (ix->pq_M == 192) return (pqw_kernel_t)jvk_pqw12_kernel(pqw_capk(cap), pqw_nch_slot(ix));
+    if (ix->pq_M >= 128) return (pqw_kernel_t)jvk_pqw12_kernel(ix->pq_M / 16, pqw_capk(cap), pqw_nch_slot(ix));
     return g_pqw_kernels[(variant ? 2 : 0) + (ix->pq_M == 64 ? 1 : 0)][pqw_capk(cap)][pqw_nch_slot(ix)];
 }
 

@@ -31,13 +31,13 @@ def _both_kernels(gpu, what, fn, want):
 
 @pytest.mark.parametrize("sim", [0, 1])
 @pytest.mark.parametrize("M,R,d", [(32, 32, 64), (32, 16, 64), (32, 24, 96), (32, 8, 64), (64, 32, 128), (64, 16, 128), (32, 64, 64),
-                                   (192, 32, 384), (192, 16, 768)])   # (192: twelve waves per query — the reference's default for 768-d fields)
+                                   (192, 32, 384), (192, 16, 768), (128, 32, 256), (128, 16, 512)])   # (192 / 128: twelve / eight waves per query — the reference's defaults for 768-d / 512-d fields)
 def test_shapes_and_pool_classes(pkg, pyoracle, sim, M, R, d):
     """every (waves per query, neighbours per row) shape the kernel accepts — R = 64 runs one block per pass, the others
     two — over beams from 1 to 1 900 (all three pool capacity classes), with rerank floors.  ("one wave" for PQ-192 = the
     HBM-scratch rung with the table in HBM: the only other kernel that takes that shape.)"""
     b, bl, dg = pkg.binding, pkg.builder, pkg.datagen
-    n = 4000 if M < 192 else 1500
+    n = 4000 if M < 128 else 1500
     base = dg.splitmix_uniform(70 + d + R, n, d) - np.float32(0.25)
     if sim == 1:
         base = dg.l2_normalize(base)
