@@ -437,7 +437,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("JV_BENCH_LAUNCH_CHECK") == "1":  # (tests/test_bench_launch.py: the launch path alone, no GPU needed)
-        print(f"launch-check rank {rank} of {world} local_rank {local_rank} gpus {args.gpus}", flush=True)
+        # (one write() of the whole line: ranks share the launcher's stdout pipe, and print() may split text and newline)
+        sys.stdout.flush()
+        os.write(1, f"launch-check rank {rank} of {world} local_rank {local_rank} gpus {args.gpus}\n".encode())
         raise SystemExit(0 if world == args.gpus else 3)
 
     import torch
