@@ -483,6 +483,10 @@ def main():
         args.batch = wl["batch"]
     n_cfg = args.n if args.n > 0 else wl["n"]
     d, sim, pq_M = wl["d"], wl["sim"], wl["pq_M"]
+    data_M = pq_M  # the synthetic data's block structure follows the workload's subspace count ...
+    if pq_M and os.environ.get("JV_BENCH_CODEC_PQ_M"):
+        # ... while the CODEC may use another one (e.g. 192 = the plugin's default for 768-d fields; not the BASELINE configs)
+        pq_M = int(os.environ["JV_BENCH_CODEC_PQ_M"])
     R, L, k = 32, 100, 10
     fused = bool(pq_M) and os.environ.get("JV_BENCH_FUSED", "1") == "1"
     # N > 1: doc-ID-range shards.  Default = the north star's curve: the SAME corpus (10M docs) split over the
@@ -508,7 +512,7 @@ def main():
     def make_engine(dist_name):
         t0 = time.time()
         if pq_M:
-            base, queries = make_pq_data(torch, dist_name, n, nq_pool, d, pq_M, row_offset, n_total, wl["normalize"], device)
+            base, queries = make_pq_data(torch, dist_name, n, nq_pool, d, data_M, row_offset, n_total, wl["normalize"], device)
         else:
             centres = max(64, min(4096, n_total // 256))
             cen, basis = make_generators(torch, d, device, centres, 32)
@@ -634,7 +638,8 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": f"{args.workload}: {wl['desc']}" + ("" if n_total == wl["n"] * (world if scaling == "weak" else 1) else f" [n_total={n_total}]"),
+            "workload": f"{args.workload}: {wl['desc']}" + ("" if n_total == wl["n"] * (world if scaling == "weak" else 1) else f" [n_total={n_total}]") +
+                        ("" if pq_M == data_M else f" [codec overridden: PQ-{pq_M} instead of the workload's PQ-{data_M}]"),
             "distribution": dist_name,
             "docs_per_gpu": n, "total_docs": n_total, "dim": d, "similarity": ["l2", "dot", "cosine"][sim],
             "R": R, "ef_construction": L, "k": k, "rerankK": rk, "pq_M": pq_M, "queries_per_step": B,
