@@ -1187,7 +1187,7 @@ int serve_query(jv_index* ix, const float* query, int32_t topK, int32_t rerankK,
         return 1;
     if (topK < 1 || topK > JV_SERVE_TOPK_MAX || ix->dev.pq_M <= 0 || !ix->dev.pq_fused || ix->build_client) return 1;
     if (kind == 0) {
-        if (OPT(ix, OPT_NO_PQW) != 0 || !jvk_pqw_ok(&ix->dev, cap) || !(ix->dev.pq_M == 32 || ix->dev.pq_M == 64)) return 1;  // (server instances: two / four waves)
+        if (OPT(ix, OPT_NO_PQW) != 0 || !jvk_pqw_ok(&ix->dev, cap)) return 1;
     } else {
         // the shapes the filtered pool kernel takes (enqueue_batch): single-pass fused blocks, flat graph, ordinals below 2^29
         const JvIndexDev& dv = ix->dev;

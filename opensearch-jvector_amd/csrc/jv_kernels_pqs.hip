@@ -18,9 +18,18 @@ static int pqs_nch_slot(const JvIndexDev* ix) {
     return ix->nch == 2 ? 1 : ix->nch == 12 ? 2 : ix->nch == 24 ? 3 : 0;
 }
 static int pqs_capk(int cap) { return cap <= 512 ? 0 : cap <= 1024 ? 1 : 2; }
-static pqs_kernel_t pqs_pick(const JvIndexDev* ix, int cap) { return g_pqs_kernels[ix->pq_M == 64 ? 1 : 0][pqs_capk(cap)][pqs_nch_slot(ix)]; }
+extern "C" const void* jvk_pqs12_kernel(int waves, int capk, int nch_slot);  // jv_kernels_pqw12.hip: eight / twelve waves per query
+extern "C" hipError_t jvk_pqs12_set_max_lds(int bytes);
+static pqs_kernel_t pqs_pick(const JvIndexDev* ix, int cap) {
+    if (ix->pq_M >= 128) return (pqs_kernel_t)jvk_pqs12_kernel(ix->pq_M / 16, pqs_capk(cap), pqs_nch_slot(ix));
+    return g_pqs_kernels[ix->pq_M == 64 ? 1 : 0][pqs_capk(cap)][pqs_nch_slot(ix)];
+}
 
 extern "C" hipError_t jvk_pqs_set_max_lds(int bytes) {
+    {
+        hipError_t e = jvk_pqs12_set_max_lds(bytes);
+        if (e != hipSuccess) return e;
+    }
     for (int w = 0; w < 2; w++)
         for (int c = 0; c < 3; c++)
             for (int s = 0; s < 4; s++) {

@@ -25,3 +25,19 @@ extern "C" hipError_t jvk_pqw12_set_max_lds(int bytes) {
         }
     return hipSuccess;
 }
+
+// the device-resident query server for these shapes (jv_serve_pqw_kernel: one-query calls answered from the ring)
+#define JV_PQS12_ROW(CAPK, W) \
+    { jv_serve_pqw_kernel<0, CAPK, W, 4, 8>, jv_serve_pqw_kernel<2, CAPK, W, 4, 8>, jv_serve_pqw_kernel<12, CAPK, W, 4, 8>, jv_serve_pqw_kernel<24, CAPK, W, 4, 8> }
+static const pqw_kernel_t g_pqs12_kernels[2][3][4] = {{JV_PQS12_ROW(0, 8), JV_PQS12_ROW(1, 8), JV_PQS12_ROW(2, 8)},
+                                                      {JV_PQS12_ROW(0, 12), JV_PQS12_ROW(1, 12), JV_PQS12_ROW(2, 12)}};
+extern "C" const void* jvk_pqs12_kernel(int waves, int capk, int nch_slot) { return (const void*)g_pqs12_kernels[waves == 8 ? 0 : 1][capk][nch_slot]; }
+extern "C" hipError_t jvk_pqs12_set_max_lds(int bytes) {
+    for (int w = 0; w < 2; w++)
+        for (int c = 0; c < 3; c++)
+            for (int s = 0; s < 4; s++) {
+                hipError_t e = hipFuncSetAttribute((const void*)g_pqs12_kernels[w][c][s], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+                if (e != hipSuccess) return e;
+            }
+    return hipSuccess;
+}

@@ -245,3 +245,37 @@ def test_filtered_query_server(pkg, pyoracle, sim, pq_M):
     got = gpu.search(q[3], 10, 120, accept=filters[0], accept_num_docs=max_doc)
     assert np.array_equal(got.nodes[0], want[0, 0].nodes[3]) and gpu.counter("served_queries") == served
     gpu.close()
+
+
+@pytest.mark.parametrize("M,d", [(192, 768), (128, 512)])
+def test_query_server_wide_tables(pkg, pyoracle, M, d):
+    """One-query calls on the plugin's default PQ shapes (192 / 128 subspaces: twelve / eight waves per query) are answered
+    by the device-resident server too; answers equal the oracle's and the batch path's."""
+    import threading
+    b, bl, dg = pkg.binding, pkg.builder, pkg.datagen
+    n = 1500
+    base = dg.splitmix_uniform(51 + M, n, d)
+    q = dg.splitmix_uniform(52 + M, 48, d)
+    ix = bl.build_index_cpu(base, 0, R=32, L=50, pq_M=M)
+    gpu, orc = b.GpuIndex(ix, flags=b.DESC_FUSED_ADC), pyoracle.Oracle(b, ix)
+    want = {rk: orc.search_batch(q, 10, rk) for rk in (40, 300)}
+    errors = []
+
+    def worker(tid):
+        for it in range(24):
+            rk = (40, 300)[(tid + it) & 1]
+            j = (tid * 7 + it) % len(q)
+            got = gpu.search(q[j], 10, rk)
+            w = want[rk]
+            if not (np.array_equal(got.nodes[0], w.nodes[j]) and np.array_equal(got.scores[0].view(np.uint32), w.scores[j].view(np.uint32)) and
+                    np.array_equal(got.stats[0], w.stats[j])):
+                errors.append((tid, rk, j))
+                return
+
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    [t.start() for t in ts]
+    [t.join(timeout=120) for t in ts]
+    assert not any(t.is_alive() for t in ts), "a caller is stuck"
+    assert not errors, errors[:4]
+    assert gpu.counter("served_queries") >= 8 * 24 - 8, gpu.counter("served_queries")
+    gpu.close()
