@@ -530,6 +530,7 @@ int plan_pqw_lds(const jv_index* ix, JvSearchArgs& x, int variant) {
 // leave free on a CU would not start before the grids idle out (serve_idle_ms) — or never, under steady one-query traffic.
 // Such a launch asks the grids to leave first (they come back with the next one-query call).  Defined with the servers below.
 void servers_yield_lds(int device, int lds_needed);
+bool servers_leave_room(int device, int lds_needed);  // true when a launch of that LDS size fits beside the live grids
 
 // LDS plan of one launch of the one-wave pool kernel (jv_kernels_pqp.hip / jv_kernels_pqpf.hip / jv_kernels_pqsf.hip): offsets
 // into the workgroup's LDS for a pool of x.cand_cap entries and beams of up to `rk`; regs = look-up table in registers
@@ -625,7 +626,9 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
         ap.cand_cap = rk + 64 + ix->dev.R;
         ap.pqp_log_cap = (12 * rk + 1024 + 3) & ~3;
         const int lds = plan_pqw_lds(ix, ap, 0);
-        if (lds <= kMaxLds) {
+        // (a few queries — e.g. one row the query server handed back — are not worth asking a live server grid to leave for:
+        //  they go straight to the HBM-table rung, which fits beside it)
+        if (lds <= kMaxLds && (nq > 64 || servers_leave_room(ix->device, lds))) {
             int blocks = ix->cu_count * jvk_pqw_blocks_per_cu(&ix->dev, ap.cand_cap, lds, 0);
             if (blocks > nq) blocks = nq;
             const size_t need = (size_t)blocks * (size_t)ap.pqp_log_cap;
@@ -1018,13 +1021,22 @@ void free_with_servers_paused(void* p) {
     }
 }
 
-void servers_yield_lds(int device, int lds_needed) {
-    std::lock_guard<std::mutex> g(g_servers_mu);
-    int held = 0;  // LDS bytes per CU the live grids on this device occupy
+static int servers_held_lds_locked(int device) {  // g_servers_mu held: LDS bytes per CU the live grids on this device occupy
+    int held = 0;
     for (Server* sv : g_servers)
         if (sv->ix->device == device && sv->h_words && __atomic_load_n(&sv->h_words[JV_SH_ALIVE], __ATOMIC_ACQUIRE) != 0)
             held += (sv->blocks / std::max(1, sv->ix->cu_count)) * sv->lds;
-    if (held == 0 || lds_needed <= 161280 - held) return;  // (161 280: what a CU's workgroups can share, tools/lds_residency.hip)
+    return held;
+}
+bool servers_leave_room(int device, int lds_needed) {
+    std::lock_guard<std::mutex> g(g_servers_mu);
+    const int held = servers_held_lds_locked(device);
+    return held == 0 || lds_needed <= 161280 - held;  // (161 280: what a CU's workgroups can share, tools/lds_residency.hip)
+}
+void servers_yield_lds(int device, int lds_needed) {
+    std::lock_guard<std::mutex> g(g_servers_mu);
+    const int held = servers_held_lds_locked(device);
+    if (held == 0 || lds_needed <= 161280 - held) return;
     for (Server* sv : g_servers)
         if (sv->ix->device == device) {
             std::lock_guard<std::mutex> lk(sv->mu);

@@ -1496,13 +1496,17 @@ __global__ __launch_bounds__(JV_WAVE) void jv_search_big_kernel(const JvIndexDev
     int64_t* my_cand = a.big_cand + (size_t)blockIdx.x * a.big_cand_cap;
     uint32_t* my_bits = a.big_visited + (size_t)blockIdx.x * words;
     const int lane = threadIdx.x;
-    for (;;) {  // dequeue 64 queries at a time, one flag per lane
+    // dequeue up to 64 queries at a time, one flag per lane.  (A handful of 65 536 flags are set behind the pool kernels: big
+    // chunks.  Where this rung carries a whole small batch — filters on tables beyond the LDS, forced runs — 64 queries per
+    // workgroup would leave all but a few workgroups idle: the chunk shrinks with the number of flags per workgroup.)
+    const int chunk = max(1, min(JV_WAVE, a.nq / ((int)gridDim.x * 2)));
+    for (;;) {
         int base = 0;
-        if (lane == 0) base = atomicAdd(a.work_counter, JV_WAVE);
+        if (lane == 0) base = atomicAdd(a.work_counter, chunk);
         base = __shfl(base, 0, JV_WAVE);
         if (base >= a.nq) break;
         const int qi = base + lane;
-        const bool todo_q = qi < a.nq && (force_all || ((uint32_t)a.out_flags[qi] & JV_FLAG_OVERFLOW));
+        const bool todo_q = lane < chunk && qi < a.nq && (force_all || ((uint32_t)a.out_flags[qi] & JV_FLAG_OVERFLOW));
         unsigned long long m = __ballot(todo_q);
         while (m) {
             const int j = __ffsll((long long)m) - 1;
