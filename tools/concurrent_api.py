@@ -11,7 +11,7 @@ b = importlib.import_module("opensearch_jvector_amd.binding")
 gb = importlib.import_module("opensearch_jvector_amd.builder_gpu")
 host = importlib.import_module("opensearch_jvector_amd.host")
 import bench
-n = int(os.environ.get("N", 2_000_000)); d = 768; M = 32; rk = int(os.environ.get("RK", 160)); NQ = 8192
+n = int(os.environ.get("N", 2_000_000)); d = 768; M = int(os.environ.get("M", 32)); rk = int(os.environ.get("RK", 160)); NQ = 8192
 secs = float(os.environ.get("SECS", 3))
 dev = torch.device("cuda", 0)
 zc, Bl, Bg = bench.make_block_generators(torch, d, dev, max(64, min(4096, n // 256)), M=M, per=2)
@@ -50,6 +50,7 @@ rows = []
 for T in [int(x) for x in os.environ.get("THREADS", "1,8,32,64,128,256").split(",")]:
     r = host.concurrent_search_bench(ix, qh, 10, rk, T, secs, want, accept=acc, accept_num_docs=(n if acc is not None else 0), accept_key=acc_key)
     rows.append(r)
+    r["counters"] = {nm: ix.counter(nm) for nm in ("launches_pqw", "launches_pqp", "launches_big", "launches_serve", "served_queries")}
     print(json.dumps(r), flush=True)
     assert r["mismatches"] == 0, "single-query answers differ from the batch API's"
 print("done")
