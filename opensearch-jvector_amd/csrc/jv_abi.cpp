@@ -531,6 +531,7 @@ int plan_pqw_lds(const jv_index* ix, JvSearchArgs& x, int variant) {
 // Such a launch asks the grids to leave first (they come back with the next one-query call).  Defined with the servers below.
 void servers_yield_lds(int device, int lds_needed);
 bool servers_leave_room(int device, int lds_needed);  // true when a launch of that LDS size fits beside the live grids
+int servers_free_lds(int device);  // LDS bytes per CU the live grids leave to other workgroups (the whole budget when none is alive)
 
 // LDS plan of one launch of the one-wave pool kernel (jv_kernels_pqp.hip / jv_kernels_pqpf.hip / jv_kernels_pqsf.hip): offsets
 // into the workgroup's LDS for a pool of x.cand_cap entries and beams of up to `rk`; regs = look-up table in registers
@@ -841,6 +842,7 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
             return b_;
         };
         if (shape_ok && rerank_b <= lut_b && loop_bytes(ap) <= kMaxLds) {
+            servers_yield_lds(ix->device, (loop_bytes(ap) + 15) & ~15);
             HIPCHK(jvk_launch_search_pqf(&ix->dev, &ap, (loop_bytes(ap) + 15) & ~15, stream));
             ix->launches[LAUNCH_PQF]++;
             pqf = true;
@@ -858,6 +860,7 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
     first_ran = first_ran || pqf;
     if (!force_big) {
         if (!pqf) {
+            servers_yield_lds(ix->device, g.lds_fast);
             HIPCHK(jvk_launch_search_lds(&ix->dev, &a, pq ? 1 : 0, g.pool ? 1 : 0, ix->build_client ? 2 : 0, g.lds_fast, stream));
             ix->launches[LAUNCH_LDS]++;
         }
@@ -873,6 +876,7 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
                 a2.res_cap = g2.res_cap;
                 a2.retry_only = 1;
                 a2.retry_counter = c->work_counter + 4;
+                servers_yield_lds(ix->device, g2.lds_fast);
                 HIPCHK(jvk_launch_search_lds(&ix->dev, &a2, pq ? 1 : 0, g2.pool ? 1 : 0, 1, g2.lds_fast, stream));
             }
         }
@@ -911,6 +915,7 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
             // queries per CU), then in HBM for what outgrew them
             const int fixed_g = (g.lds_big + 15) & ~15;
             const int qslots_g = (kMaxLds / 4 - fixed_g - 256) / 8;
+            servers_yield_lds(ix->device, fixed_g + std::max(0, qslots_g) * 8);
             if (qslots_g >= a.res_cap + 4 * rk + 256 && OPT(ix, OPT_NO_ESCALATION) == 0) {
                 JvSearchArgs aq = a;
                 aq.cand_cap = qslots_g - aq.res_cap;
@@ -929,13 +934,17 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
         //  either ran one or, forced here, did everything itself)
         const int all_rows = (force_big && !first_ran && phase != 2) ? 1 : 0;
         // first with both queues in LDS (every slot the workgroup's LDS has left; the visited set is the HBM bitset) ...
+        // (this rung is enqueued behind every device-pointer batch, flagged rows or not: it must not wait for — nor displace —
+        //  a resident query-server grid, so the LDS variant takes what the live grids leave free on a CU)
         const int fixed_lds = (g.lds_big + 15) & ~15;
-        const int qslots = (kMaxLds - fixed_lds) / 8;
+        const int lds_q = std::min(kMaxLds, servers_free_lds(ix->device)) & ~15;
+        const int qslots = (lds_q - fixed_lds) / 8;
+        servers_yield_lds(ix->device, fixed_lds);
         if (qslots >= a.res_cap + 4 * rk + 256 && OPT(ix, OPT_NO_ESCALATION) == 0) {
             JvSearchArgs aq = a;
             aq.cand_cap = qslots - aq.res_cap;
             aq.work_counter = c->work_counter + 7;
-            HIPCHK(jvk_launch_search_big(&ix->dev, &aq, pq ? 1 : 0, my_blocks, kMaxLds, all_rows, 1, stream));
+            HIPCHK(jvk_launch_search_big(&ix->dev, &aq, pq ? 1 : 0, my_blocks, lds_q, all_rows, 1, stream));
             // ... then, for what outgrew them (and for the rerankFloor corner that needs the admission log), in HBM
             HIPCHK(jvk_launch_search_big(&ix->dev, &a, pq ? 1 : 0, my_blocks, g.lds_big, 0, 0, stream));
         } else {
@@ -978,12 +987,25 @@ typedef JvQueryServer Server;
 std::mutex g_servers_mu;
 std::vector<Server*> g_servers;  // every live server of the process (device-wide synchronisation points pause them)
 
-void server_stop_locked(Server* sv) {  // sv->mu held: ask the grid to leave and wait until it has
+static bool serve_trace() {
+    static const bool on = getenv("JV_SERVE_TRACE") != nullptr;  // diagnostics: who starts and stops the resident grids
+    return on;
+}
+void server_stop_locked(Server* sv, const char* why = "pause") {  // sv->mu held: ask the grid to leave and wait until it has
     if (!sv->stream) return;
+    const bool was_alive = __atomic_load_n(&sv->h_words[JV_SH_ALIVE], __ATOMIC_ACQUIRE) != 0;
+    struct timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
     __atomic_store_n(&sv->h_words[JV_SH_STOP], 1, __ATOMIC_RELEASE);
     hipStreamSynchronize(sv->stream);
     __atomic_store_n(&sv->h_words[JV_SH_ALIVE], 0, __ATOMIC_RELEASE);
     __atomic_store_n(&sv->h_words[JV_SH_STOP], 0, __ATOMIC_RELEASE);
+    if (serve_trace() && was_alive) {
+        struct timespec t1;
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        fprintf(stderr, "[jvgpu serve] grid kind %d stopped (%s) in %.2f ms\n", sv->kind, why,
+                (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) / 1e6);
+    }
 }
 
 // RAII: no query server runs on `device` while this object lives (hipFree / hipDeviceSynchronize would otherwise wait for
@@ -1021,12 +1043,19 @@ void free_with_servers_paused(void* p) {
     }
 }
 
-static int servers_held_lds_locked(int device) {  // g_servers_mu held: LDS bytes per CU the live grids on this device occupy
+// g_servers_mu held: LDS bytes per CU the server grids of this device occupy.  alive_only = false counts every EXISTING server:
+// a grid that is not running now may be started by the next one-query call — before a kernel enqueued now gets its CUs
+static int servers_held_lds_locked(int device, bool alive_only = true) {
     int held = 0;
     for (Server* sv : g_servers)
-        if (sv->ix->device == device && sv->h_words && __atomic_load_n(&sv->h_words[JV_SH_ALIVE], __ATOMIC_ACQUIRE) != 0)
+        if (sv->ix->device == device && sv->h_words && (!alive_only || __atomic_load_n(&sv->h_words[JV_SH_ALIVE], __ATOMIC_ACQUIRE) != 0))
             held += (sv->blocks / std::max(1, sv->ix->cu_count)) * sv->lds;
     return held;
+}
+int servers_free_lds(int device) {
+    std::lock_guard<std::mutex> g(g_servers_mu);
+    const int held = servers_held_lds_locked(device, false);
+    return held == 0 ? kMaxLds : std::max(0, 161280 - held - 8192);  // (8 KB of slack: allocation granules)
 }
 bool servers_leave_room(int device, int lds_needed) {
     std::lock_guard<std::mutex> g(g_servers_mu);
@@ -1040,7 +1069,7 @@ void servers_yield_lds(int device, int lds_needed) {
     for (Server* sv : g_servers)
         if (sv->ix->device == device) {
             std::lock_guard<std::mutex> lk(sv->mu);
-            server_stop_locked(sv);
+            server_stop_locked(sv, "a launch needs its LDS");
         }
 }
 
@@ -1083,6 +1112,7 @@ int server_launch_locked(Server* sv) {  // sv->mu held, grid not alive
         return fail(JV_EDEVICE, "query server launch failed: %s", hipGetErrorString(e));
     }
     ix->launches[LAUNCH_SERVE]++;
+    if (serve_trace()) fprintf(stderr, "[jvgpu serve] grid kind %d launched (%d workgroups, %d B of LDS each)\n", sv->kind, sv->blocks, sv->lds);
     return JV_OK;
 }
 
@@ -1100,6 +1130,12 @@ Server* server_get(jv_index* ix, int kind, int need_cap, int* rc) {
     if (hipSetDevice(ix->device) != hipSuccess) {
         *rc = fail(JV_EDEVICE, "hipSetDevice failed");
         return nullptr;
+    }
+    {
+        std::lock_guard<std::mutex> g(g_servers_mu);
+        int same = 0;
+        for (Server* o : g_servers) same += (o->ix->device == ix->device && o->kind == kind) ? 1 : 0;
+        if (same >= 4) return nullptr;  // (one hardware queue per grid: see the stream's creation below; such calls take the launch path)
     }
     Server* sv = new Server();
     sv->ix = ix;
@@ -1155,7 +1191,14 @@ Server* server_get(jv_index* ix, int kind, int need_cap, int* rc) {
     sv->slots = next_pow2(std::max(1024, 2 * sv->blocks));
     const int qbytes = ((ix->dev.nch * 64 * 4) + 255) & ~255;
     sv->slot_bytes = (JV_SERVE_QUERY_OFF + qbytes + 255) & ~255;
-    hipError_t e = hipStreamCreateWithFlags(&sv->stream, hipStreamNonBlocking);
+    // The grid never ends, and the HIP runtime multiplexes streams onto a few hardware queues PER PRIORITY LEVEL
+    // (GPU_MAX_HW_QUEUES = 4): on a default-priority stream it sat in front of every other stream that happened to share its
+    // queue — a batch call then waited until the one-query traffic stopped.  The grids therefore run on streams of their own
+    // priority levels (unfiltered servers: the highest, filtered servers: the lowest; nothing else in this library uses those),
+    // and at most four per level and device are started (a fifth would share a queue with — and wait for ever behind — another).
+    int prio_least = 0, prio_greatest = 0;
+    hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    hipError_t e = hipStreamCreateWithPriority(&sv->stream, hipStreamNonBlocking, prio_least);
     if (e != hipSuccess) return bail("stream", e);
     if (kind == 1 && (e = hipStreamCreateWithFlags(&sv->up_stream, hipStreamNonBlocking)) != hipSuccess) return bail("upload stream", e);
     if ((e = hipHostMalloc((void**)&sv->ring, (size_t)sv->slots * sv->slot_bytes, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) return bail("ring", e);

@@ -12,6 +12,9 @@ __device__ __forceinline__ int jv_serve_claim(const JvSearchArgs& a) {
     const uint32_t t_idle0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
     int polls = 0, idle_iters = 0;
     for (;;) {
+        // (the host's STOP must be honoured under load too: it used to be looked at by idle workgroups only, so a pause — hipFree,
+        //  a launch that needs the grid's LDS — waited until the one-query traffic paused by itself)
+        if (__hip_atomic_load(&a.serve_dev[JV_SV_STOP_SEEN], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
         const int h = __hip_atomic_load(&a.serve_dev[JV_SV_HEAD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int pb = __hip_atomic_load(&a.serve_dev[JV_SV_PUBLISHED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (pb - h <= 0) {
@@ -45,6 +48,10 @@ __device__ __forceinline__ int jv_serve_claim(const JvSearchArgs& a) {
         }
         if (atomicCAS(&a.serve_dev[JV_SV_HEAD], h, h + 1) == h) {
             ticket = h;
+            // every 32nd ticket's owner reads the host's STOP word (one PCIe read per 32 queries); the unclaimed tickets stay
+            // published and are served by the next grid
+            if ((h & 31) == 0 && __hip_atomic_load(&a.serve_host[JV_SH_STOP], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0)
+                __hip_atomic_store(&a.serve_dev[JV_SV_STOP_SEEN], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&a.serve_dev[JV_SV_LAST_CLAIM], (int)(uint32_t)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
         }
