@@ -34,6 +34,7 @@ hipError_t jvk_launch_search_lds(const JvIndexDev* ix, const JvSearchArgs* a, in
 hipError_t jvk_launch_search_pqf(const JvIndexDev* ix, const JvSearchArgs* a, int lds_bytes, hipStream_t s);
 hipError_t jvk_launch_search_big(const JvIndexDev* ix, const JvSearchArgs* a, int pq, int blocks, int lds_bytes,
                                  int force_all, int qlds, hipStream_t s);
+hipError_t jvk_launch_mark(int32_t* word, int32_t value, hipStream_t stream);
 hipError_t jvk_launch_search_big_lutg(const JvIndexDev* ix, const JvSearchArgs* a, int blocks, int lds_bytes, int force_all, int qlds, hipStream_t stream);
 hipError_t jvk_launch_score_ordinals(const JvIndexDev* ix, const float* d_query, const int32_t* d_ordinals,
                                      int count, float* d_out, hipStream_t s);
@@ -189,6 +190,8 @@ struct Ctx {
     uint8_t* h_direct = nullptr;
     size_t direct_cap = 0;
     hipEvent_t ev_direct = nullptr;
+    int32_t* h_mark = nullptr;   // pinned: stream marker written by jv_mark_kernel, polled by the host (see wait_mark)
+    int32_t mark_seq = 0;
     int32_t* work_counter = nullptr;  // 16 words: [0] big-path dequeue, [1] spill-table allocator, [2..7] rung counters, [8..15] filtered pool rungs
     // pool of visited-set spill tables of the generic kernels (allocated on the first launch that can use it)
     uint32_t* spill = nullptr;
@@ -345,6 +348,7 @@ void ctx_destroy(Ctx* c) {
     jv_free(c->d_flags);
     jv_free(c->d_accept);
     jv_free(c->d_accept_ord);
+    if (c->h_mark) hipHostFree(c->h_mark);
     jv_free(c->d_arena);
     if (c->h_arena) hipHostFree(c->h_arena);
     if (c->h_query) hipHostFree(c->h_query);
@@ -1849,6 +1853,40 @@ void filter_release(jv_index* ix, int slot) {
     ix->filters[(size_t)slot].users--;
 }
 
+// Enqueue a marker behind everything on the context's stream and wait for it by polling host memory; falls back to the
+// runtime's wait when the marker does not show up (a faulted kernel never writes it)
+int mark_enqueue(Ctx* c) {
+    if (!c->h_mark) {
+        HIPCHK(hipHostMalloc((void**)&c->h_mark, 64, hipHostMallocMapped | hipHostMallocCoherent));
+        __atomic_store_n(c->h_mark, 0, __ATOMIC_RELEASE);
+    }
+    c->mark_seq = c->mark_seq == INT32_MAX ? 1 : c->mark_seq + 1;
+    HIPCHK(jvk_launch_mark(c->h_mark, c->mark_seq, c->stream));
+    return JV_OK;
+}
+bool mark_reached(const Ctx* c) { return __atomic_load_n(c->h_mark, __ATOMIC_ACQUIRE) == c->mark_seq; }
+int mark_wait(Ctx* c) {
+    struct timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int spins = 0; !mark_reached(c); spins++) {
+        if (spins < 200) {
+            sched_yield();
+            continue;
+        }
+        struct timespec ts = {0, 20000};  // 20 us
+        nanosleep(&ts, nullptr);
+        if ((spins & 1023) == 0) {
+            struct timespec t1;
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            if (t1.tv_sec - t0.tv_sec > 20) {  // something is wrong: let the runtime report it
+                HIPCHK(hipStreamSynchronize(c->stream));
+                return JV_OK;
+            }
+        }
+    }
+    return JV_OK;
+}
+
 struct HostSearchExtras {
     int64_t visit_limit = 0;
     uint64_t accept_key = 0;
@@ -1920,8 +1958,11 @@ int search_batch_host(jv_index* index, const float* queries, int32_t nq, int32_t
         c->arena_cap = cap;
     }
     const bool direct = ex.on_ready != nullptr;
+    // small batches write their rows straight into pinned, device-visible memory as well: no result copy at all (next to a
+    // starting query-server grid the wait for that copy was seen to last until the grid left — DESIGN.md "Resident grids")
+    const bool pinned_out = !direct && nq <= 1024;
     int32_t* done = nullptr;
-    if (direct) {
+    if (direct || pinned_out) {
         const size_t need = (total4 + (size_t)nq) * 4;
         if (need > c->direct_cap) {
             if (c->h_direct) hipHostFree(c->h_direct);
@@ -1932,10 +1973,12 @@ int search_batch_host(jv_index* index, const float* queries, int32_t nq, int32_t
             c->direct_cap = cap;
         }
         if (!c->ev_direct) HIPCHK(hipEventCreateWithFlags(&c->ev_direct, hipEventDisableTiming));
-        done = (int32_t*)c->h_direct + total4;
-        memset(done, 0, (size_t)nq * 4);
+        if (direct) {
+            done = (int32_t*)c->h_direct + total4;
+            memset(done, 0, (size_t)nq * 4);
+        }
     }
-    int32_t* const a32 = direct ? (int32_t*)c->h_direct : (int32_t*)c->d_arena;
+    int32_t* const a32 = (direct || pinned_out) ? (int32_t*)c->h_direct : (int32_t*)c->d_arena;
     int32_t* const dn = a32 + o_nodes;
     int32_t* const dd = a32 + o_docs;
     float* const dsc = (float*)(a32 + o_scores);
@@ -2002,14 +2045,13 @@ int search_batch_host(jv_index* index, const float* queries, int32_t nq, int32_t
     if (direct) {
         // Rows land in pinned host memory.  A row whose completion word is set is final; every row is once the stream has
         // run dry (the rungs behind the first launch only touch flagged rows).  One poller per batch: this thread.
-        HIPCHK(hipEventRecord(c->ev_direct, c->stream));
+        if ((rc = mark_enqueue(c)) != JV_OK) return rc;
         if (ex.on_launched) ex.on_launched(ex.user);
         const int32_t* h32d = (const int32_t*)c->h_direct;
         std::vector<char> delivered((size_t)nq, 0);
         int remaining = nq, failed_d = 0, first_d = -1;
         for (int spins = 0; remaining > 0; spins++) {
-            const hipError_t qe = hipEventQuery(c->ev_direct);
-            if (qe != hipSuccess && qe != hipErrorNotReady) return fail(JV_EDEVICE, "hipEventQuery failed: %s", hipGetErrorString(qe));
+            const hipError_t qe = mark_reached(c) ? hipSuccess : hipErrorNotReady;  // (a marker in host memory, not hipEventQuery: see mark_enqueue)
             bool finished = qe == hipSuccess;
             if (finished && big_owed) {
                 bool any = false;
@@ -2017,7 +2059,7 @@ int search_batch_host(jv_index* index, const float* queries, int32_t nq, int32_t
                     any = !delivered[(size_t)i] && ((uint32_t)h32d[o_flags + (size_t)i] & JV_FLAG_OVERFLOW) != 0;
                 if (any) {
                     if ((rc = enqueue_big()) != JV_OK) return rc;
-                    HIPCHK(hipEventRecord(c->ev_direct, c->stream));
+                    if ((rc = mark_enqueue(c)) != JV_OK) return rc;
                     finished = false;  // (rows without the flag are final and are handed out below)
                 }
                 big_owed = false;
@@ -2051,19 +2093,20 @@ int search_batch_host(jv_index* index, const float* queries, int32_t nq, int32_t
                         failed_d, nq, first_d);
         return JV_OK;
     }
-    HIPCHK(hipMemcpyAsync(c->h_arena, c->d_arena, total4 * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    if (!pinned_out) HIPCHK(hipMemcpyAsync(c->h_arena, c->d_arena, total4 * 4, hipMemcpyDeviceToHost, c->stream));
+    if ((rc = mark_enqueue(c)) != JV_OK || (rc = mark_wait(c)) != JV_OK) return rc;
+    const int32_t* const res32 = pinned_out ? (const int32_t*)c->h_direct : (const int32_t*)c->h_arena;
     if (big_owed) {
-        const int32_t* fl0 = (const int32_t*)c->h_arena + o_flags;
+        const int32_t* fl0 = res32 + o_flags;
         bool any = false;
         for (int i = 0; i < nq && !any; i++) any = ((uint32_t)fl0[i] & JV_FLAG_OVERFLOW) != 0;
         if (any) {
             if ((rc = enqueue_big()) != JV_OK) return rc;
-            HIPCHK(hipMemcpyAsync(c->h_arena, c->d_arena, total4 * 4, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipStreamSynchronize(c->stream));
+            if (!pinned_out) HIPCHK(hipMemcpyAsync(c->h_arena, c->d_arena, total4 * 4, hipMemcpyDeviceToHost, c->stream));
+            if ((rc = mark_enqueue(c)) != JV_OK || (rc = mark_wait(c)) != JV_OK) return rc;
         }
     }
-    const int32_t* h32 = (const int32_t*)c->h_arena;
+    const int32_t* h32 = res32;
     if (out_nodes) memcpy(out_nodes, h32 + o_nodes, outn * 4);
     if (out_docs) memcpy(out_docs, h32 + o_docs, outn * 4);
     if (out_scores) memcpy(out_scores, h32 + o_scores, outn * 4);

@@ -1733,6 +1733,17 @@ extern "C" hipError_t jvk_launch_search_big(const JvIndexDev* ix, const JvSearch
     (qlds ? g_bigq_kernels : g_big_kernels)[pq ? 1 : 0][nch_slot(ix)]<<<blocks, JV_WAVE, lds_bytes, stream>>>(*ix, *a, force_all);
     return hipGetLastError();
 }
+// stream marker: one store to host-visible memory.  The host polls the word instead of asking the runtime (hipEventQuery /
+// hipStreamQuery never turn ready while a resident query-server grid runs, and waits for a result copy were seen to return
+// only after the grid left: DESIGN.md "Resident grids and the rest of the runtime")
+__global__ void jv_mark_kernel(int32_t* word, int32_t value) {
+    __hip_atomic_store(word, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+extern "C" hipError_t jvk_launch_mark(int32_t* word, int32_t value, hipStream_t stream) {
+    jv_mark_kernel<<<1, 1, 0, stream>>>(word, value);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t jvk_launch_search_big_lutg(const JvIndexDev* ix, const JvSearchArgs* a, int blocks, int lds_bytes, int force_all,
                                                  int qlds, hipStream_t stream) {
     if (a->nq <= 0) return hipSuccess;
