@@ -78,3 +78,20 @@ def test_splitmix_generator_is_counter_based(pkg):
     assert np.array_equal(a[60:], b)  # shards can generate their own doc range independently
     assert a.dtype == np.float32 and 0 <= a.min() and a.max() < 1
     assert abs(a.mean() - 0.5) < 0.05
+
+
+def test_hardware_probes_cross_compile(tmp_path):
+    """tools/lds_residency.hip and tools/hwq_probe.hip (the measurements behind the rung sizes and the query servers' stream
+    priorities) must keep compiling for gfx950 — hipcc cross-compiles without a GPU."""
+    import os
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for src in ("lds_residency.hip", "hwq_probe.hip"):
+        out = tmp_path / (src + ".o")
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-c", "-o", str(out), os.path.join(root, "tools", src)],
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
