@@ -258,8 +258,16 @@ __device__ void search_one_pqw(const JvIndexDev& ix, const JvSearchArgs& a, cons
         // runner-up's half keeps them for its own expansion, corrected there for the keys the first half inserted meanwhile
         int rold_s = 0;
         bool cand_s = false;
+        int ru_pos = -1, ru_lo = 0, ru_hi = 0;  // the runner-up's pool entry as the pass iteration found it
         unsigned long long ins_lo = 0ull;  // lanes (lower half) whose keys went into the pool in the pass iteration
         while (true) {
+            // (wave-uniform state, said so: the compiler's divergence analysis gives up on values that pass through LDS loads and
+            //  the joins behind lane-level branches, and then runs this whole loop with vector compares and exec masks)
+#define PQW_UNI(x) x = __builtin_amdgcn_readfirstlane(x)
+            PQW_UNI(np); PQW_UNI(nexp); PQW_UNI(expanded); PQW_UNI(lo_un); PQW_UNI(why); PQW_UNI(nrej);
+            PQW_UNI(sc_node0); PQW_UNI(sc_node1); PQW_UNI(pf_node0); PQW_UNI(pf_node1); PQW_UNI(ru_pos); PQW_UNI(ru_lo); PQW_UNI(ru_hi);
+            bscore = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(bscore)));
+#undef PQW_UNI
             // ---- best unexpanded entry (every position < lo_un is expanded; sentinels have bit 0 clear) ----
             int t1 = lo_un >> 6;
             int64_t e1 = 0;
@@ -311,9 +319,10 @@ __device__ void search_one_pqw(const JvIndexDev& ix, const JvSearchArgs& a, cons
                 // ---- scoring pass: the next three unexpanded entries as well (runner-up: scored now; the two after it:
                 // their blocks are requested for the next pass) ----
                 int bn1 = -1, bn2 = -1, bn3 = -1;
+                ru_pos = -1;
                 if (!stop) {
                     unsigned long long mm = m1 & (m1 - 1ull);
-                    int elo = e1lo;
+                    int elo = e1lo, ehi = e1hi;
                     bool second = false;
 #pragma unroll
                     for (int k = 1; k < 4; k++) {
@@ -321,11 +330,19 @@ __device__ void search_one_pqw(const JvIndexDev& ix, const JvSearchArgs& a, cons
                             const int64_t e2 = pool[min(((t1 + 1) << 6) + lane, cap)];
                             mm = __ballot((e2 & 1ll) != 0);
                             elo = (int)(uint32_t)(e2 & 0xFFFFFFFFll);
+                            ehi = (int)(e2 >> 32);
                             second = true;
                         }
                         int nb = -1;
                         if (mm) {
-                            nb = lo_node<false>(__builtin_amdgcn_readlane(elo, __ffsll((long long)mm) - 1));
+                            const int ln = __ffsll((long long)mm) - 1;
+                            const int klo = __builtin_amdgcn_readlane(elo, ln);
+                            nb = lo_node<false>(klo);
+                            if (k == 1) {  // the runner-up's entry: its key and position decide whether both entries are expanded at once
+                                ru_lo = klo;
+                                ru_hi = __builtin_amdgcn_readlane(ehi, ln);
+                                ru_pos = ((second ? t1 + 1 : t1) << 6) + ln;
+                            }
                             mm &= mm - 1ull;
                         }
                         if (k == 1) bn1 = nb;
@@ -400,7 +417,7 @@ __device__ void search_one_pqw(const JvIndexDev& ix, const JvSearchArgs& a, cons
             else sc_node1 = -1;
             PQW_STAMP(1)
             const int64_t v = pqp_key<false>(score, nn, true);
-            bool keep;
+            bool keep, dual = false;
             int rold;
             if (fresh) {
                 bool cand = nn >= 0;
@@ -469,6 +486,30 @@ __device__ void search_one_pqw(const JvIndexDev& ix, const JvSearchArgs& a, cons
                 cand_s = cand;
                 keep = cand && hf == 0;
                 rold = rold_a;
+                // ---- both entries at once.  The runner-up IS the next entry expanded unless one of this entry's new keys ranks
+                // ahead of it; then its own new keys can go into the pool in the same insert (ranks, shift, boundary and trim
+                // once for two expansions — the final pool is the one two inserts would leave: every key the first insert's
+                // higher boundary would have refused falls off in the trim).  Only while nothing of jvector's pop-time logic
+                // can apply to the runner-up: result queue not full (no strict admission), inside the best rerankK, score
+                // above the threshold, room in the log and in the pool, no visit limit in reach.
+                // (`expanded` and `nexp` already count this iteration's entry: they are what the runner-up's own pop would see)
+                if (sc_node1 >= 0 && ru_pos >= 0 && ru_pos < rk && nrej == 0 && expanded < rk && nexp < log_cap &&
+                    hi_score(ru_hi) >= a.threshold && (a.visit_limit <= 0 || expanded < a.visit_limit)) {
+                    const int64_t ruk = (int64_t)(((uint64_t)(uint32_t)ru_hi << 32) | (uint64_t)(uint32_t)ru_lo);
+                    const unsigned long long all = __ballot(cand);
+                    if (!__ballot(keep && v > ruk) && np + __popcll(all) <= cap) {
+                        dual = true;
+                        keep = cand;
+                        if (lane == 0) {
+                            ((int*)pool)[2 * ru_pos] = ru_lo & ~1;
+                            explog[nexp] = sc_node1;
+                        }
+                        nexp++;
+                        expanded++;
+                        lo_un = ru_pos + 1;
+                        sc_node1 = -1;
+                    }
+                }
             } else {
                 // the runner-up's half: ranked against the pool as it was before the first half's keys went in
                 keep = cand_s && hf == 1;
@@ -486,7 +527,7 @@ __device__ void search_one_pqw(const JvIndexDev& ix, const JvSearchArgs& a, cons
             }
             unsigned long long km = __ballot(keep);
             int nk = __popcll(km);
-            if (fresh) ins_lo = km;  // (twins inside the row are taken out below)
+            if (fresh) ins_lo = dual ? 0ull : km;  // (twins inside the row are taken out below)
             PQW_STAMP_COUNT(8, __popcll(km))
             PQW_STAMP(3)  // boundary test + rank search + duplicate test
             if (nk > 0) {
@@ -528,7 +569,7 @@ __device__ void search_one_pqw(const JvIndexDev& ix, const JvSearchArgs& a, cons
                         keep = keep && !twin;
                         km = km2;
                         nk = __popcll(km);
-                        if (fresh) ins_lo = km;
+                        if (fresh) ins_lo = dual ? 0ull : km;
                     }
                     const int lane_first = __ffsll((long long)__ballot(keep && rnew == 0)) - 1;     // largest new key
                     const int lane_last = __ffsll((long long)__ballot(keep && rnew == nk - 1)) - 1;  // smallest new key
@@ -571,7 +612,7 @@ __device__ void search_one_pqw(const JvIndexDev& ix, const JvSearchArgs& a, cons
                 const int ntot = np + nk;
                 np = ntot;
                 if (ntot >= rk) {
-                    const int bhi = (int)(pool[rk - 1] >> 32);
+                    const int bhi = __builtin_amdgcn_readfirstlane((int)(pool[rk - 1] >> 32));  // (wave-uniform, and said so: the boundary and the rejected count steer wave-level branches)
                     const float nb = hi_score(bhi);
                     if (nb != bscore) nrej = 0;  // the boundary rose: every rejected entry (they tied with the old one) falls off below
                     bscore = nb;
