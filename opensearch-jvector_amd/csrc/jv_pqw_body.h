@@ -199,7 +199,7 @@ __device__ void search_one_pqw(const JvIndexDev& ix, const JvSearchArgs& a, cons
     const int cap = a.cand_cap;  // entries; slot `cap` is a permanent sentinel
     int64_t* pool = (int64_t*)(smem + a.pqp_pool_off);
     for (int i = threadIdx.x; i <= cap; i += JV_WAVE * W) pool[i] = KEY_MIN;
-    int np = 0, nexp = 0, expanded = 0, lo_un = 0;
+    int np = 0, nexp = 0, expanded = 0;
     int why = 0;
     int nrej = 0;         // rejected entries in the pool (all at the boundary score)
     float bscore = 0.0f;  // score of the rk-th best entry once np >= rk
@@ -259,23 +259,30 @@ __device__ void search_one_pqw(const JvIndexDev& ix, const JvSearchArgs& a, cons
         int rold_s = 0;
         bool cand_s = false;
         int ru_pos = -1, ru_lo = 0, ru_hi = 0;  // the runner-up's pool entry as the pass iteration found it
+        // bit t: pool chunk t MAY hold an unexpanded entry (a clear bit: it holds none).  The best unexpanded entry is one
+        // chunk read away wherever it is — a key that lands far ahead of the frontier no longer costs a walk through every
+        // fully expanded chunk in between once it has been expanded itself (that walk was most of the "find" step)
+        unsigned long long um = 1ull;
         unsigned long long ins_lo = 0ull;  // lanes (lower half) whose keys went into the pool in the pass iteration
         while (true) {
             // (wave-uniform state, said so: the compiler's divergence analysis gives up on values that pass through LDS loads and
             //  the joins behind lane-level branches, and then runs this whole loop with vector compares and exec masks)
 #define PQW_UNI(x) x = __builtin_amdgcn_readfirstlane(x)
-            PQW_UNI(np); PQW_UNI(nexp); PQW_UNI(expanded); PQW_UNI(lo_un); PQW_UNI(why); PQW_UNI(nrej);
+            PQW_UNI(np); PQW_UNI(nexp); PQW_UNI(expanded); PQW_UNI(why); PQW_UNI(nrej);
+            um = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(um >> 32)) << 32) | (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)um);
             PQW_UNI(sc_node0); PQW_UNI(sc_node1); PQW_UNI(pf_node0); PQW_UNI(pf_node1); PQW_UNI(ru_pos); PQW_UNI(ru_lo); PQW_UNI(ru_hi);
             bscore = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(bscore)));
 #undef PQW_UNI
-            // ---- best unexpanded entry (every position < lo_un is expanded; sentinels have bit 0 clear) ----
-            int t1 = lo_un >> 6;
+            // ---- best unexpanded entry: first chunk whose bit is set (stale bits are cleared on the way; sentinels have bit 0 clear) ----
+            int t1 = 0;
             int64_t e1 = 0;
             unsigned long long m1 = 0ull;
-            for (; (t1 << 6) < np; t1++) {
+            while (um) {
+                t1 = __ffsll((long long)um) - 1;
                 e1 = pool[min((t1 << 6) + lane, cap)];
                 m1 = __ballot((e1 & 1ll) != 0);
                 if (m1) break;
+                um &= um - 1ull;
             }
             int c = -1, b1 = 0, idx = 0, pk_lo = 0, pk_hi = 0;
             bool reject = false;
@@ -322,12 +329,14 @@ __device__ void search_one_pqw(const JvIndexDev& ix, const JvSearchArgs& a, cons
                 ru_pos = -1;
                 if (!stop) {
                     unsigned long long mm = m1 & (m1 - 1ull);
-                    int elo = e1lo, ehi = e1hi;
+                    int elo = e1lo, ehi = e1hi, t2 = t1;
                     bool second = false;
 #pragma unroll
                     for (int k = 1; k < 4; k++) {
-                        if (!mm && !second && ((t1 + 1) << 6) < np) {
-                            const int64_t e2 = pool[min(((t1 + 1) << 6) + lane, cap)];
+                        const unsigned long long um2 = um & ~((2ull << t1) - 1ull);  // chunks behind the first that may hold more
+                        if (!mm && !second && um2) {
+                            t2 = __ffsll((long long)um2) - 1;
+                            const int64_t e2 = pool[min((t2 << 6) + lane, cap)];
                             mm = __ballot((e2 & 1ll) != 0);
                             elo = (int)(uint32_t)(e2 & 0xFFFFFFFFll);
                             ehi = (int)(e2 >> 32);
@@ -341,7 +350,7 @@ __device__ void search_one_pqw(const JvIndexDev& ix, const JvSearchArgs& a, cons
                             if (k == 1) {  // the runner-up's entry: its key and position decide whether both entries are expanded at once
                                 ru_lo = klo;
                                 ru_hi = __builtin_amdgcn_readlane(ehi, ln);
-                                ru_pos = ((second ? t1 + 1 : t1) << 6) + ln;
+                                ru_pos = (t2 << 6) + ln;
                             }
                             mm &= mm - 1ull;
                         }
@@ -364,6 +373,9 @@ __device__ void search_one_pqw(const JvIndexDev& ix, const JvSearchArgs& a, cons
                     pqw_barrier();  // A: the other waves learn which blocks to score
                 }
                 if (stop) break;
+                PQW_STAMP_COUNT(11, (pf_node0 == c && pf_node1 == bn1) ? 1 : 0)
+                PQW_STAMP_COUNT(12, (pf_node0 == c) ? 1 : 0)
+                PQW_STAMP_COUNT(8, 1)
                 PQW_STAMP(0)  // barrier A
                 const int wy = bn1 >= 0 ? bn1 : c;  // (no runner-up: the upper lanes score the same block again, unused)
                 u32x4 cw;
@@ -411,7 +423,6 @@ __device__ void search_one_pqw(const JvIndexDev& ix, const JvSearchArgs& a, cons
             nrej += reject ? 1 : 0;
             if (lane == 0) explog[nexp] = c;
             nexp++;
-            lo_un = idx + 1;
             expanded++;
             if (half == 0) sc_node0 = -1;
             else sc_node1 = -1;
@@ -499,6 +510,7 @@ __device__ void search_one_pqw(const JvIndexDev& ix, const JvSearchArgs& a, cons
                     const unsigned long long all = __ballot(cand);
                     if (!__ballot(keep && v > ruk) && np + __popcll(all) <= cap) {
                         dual = true;
+                        PQW_STAMP_COUNT(10, 1)
                         keep = cand;
                         if (lane == 0) {
                             ((int*)pool)[2 * ru_pos] = ru_lo & ~1;
@@ -506,7 +518,6 @@ __device__ void search_one_pqw(const JvIndexDev& ix, const JvSearchArgs& a, cons
                         }
                         nexp++;
                         expanded++;
-                        lo_un = ru_pos + 1;
                         sc_node1 = -1;
                     }
                 }
@@ -528,7 +539,6 @@ __device__ void search_one_pqw(const JvIndexDev& ix, const JvSearchArgs& a, cons
             unsigned long long km = __ballot(keep);
             int nk = __popcll(km);
             if (fresh) ins_lo = dual ? 0ull : km;  // (twins inside the row are taken out below)
-            PQW_STAMP_COUNT(8, __popcll(km))
             PQW_STAMP(3)  // boundary test + rank search + duplicate test
             if (nk > 0) {
                 int rnew = 0, r_min, r_max;
@@ -605,8 +615,19 @@ __device__ void search_one_pqw(const JvIndexDev& ix, const JvSearchArgs& a, cons
                     }
                 }
                 if (keep) pool[rold + rnew] = v;
-                PQW_STAMP_COUNT(11, nk)
-                PQW_STAMP_COUNT(12, ((np - 1) >> 6) - (r_min >> 6) + 1)
+                {
+                    // entries from the first insertion point on moved up by at most nk <= 64 positions: into their own chunk or
+                    // the next; the new keys are unexpanded where they landed
+                    const unsigned long long lowm = (1ull << (r_min >> 6)) - 1ull;
+                    um = (um & lowm) | ((um | (um << 1)) & ~lowm);
+                    const int npos = rold + rnew;
+                    unsigned long long it = km;
+                    while (it) {
+                        const int j = __ffsll((long long)it) - 1;
+                        it &= it - 1ull;
+                        um |= 1ull << (__builtin_amdgcn_readlane(npos, j) >> 6);
+                    }
+                }
                 PQW_STAMP(4)  // ranks among the new keys + shift + insert
                 // boundary = the rk-th best entry; entries behind it stay only while they tie with its score
                 const int ntot = np + nk;
@@ -639,7 +660,7 @@ __device__ void search_one_pqw(const JvIndexDev& ix, const JvSearchArgs& a, cons
                     }
                 }
                 if (lane >= (r_min >> 6)) pv = pool[min((lane << 6) + 63, cap)];  // chunks from the first insertion point on changed
-                lo_un = lo_un < r_min ? lo_un : r_min;
+                um &= (2ull << ((np - 1) >> 6)) - 1ull;  // (nothing behind the pool's last chunk)
                 PQW_STAMP(5)  // boundary + trim
                 if (why != 0) {  // (why = 3) leave through the common exit so that every wave sees it
                     if (W > 1) {

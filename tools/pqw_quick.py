@@ -74,5 +74,5 @@ for rk in rks:
             print(f"  {label}: cycles per expansion by phase")
             for i, nme in enumerate(names):
                 print(f"     {nme:40s} {100 * cyc[i] / max(cyc.sum(), 1):5.1f} %   {cyc[i] / ne:8.0f}")
-            print(f"     raw slots / expansion: " + " ".join(f"[{i}]={v[i] / ne:.2f}" if i in (8, 11, 12) else f"[{i}]={v[i] / ne:.0f}" for i in range(16)))
+            print(f"     raw slots / expansion: " + " ".join(f"[{i}]={v[i] / ne:.2f}" if i in (8, 10, 11, 12) else f"[{i}]={v[i] / ne:.0f}" for i in range(16)))
 ix.close()
