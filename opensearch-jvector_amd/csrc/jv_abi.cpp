@@ -312,11 +312,15 @@ int dev_alloc(jv_index* ix, T** out, size_t count) {
     return JV_OK;
 }
 
-void free_with_servers_paused(void* p);  // hipFree synchronises the device: resident query servers must leave first
+// hipFree / hipHostFree synchronise the device (they drain every stream): resident query servers of that device must leave
+// first — next to another index's grid under steady one-query load such a call would wait for ever.  The device is the
+// pointer's OWNER (hipPointerGetAttributes), not whatever device the calling thread happens to have current.
+void free_with_servers_paused(void* p, bool host);
 static inline hipError_t jv_free(void* p) {
-    free_with_servers_paused(p);
+    free_with_servers_paused(p, false);
     return hipSuccess;
 }
+static inline void jv_host_free(void* p) { free_with_servers_paused(p, true); }
 
 int grow(void** p, size_t* cap, size_t need, size_t elem) {
     if (need <= *cap && *p) return JV_OK;
@@ -348,11 +352,11 @@ void ctx_destroy(Ctx* c) {
     jv_free(c->d_flags);
     jv_free(c->d_accept);
     jv_free(c->d_accept_ord);
-    if (c->h_mark) hipHostFree(c->h_mark);
+    jv_host_free(c->h_mark);
     jv_free(c->d_arena);
-    if (c->h_arena) hipHostFree(c->h_arena);
-    if (c->h_query) hipHostFree(c->h_query);
-    if (c->h_direct) hipHostFree(c->h_direct);
+    jv_host_free(c->h_arena);
+    jv_host_free(c->h_query);
+    jv_host_free(c->h_direct);
     if (c->ev_direct) hipEventDestroy(c->ev_direct);
     jv_free(c->work_counter);
     jv_free(c->spill);
@@ -571,6 +575,7 @@ int plan_pqp_lds(const jv_index* ix, JvSearchArgs& x, bool regs, int rk) {
 }
 
 // enqueue one batch on `stream`; all pointers are device pointers
+void trace_point(Ctx* c, int i, hipStream_t stream);  // (JV_BATCH_TRACE diagnostics)
 int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queries, int nq, int topK, int rk,
                   float thr, float floor_, const uint64_t* d_accept, int64_t accept_docs, int32_t* d_nodes,
                   int32_t* d_docs, float* d_scores, int32_t* d_count, int32_t* d_stats, int32_t* d_flags,
@@ -620,7 +625,25 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
     a.retry_counter = c->work_counter + 2;
     a.dbg = (int64_t*)(uintptr_t)OPT(ix, OPT_DBG_PTR);  // always 0 unless a diagnostic run set it
     const bool force_big = OPT(ix, OPT_FORCE_BIG) != 0 || !g.fast_ok;
+    trace_point(c, 3, stream);
     HIPCHK(hipMemsetAsync(c->work_counter, 0, 16 * sizeof(int32_t), stream));
+    trace_point(c, 4, stream);
+    // Launches that only REDO flagged rows (second pool launch, 4x-hash escalation) need large workgroups; beside a live query-
+    // server grid they used to ask the grid to leave (servers_yield_lds) on EVERY batch call, flagged rows or not — a stop the
+    // caller waits for, and a restart for the next one-query call (tools/grid_start_probe.py: 600 grid starts in 6 s, p99 of the
+    // batch calls 17 ms, stalls of 0.6 s).  A host-pointer call (phase 1) now skips such a launch when it does not fit beside
+    // the live grids: its rows stay flagged and take the HBM-scratch rung in phase 2, which the caller only enqueues when a row
+    // actually came back flagged.  Unfiltered calls only: a selective filter's wide-pool rungs are its main path.
+    // "Fits" counts every EXISTING server grid, running or not (servers_free_lds): a grid that starts between this check and the
+    // kernel's dispatch takes its LDS on every CU first, and a workgroup that needs more than the rest is not placed until the grid
+    // leaves — idle for serve_idle_ms, or never under steady traffic.  That race was the "call that overlaps a grid's START waits
+    // until the grid idles out" of round 3 (JV_BATCH_TRACE=1: the stream stopped in front of the escalation rung's launch, whose
+    // workgroups had no row to redo but each needed ~100 KB of LDS).
+    auto retry_rung_ok = [&](int lds_bytes) -> bool {
+        if (phase == 1 && d_accept == nullptr && servers_free_lds(ix->device) < lds_bytes) return false;
+        servers_yield_lds(ix->device, lds_bytes);
+        return true;
+    };
     // PQ tables beyond the LDS (g.lutg: the reference's default 192 subspaces): on the fused layout the several-waves kernel
     // takes them first — twelve waves hold the table in registers + LDS rows — and the HBM-scratch rung (table in HBM) only
     // redoes what comes back flagged; everything else about such shapes (filters, thresholds, cosine) is that rung's alone
@@ -800,15 +823,17 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
             }
             ap.pqp_log = c->pqp_log;
             ap.pqp_counter = c->work_counter + 6;
+            const bool second_now = second && nrungs == 0 && retry_rung_ok(lds2);
             {
-                int lds_max = std::max(lds, second ? lds2 : 0);
+                int lds_max = lds;
                 for (int i = 0; i < nrungs; i++) lds_max = std::max(lds_max, rungs[i].lds);
                 servers_yield_lds(ix->device, lds_max);
             }
             if (pqw) HIPCHK(jvk_launch_search_pqw(&ix->dev, &ap, lds, blocks, pqw_variant, stream));
             else HIPCHK(jvk_launch_search_pqp(&ix->dev, &ap, lds, blocks, lutr, stream));
             ix->launches[pqw ? LAUNCH_PQW : LAUNCH_PQP]++;
-            if (second && nrungs == 0) {
+            trace_point(c, 5, stream);
+            if (second_now) {
                 ap2.pqp_log = c->pqp_log;
                 HIPCHK(jvk_launch_search_pqp(&ix->dev, &ap2, lds2, blocks2, lutr2, stream));
             }
@@ -856,7 +881,7 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
                 ap2.res_cap = 2048;
                 ap2.retry_only = 1;
                 ap2.retry_counter = c->work_counter + 5;
-                if (loop_bytes(ap2) <= kMaxLds) HIPCHK(jvk_launch_search_pqf(&ix->dev, &ap2, (loop_bytes(ap2) + 15) & ~15, stream));
+                if (loop_bytes(ap2) <= kMaxLds && retry_rung_ok((loop_bytes(ap2) + 15) & ~15)) HIPCHK(jvk_launch_search_pqf(&ix->dev, &ap2, (loop_bytes(ap2) + 15) & ~15, stream));
             }
         }
     }
@@ -880,12 +905,15 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
                 a2.res_cap = g2.res_cap;
                 a2.retry_only = 1;
                 a2.retry_counter = c->work_counter + 4;
-                servers_yield_lds(ix->device, g2.lds_fast);
-                HIPCHK(jvk_launch_search_lds(&ix->dev, &a2, pq ? 1 : 0, g2.pool ? 1 : 0, 1, g2.lds_fast, stream));
+                if (!pqf || retry_rung_ok(g2.lds_fast)) {  // (behind the generic first launch it stays: that one already needed the room)
+                    servers_yield_lds(ix->device, g2.lds_fast);
+                    HIPCHK(jvk_launch_search_lds(&ix->dev, &a2, pq ? 1 : 0, g2.pool ? 1 : 0, 1, g2.lds_fast, stream));
+                }
             }
         }
     }
     }
+    trace_point(c, 6, stream);
     if (phase == 1 && (!force_big || first_ran)) {
         if (big_deferred) *big_deferred = true;
         return JV_OK;
@@ -1030,10 +1058,12 @@ struct ServerPause {
     }
 };
 
-void free_with_servers_paused(void* p) {
+void free_with_servers_paused(void* p, bool host) {
     if (!p) return;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) == hipSuccess && attr.device >= 0) dev = attr.device;
+    else if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     bool any;
     {
         std::lock_guard<std::mutex> g(g_servers_mu);
@@ -1041,9 +1071,11 @@ void free_with_servers_paused(void* p) {
     }
     if (any) {
         ServerPause pause(dev);
-        hipFree(p);
+        if (host) hipHostFree(p);
+        else hipFree(p);
     } else {
-        hipFree(p);
+        if (host) hipHostFree(p);
+        else hipFree(p);
     }
 }
 
@@ -1090,10 +1122,11 @@ void server_destroy_one(jv_index* ix, Server*& ref) {
     }
     if (sv->stream) hipStreamDestroy(sv->stream);
     if (sv->up_stream) hipStreamDestroy(sv->up_stream);
-    if (sv->ring) hipHostFree(sv->ring);
-    if (sv->h_words) hipHostFree(sv->h_words);
-    hipFree(sv->d_words);
-    hipFree(sv->log);
+    // (this server is off the list and its grid has left: the frees below pause the OTHER servers of the device)
+    jv_host_free(sv->ring);
+    jv_host_free(sv->h_words);
+    jv_free(sv->d_words);
+    jv_free(sv->log);
     delete[] sv->slot_free;
     delete sv;
     ref = nullptr;
@@ -1125,7 +1158,13 @@ Server* server_get(jv_index* ix, int kind, int need_cap, int* rc) {
     *rc = JV_OK;
     std::lock_guard<std::mutex> lk(ix->server_mu);
     Server*& ref = kind == 0 ? ix->server : ix->server_f;
-    if (ref && ref->cap_max >= need_cap) return ref;
+    // (the caller's reference is taken HERE, under ix->server_mu: a concurrent call that needs a larger pool waits for
+    //  inflight == 0 under the same lock before it frees the server — counted after the lock was dropped, a caller could be
+    //  left writing into a freed ring)
+    if (ref && ref->cap_max >= need_cap) {
+        ref->inflight++;
+        return ref;
+    }
     if (ref) {  // a larger beam than the ring was planned for: rebuild it once nothing is in flight
         Server* old = ref;
         while (old->inflight.load() > 0) sched_yield();
@@ -1138,8 +1177,8 @@ Server* server_get(jv_index* ix, int kind, int need_cap, int* rc) {
     {
         std::lock_guard<std::mutex> g(g_servers_mu);
         int same = 0;
-        for (Server* o : g_servers) same += (o->ix->device == ix->device && o->kind == kind) ? 1 : 0;
-        if (same >= 4) return nullptr;  // (one hardware queue per grid: see the stream's creation below; such calls take the launch path)
+        for (Server* o : g_servers) same += o->ix->device == ix->device ? 1 : 0;
+        if (same >= 4) return nullptr;  // (one hardware queue per grid, BOTH kinds share the priority level: see the stream's creation below; such calls take the launch path)
     }
     Server* sv = new Server();
     sv->ix = ix;
@@ -1157,7 +1196,7 @@ Server* server_get(jv_index* ix, int kind, int need_cap, int* rc) {
     a.nq = 1;
     int per_cu;
     if (kind == 0) {
-        sv->cap_max = std::min(2048, std::max(need_cap, 512));
+        sv->cap_max = need_cap <= 512 ? 512 : (need_cap <= 1024 ? 1024 : 2048);  // (the kernel's capacity classes: at most two rebuilds per index)
         a.cand_cap = sv->cap_max;
         a.rk = sv->cap_max - 64 - R;
         a.pqp_log_cap = (3 * a.rk + 64 + 3) & ~3;
@@ -1198,8 +1237,8 @@ Server* server_get(jv_index* ix, int kind, int need_cap, int* rc) {
     // The grid never ends, and the HIP runtime multiplexes streams onto a few hardware queues PER PRIORITY LEVEL
     // (GPU_MAX_HW_QUEUES = 4): on a default-priority stream it sat in front of every other stream that happened to share its
     // queue — a batch call then waited until the one-query traffic stopped.  The grids therefore run on streams of their own
-    // priority levels (unfiltered servers: the highest, filtered servers: the lowest; nothing else in this library uses those),
-    // and at most four per level and device are started (a fifth would share a queue with — and wait for ever behind — another).
+    // priority level (the lowest; nothing else in this library uses it), and at most four per device — both kinds together —
+    // are started (a fifth would share a queue with — and wait for ever behind — another).
     int prio_least = 0, prio_greatest = 0;
     hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     hipError_t e = hipStreamCreateWithPriority(&sv->stream, hipStreamNonBlocking, prio_least);
@@ -1227,6 +1266,7 @@ Server* server_get(jv_index* ix, int kind, int need_cap, int* rc) {
         std::lock_guard<std::mutex> g(g_servers_mu);
         g_servers.push_back(sv);
     }
+    sv->inflight++;  // (the caller's reference, as above)
     return sv;
 }
 
@@ -1258,8 +1298,6 @@ int serve_query(jv_index* ix, const float* query, int32_t topK, int32_t rerankK,
     int rc = JV_OK;
     Server* sv = server_get(ix, kind, kind == 0 ? cap : 0, &rc);  // (the filtered server has ONE pool size: what the LDS allows)
     if (!sv) return rc != JV_OK ? rc : 1;
-    if (kind == 1 && cap > sv->cap_max) return 1;
-    sv->inflight++;
     struct Leave {
         Server* sv;
         jv_index* ix;
@@ -1268,7 +1306,8 @@ int serve_query(jv_index* ix, const float* query, int32_t topK, int32_t rerankK,
             if (fslot >= 0) filter_release(ix, fslot);
             sv->inflight--;
         }
-    } leave{sv, ix, -1};
+    } leave{sv, ix, -1};  // (server_get took the reference)
+    if (kind == 1 && cap > sv->cap_max) return 1;
     const uint64_t* d_filter = nullptr;
     if (kind == 1) {
         // the filter's bits in HBM: from the cache (verified byte for byte), or uploaded now and waited for — the grid reads
@@ -1300,6 +1339,7 @@ int serve_query(jv_index* ix, const float* query, int32_t topK, int32_t rerankK,
     slot->done = 0;
     slot->count = 0;
     slot->flags = 0;
+    slot->ticket = (int32_t)seq;  // (a grid only answers a slot whose content belongs to the ticket it claimed)
     memcpy(sp + JV_SERVE_QUERY_OFF, query, (size_t)ix->dev.d * sizeof(float));
     // publish in ticket order
     for (int spins = 0; (uint32_t)__atomic_load_n(&sv->h_words[JV_SH_TAIL], __ATOMIC_ACQUIRE) != seq; spins++) {
@@ -1316,7 +1356,9 @@ int serve_query(jv_index* ix, const float* query, int32_t topK, int32_t rerankK,
         return server_launch_locked(sv);
     };
     if ((rc = ensure_alive()) != JV_OK) {
-        // nobody will ever answer this slot: give it back in order (the row is simply never read)
+        // nobody answers this call: the ticket stays published, so the slot is marked abandoned before it is handed on — the
+        // grid that claims the ticket later finds another generation in the slot and skips it
+        __atomic_store_n(&slot->ticket, (int32_t)(seq ^ 0x40000000u), __ATOMIC_RELEASE);
         sv->slot_free[si].store(seq + (uint32_t)sv->slots, std::memory_order_release);
         return rc;
     }
@@ -1333,6 +1375,7 @@ int serve_query(jv_index* ix, const float* query, int32_t topK, int32_t rerankK,
         nanosleep(&ts, nullptr);
         nap_ns = std::max<long>(20000, (long)est * 25);  // then every est / 40
         if ((it & 7) == 7 && (rc = ensure_alive()) != JV_OK) {
+            __atomic_store_n(&slot->ticket, (int32_t)(seq ^ 0x40000000u), __ATOMIC_RELEASE);
             sv->slot_free[si].store(seq + (uint32_t)sv->slots, std::memory_order_release);
             return rc;
         }
@@ -1855,6 +1898,16 @@ void filter_release(jv_index* ix, int slot) {
 
 // Enqueue a marker behind everything on the context's stream and wait for it by polling host memory; falls back to the
 // runtime's wait when the marker does not show up (a faulted kernel never writes it)
+// diagnostics (JV_BATCH_TRACE=1): trace point i of the running call — a marker kernel writes the call's sequence number into
+// word i of the marker block; a call that waits longer than 5 ms prints which points the stream has passed
+static bool batch_trace() {
+    static const bool on = getenv("JV_BATCH_TRACE") != nullptr;
+    return on;
+}
+void trace_point(Ctx* c, int i, hipStream_t stream) {
+    if (!batch_trace() || !c->h_mark || i < 1 || i > 15) return;
+    jvk_launch_mark(c->h_mark + i, c->mark_seq + 1, stream);
+}
 int mark_enqueue(Ctx* c) {
     if (!c->h_mark) {
         HIPCHK(hipHostMalloc((void**)&c->h_mark, 64, hipHostMallocMapped | hipHostMallocCoherent));
@@ -1875,6 +1928,11 @@ int mark_wait(Ctx* c) {
         }
         struct timespec ts = {0, 20000};  // 20 us
         nanosleep(&ts, nullptr);
+        if (batch_trace() && spins == 400) {  // ~ 8 ms in
+            fprintf(stderr, "[jvgpu batch] call %d still waiting; trace points passed:", c->mark_seq);
+            for (int i = 1; i < 16; i++) fprintf(stderr, " %d%s", i, __atomic_load_n(c->h_mark + i, __ATOMIC_ACQUIRE) == c->mark_seq ? "+" : "-");
+            fprintf(stderr, "\n");
+        }
         if ((spins & 1023) == 0) {
             struct timespec t1;
             clock_gettime(CLOCK_MONOTONIC, &t1);
@@ -1949,7 +2007,7 @@ int search_batch_host(jv_index* index, const float* queries, int32_t nq, int32_t
     if (total4 * 4 > c->arena_cap) {
         jv_free(c->d_arena);
         c->d_arena = nullptr;
-        if (c->h_arena) hipHostFree(c->h_arena);
+        jv_host_free(c->h_arena);
         c->h_arena = nullptr;
         c->arena_cap = 0;
         const size_t cap = total4 * 4 + total4;  // 25 % head room
@@ -1965,7 +2023,7 @@ int search_batch_host(jv_index* index, const float* queries, int32_t nq, int32_t
     if (direct || pinned_out) {
         const size_t need = (total4 + (size_t)nq) * 4;
         if (need > c->direct_cap) {
-            if (c->h_direct) hipHostFree(c->h_direct);
+            jv_host_free(c->h_direct);
             c->h_direct = nullptr;
             c->direct_cap = 0;
             const size_t cap = std::max<size_t>(need + need / 4, 65536);
@@ -2020,9 +2078,10 @@ int search_batch_host(jv_index* index, const float* queries, int32_t nq, int32_t
         }
     }
     const size_t qbytes = (size_t)nq * d * sizeof(float);
+    trace_point(c, 1, c->stream);
     if (qbytes <= (1u << 20)) {  // small batches: stage through pinned memory (a pageable H2D is a blocking staged copy)
         if (qbytes > c->h_query_cap) {
-            if (c->h_query) hipHostFree(c->h_query);
+            jv_host_free(c->h_query);
             c->h_query = nullptr;
             HIPCHK(hipHostMalloc((void**)&c->h_query, qbytes < 65536 ? 65536 : qbytes, hipHostMallocDefault));
             c->h_query_cap = qbytes < 65536 ? 65536 : qbytes;
@@ -2032,6 +2091,7 @@ int search_batch_host(jv_index* index, const float* queries, int32_t nq, int32_t
     } else {
         HIPCHK(hipMemcpyAsync(c->d_queries, queries, qbytes, hipMemcpyHostToDevice, c->stream));
     }
+    trace_point(c, 2, c->stream);
     const int phase1 = OPT(index, OPT_LAZY_BIG) != 0 ? 1 : 0;
     bool big_owed = false;
     rc = enqueue_batch(index, c, c->stream, c->d_queries, nq, topK, rerankK, threshold, rerankFloor, d_accept,
@@ -2050,8 +2110,23 @@ int search_batch_host(jv_index* index, const float* queries, int32_t nq, int32_t
         const int32_t* h32d = (const int32_t*)c->h_direct;
         std::vector<char> delivered((size_t)nq, 0);
         int remaining = nq, failed_d = 0, first_d = -1;
+        struct timespec td0;
+        clock_gettime(CLOCK_MONOTONIC, &td0);
+        bool drained = false;  // the runtime confirmed that the stream ran dry (deadline path)
         for (int spins = 0; remaining > 0; spins++) {
-            const hipError_t qe = mark_reached(c) ? hipSuccess : hipErrorNotReady;  // (a marker in host memory, not hipEventQuery: see mark_enqueue)
+            if (!drained && (spins & 4095) == 4095) {
+                // same deadline as mark_wait: a marker that never lands (a kernel of the batch faulted) must not leave this
+                // leader — and every combined caller blocked on its semaphore — spinning for ever
+                struct timespec td1;
+                clock_gettime(CLOCK_MONOTONIC, &td1);
+                if (td1.tv_sec - td0.tv_sec > 20) {
+                    const hipError_t se = hipStreamSynchronize(c->stream);
+                    if (se != hipSuccess)  // (the caller hands this code to every owner that was not served: jv_search's combiner)
+                        return fail(JV_EDEVICE, "batch did not complete: %s", hipGetErrorString(se));
+                    drained = true;
+                }
+            }
+            const hipError_t qe = (drained || mark_reached(c)) ? hipSuccess : hipErrorNotReady;  // (a marker in host memory, not hipEventQuery: see mark_enqueue)
             bool finished = qe == hipSuccess;
             if (finished && big_owed) {
                 bool any = false;
@@ -2060,6 +2135,8 @@ int search_batch_host(jv_index* index, const float* queries, int32_t nq, int32_t
                 if (any) {
                     if ((rc = enqueue_big()) != JV_OK) return rc;
                     if ((rc = mark_enqueue(c)) != JV_OK) return rc;
+                    drained = false;
+                    clock_gettime(CLOCK_MONOTONIC, &td0);
                     finished = false;  // (rows without the flag are final and are handed out below)
                 }
                 big_owed = false;
@@ -2480,7 +2557,7 @@ int jv_score_ordinals(jv_index* index, const float* query, const int32_t* ordina
     if (need > c->arena_cap) {
         jv_free(c->d_arena);
         c->d_arena = nullptr;
-        if (c->h_arena) hipHostFree(c->h_arena);
+        jv_host_free(c->h_arena);
         c->h_arena = nullptr;
         c->arena_cap = 0;
         const size_t cap = need + need / 4;
@@ -2845,11 +2922,14 @@ int jv_search_sharded_batch_ex(jv_shard_group* grp, const float* queries, int32_
             grp->cap_gathered = 2 * outn * (size_t)G;
         }
         int r = api.GroupStart();
-        for (int g = 0; g < G && r == 0; g++) {
-            HIPCHK(hipSetDevice(grp->shards[(size_t)g]->device));
+        hipError_t he = hipSuccess;  // (no early return between GroupStart and GroupEnd: the group would stay open)
+        for (int g = 0; g < G && r == 0 && he == hipSuccess; g++) {
+            he = hipSetDevice(grp->shards[(size_t)g]->device);
+            if (he != hipSuccess) break;
             r = api.AllGather(grp->per[(size_t)g].d_pairs, grp->d_gathered[(size_t)g], 2 * outn, kNcclInt32, grp->comms[(size_t)g], grp->per[(size_t)g].stream);
         }
         const int r2 = api.GroupEnd();
+        if (he != hipSuccess) return fail(JV_EDEVICE, "hipSetDevice failed inside the all-gather group: %s", hipGetErrorString(he));
         if (r != 0 || r2 != 0) return fail(JV_EDEVICE, "ncclAllGather failed: %s", api.GetErrorString ? api.GetErrorString(r != 0 ? r : r2) : "?");
         for (int g = 0; g < G; g++) {
             HIPCHK(hipSetDevice(grp->shards[(size_t)g]->device));

@@ -114,7 +114,7 @@ struct JvServeSlot {           // header of one ring slot; the query (float[d], 
     int32_t done;              // 0 while pending; 1 once the row below is final
     int32_t count, flags;
     int32_t stats[4];
-    int32_t pad0;
+    int32_t ticket;            // the sequence number this slot's content belongs to (a grid skips a slot of another generation)
     uint64_t accept;           // filtered server only: the query's doc filter, a DEVICE pointer (the index's filter cache owns it) ...
     int64_t accept_docs;       // ... and its doc-id space
     int32_t nodes[JV_SERVE_TOPK_MAX];

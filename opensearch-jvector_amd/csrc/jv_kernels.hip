@@ -31,7 +31,7 @@
 // LUTG: the PQ look-up table lives in this workgroup's HBM scratch instead of LDS (pq_M * 1 KB beyond the LDS: the reference's
 // default 192 subspaces for d >= 768, J/JVectorIndexQuantization.java:428-446) — same arithmetic, gathers served by L1 / L2
 template <bool PQ, bool BIG, bool POOL, int NCHT, bool QLDS = false, bool LUTG = false>
-__device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, unsigned char* smem,
+__device__ __forceinline__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, unsigned char* smem,
                            int64_t* big_cand, uint32_t* big_bits) {
     const int lane = threadIdx.x;
     const int rk = a.rk, topK = a.topK;
@@ -724,7 +724,7 @@ __device__ void search_one(const JvIndexDev& ix, const JvSearchArgs& a, int qi, 
 // FAST = pq_M is a multiple of 16 and the similarity is not cosine: only the unmasked LDS look-up is compiled
 // (the masked and norm-table variants cost ~70 scalar registers of hoisted lane predicates even when unused).
 template <int NCHT, int CH, int NP, bool FILT, bool FAST>
-__device__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int qi, unsigned char* smem) {
+__device__ __forceinline__ void search_one_pqf(const JvIndexDev& ix, const JvSearchArgs& a, int qi, unsigned char* smem) {
     const int lane = threadIdx.x;
     const uint64_t* const accw = FILT ? a.accept + (size_t)qi * (size_t)a.accept_stride : nullptr;
     auto accepts = [&](int node) -> bool {  // the reference's acceptOrds lambda

@@ -8,8 +8,8 @@ typedef void (*pqs_kernel_t)(const JvIndexDev, const JvSearchArgs);
 // [0 -> two waves per query (PQ-32), 1 -> four (PQ-64)][capacity class 0..2][nch slot]; the latency variant of
 // jv_kernels_pqw.hip (whole table in LDS): a server query's time is its caller's latency
 static const pqs_kernel_t g_pqs_kernels[2][3][4] = {
-    {JV_PQS_ROW(0, 2, 4, 16), JV_PQS_ROW(1, 2, 4, 16), JV_PQS_ROW(2, 2, 4, 16)},
-    {JV_PQS_ROW(0, 4, 4, 16), JV_PQS_ROW(1, 4, 4, 16), JV_PQS_ROW(2, 4, 4, 16)},
+    {JV_PQS_ROW(0, 2, 2, 16), JV_PQS_ROW(1, 2, 2, 16), JV_PQS_ROW(2, 2, 2, 16)},  // (two workgroups per CU: registers to spare — a resident grid that needs no scratch never makes the runtime move scratch between queues)
+    {JV_PQS_ROW(0, 4, 2, 16), JV_PQS_ROW(1, 4, 2, 16), JV_PQS_ROW(2, 4, 2, 16)},
 };
 
 static int pqs_nch_slot(const JvIndexDev* ix) {

@@ -18,6 +18,10 @@ __global__ __launch_bounds__(JV_WAVE, 1) void jv_serve_pqp_kernel(const JvIndexD
         if (ticket < 0) break;
         unsigned char* const sp = a.serve_ring + (size_t)(ticket & (a.serve_slots - 1)) * (size_t)a.serve_slot_bytes;
         JvServeSlot* const slot = (JvServeSlot*)sp;
+        if (!jv_serve_slot_current(slot, ticket)) {  // an abandoned ticket: nothing to answer
+            __syncthreads();
+            continue;
+        }
         JvSearchArgs aq = a;  // (pool capacity, LDS plan and log length are the server's: every request runs in the largest pool)
         aq.queries = (const float*)(sp + JV_SERVE_QUERY_OFF);
         aq.nq = 1;

@@ -12,8 +12,8 @@ typedef void (*pqw_kernel_t)(const JvIndexDev, const JvSearchArgs);
 static const pqw_kernel_t g_pqw_kernels[4][3][4] = {
     {JV_PQW_ROW(0, 2, 4, 4), JV_PQW_ROW(1, 2, 4, 4), JV_PQW_ROW(2, 2, 4, 4)},
     {JV_PQW_ROW(0, 4, 4, 4), JV_PQW_ROW(1, 4, 4, 4), JV_PQW_ROW(2, 4, 4, 4)},
-    {JV_PQW_ROW(0, 2, 4, 16), JV_PQW_ROW(1, 2, 4, 16), JV_PQW_ROW(2, 2, 4, 16)},
-    {JV_PQW_ROW(0, 4, 4, 16), JV_PQW_ROW(1, 4, 4, 16), JV_PQW_ROW(2, 4, 4, 16)},
+    {JV_PQW_ROW(0, 2, 2, 16), JV_PQW_ROW(1, 2, 2, 16), JV_PQW_ROW(2, 2, 2, 16)},  // (<= 3 workgroups per CU: two waves per SIMD, 256 registers — no scratch)
+    {JV_PQW_ROW(0, 4, 3, 16), JV_PQW_ROW(1, 4, 3, 16), JV_PQW_ROW(2, 4, 3, 16)},
 };
 
 static int pqw_nch_slot(const JvIndexDev* ix) {

@@ -71,7 +71,7 @@ __device__ __forceinline__ int rank_level(const int64_t* pool, int lo, int last,
 //       every node is traversed: the pool holds every scored node whose score >= the rerankK-th best ACCEPTED one
 //       (~ rerankK / selectivity entries); `bpos` tracks that entry.  Single-pass blocks only (NP = 1).
 template <int NCHT, int NP, bool FAST, int CAPK, bool LUTR, bool FILT = false>
-__device__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, const int qi, unsigned char* smem, int32_t* explog) {
+__device__ __forceinline__ void search_one_pqp(const JvIndexDev& ix, const JvSearchArgs& a, const int qi, unsigned char* smem, int32_t* explog) {
     const int lane = threadIdx.x;
     const int rk = a.rk, topK = a.topK;
     const int M = ix.pq_M, R = ix.R, lpn = ix.pq_lanes, cs = ix.pq_code_stride;

@@ -76,7 +76,7 @@ enum { PQW_C = 0, PQW_C2 = 1, PQW_WHY = 2, PQW_NP = 3, PQW_NEXP = 4, PQW_EXPANDE
 // NL:   the first NL of a wave's 16 subspaces keep their table rows in LDS (plain gathers) instead of registers: every
 //       look-up served from LDS saves four ds_bpermute — the LDS unit is this kernel's busiest resource — and four VGPRs
 template <int NCHT, int CAPK, int W, int NL>
-__device__ void search_one_pqw(const JvIndexDev& ix, const JvSearchArgs& a, const int qi, unsigned char* smem, int32_t* explog) {
+__device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSearchArgs& a, const int qi, unsigned char* smem, int32_t* explog) {
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int rk = a.rk, topK = a.topK;
@@ -1034,6 +1034,10 @@ __global__ __launch_bounds__(JV_WAVE * W, OCC) void jv_serve_pqw_kernel(const Jv
         if (ticket < 0) break;
         unsigned char* const sp = a.serve_ring + (size_t)(ticket & (a.serve_slots - 1)) * (size_t)a.serve_slot_bytes;
         JvServeSlot* const slot = (JvServeSlot*)sp;
+        if (!jv_serve_slot_current(slot, ticket)) {  // an abandoned ticket: nothing to answer
+            __syncthreads();
+            continue;
+        }
         JvSearchArgs aq = a;
         aq.queries = (const float*)(sp + JV_SERVE_QUERY_OFF);
         aq.nq = 1;

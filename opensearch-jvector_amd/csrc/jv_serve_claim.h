@@ -53,10 +53,19 @@ __device__ __forceinline__ int jv_serve_claim(const JvSearchArgs& a) {
             if ((h & 31) == 0 && __hip_atomic_load(&a.serve_host[JV_SH_STOP], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0)
                 __hip_atomic_store(&a.serve_dev[JV_SV_STOP_SEEN], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&a.serve_dev[JV_SV_LAST_CLAIM], (int)(uint32_t)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // the slot was written by the host BEFORE its release-store of TAIL, which some workgroup read with acquire before it
+            // advanced PUBLISHED; this workgroup only saw PUBLISHED / HEAD (relaxed): order its reads of the slot behind the claim
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
             break;
         }
     }
     return ticket;
+}
+
+// every thread: true when the slot's content belongs to the claimed ticket (a caller that gave up on a grid that could not be
+// started leaves its ticket published and marks the slot; the slot may even belong to a later call by now)
+__device__ __forceinline__ bool jv_serve_slot_current(const JvServeSlot* slot, int ticket) {
+    return __builtin_amdgcn_readfirstlane(__hip_atomic_load(&slot->ticket, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM)) == ticket;  // (wave-uniform)
 }
 
 // the last workgroup out tells the host that the grid is gone (a caller that finds work pending launches it again)

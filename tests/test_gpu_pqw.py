@@ -279,3 +279,56 @@ def test_query_server_wide_tables(pkg, pyoracle, M, d):
     assert not errors, errors[:4]
     assert gpu.counter("served_queries") >= 8 * 24 - 8, gpu.counter("served_queries")
     gpu.close()
+
+
+def test_batch_calls_do_not_wait_for_a_starting_server_grid(pkg):
+    """Host-pointer batch calls next to one-query traffic that makes the resident server grid start over and over (bursts
+    separated by pauses longer than serve_idle_ms).  Round 3's known issue: a batch call that overlapped a grid START
+    returned only when the grid idled out — its escalation rung (no rows to redo, ~100 KB of LDS per workgroup) had been
+    enqueued a moment before the grid took its LDS on every CU.  >= 50 starts, p99 of the batch calls < 10 ms, answers right."""
+    import threading, time
+    b, bl, dg = pkg.binding, pkg.builder, pkg.datagen
+    n, d, rk, nq = 4000, 64, 120, 64
+    base = dg.splitmix_uniform(31, n, d)
+    q = dg.splitmix_uniform(32, 512, d)
+    ix = bl.build_index_cpu(base, 0, R=32, L=60, pq_M=32)
+    gpu = b.GpuIndex(ix, flags=b.DESC_FUSED_ADC)
+    gpu.set_option("serve_idle_ms", 3)
+    want = gpu.search_batch(q, 10, rk)
+    for _ in range(3):
+        gpu.search_batch(q[:nq], 10, rk)   # (launch contexts and buffers exist before the clock starts)
+    stop, lat, bad = threading.Event(), [], []
+
+    def singles(tid):
+        i = tid
+        while not stop.is_set():
+            for _ in range(20):
+                j = i % len(q)
+                i += 7
+                r = gpu.search(q[j], 10, rk)
+                if not np.array_equal(r.nodes[0], want.nodes[j]):
+                    bad.append(("single", j))
+            time.sleep(0.010)
+
+    def batches():
+        while not stop.is_set():
+            t = time.perf_counter()
+            r = gpu.search_batch(q[:nq], 10, rk)
+            lat.append((time.perf_counter() - t) * 1e3)
+            if not np.array_equal(r.nodes, want.nodes[:nq]):
+                bad.append(("batch",))
+
+    ts = [threading.Thread(target=singles, args=(t,)) for t in range(4)] + [threading.Thread(target=batches)]
+    [t.start() for t in ts]
+    deadline = time.time() + 20.0
+    while gpu.counter("launches_serve") < 60 and time.time() < deadline:
+        time.sleep(0.25)
+    stop.set()
+    [t.join(timeout=60) for t in ts]
+    assert not any(t.is_alive() for t in ts), "a caller is stuck"
+    assert not bad, bad[:3]
+    starts = gpu.counter("launches_serve")
+    assert starts >= 50, f"only {starts} grid starts: the fixture no longer restarts the grid"
+    p99 = float(np.percentile(np.array(lat), 99))
+    assert len(lat) > 200 and p99 < 10.0, f"batch calls next to {starts} grid starts: p99 {p99:.1f} ms, max {max(lat):.1f} ms over {len(lat)} calls"
+    gpu.close()
