@@ -31,6 +31,10 @@ WORKLOADS = {
     # BASELINE.json configs[1]
     "c2": dict(desc="1Mx768 dot-product fp32 resident, rerankK swept for recall@10>=0.95", n=1_000_000, d=768, sim=1,
                pq_M=0, normalize=True),
+    # SURVEY 8(d)'s own distribution B at the headline's size, on the EXACT provider (no PQ: 32-byte codes cannot rank it —
+    # recall@10 0.10 at rerankK 900): one number on the survey's distribution next to the rotated headline
+    "c2b": dict(desc="10Mx768 L2 fp32 exact provider (no PQ) on SURVEY 8(d) distribution B (4 096-centre Gaussian mixture)",
+                n=10_000_000, d=768, sim=0, pq_M=0, normalize=False, dist="mixtureB"),
     # BASELINE.json configs[2] — the configuration the metric is quoted on
     # (262 144 queries per step: per-query work varies 3x around its mean, and the drain of the slowest queries at
     # the end of a launch costs ~7 % at 65 536 queries per step, ~2 % here)
@@ -511,8 +515,8 @@ def main():
 
     def make_engine(dist_name):
         t0 = time.time()
-        if pq_M:
-            base, queries = make_pq_data(torch, dist_name, n, nq_pool, d, data_M, row_offset, n_total, wl["normalize"], device)
+        if pq_M or wl.get("dist"):
+            base, queries = make_pq_data(torch, dist_name, n, nq_pool, d, data_M or 32, row_offset, n_total, wl["normalize"], device)
         else:
             centres = max(64, min(4096, n_total // 256))
             cen, basis = make_generators(torch, d, device, centres, 32)
@@ -525,7 +529,7 @@ def main():
         log(f"rank {rank}: built index ({args.builder}) in {eng.build_s:.1f}s, entry={eng.entry}")
         return eng
 
-    dist_name = args.dist if pq_M else "lowrank-mixture"
+    dist_name = wl["dist"] if wl.get("dist") else (args.dist if pq_M else "lowrank-mixture")
     eng = make_engine(dist_name)
 
     # ---- ground truth + rerankK selection (recall@10 >= 0.95) ----
@@ -546,6 +550,7 @@ def main():
     bytes_per_launch = bytes_total / args.steps
     achieved_gbs = bytes_per_launch / (kernel_avg_ms * 1e-3) / 1e9
     traffic = None
+    traffic_source = None  # (traffic is NOT measured in this run: it is the kept PMC result of the same command, labelled as such)
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tpath):
         # HBM bytes per launch from the PMC passes of the same command (tools/profile_bench.sh ->
@@ -555,6 +560,7 @@ def main():
             if world == 1 and tj and tj.get("n") == n and tj.get("batch") == B and tj.get("rerankK") == rk \
                     and tj.get("dist", "aligned") == dist_name:
                 traffic = tj.get("hbm_bytes_per_launch")
+                traffic_source = f"{tj.get('source', 'profiles/traffic_latest.json')} (PMC passes kept from {tj.get('date', 'an earlier run')}; not re-measured by this run)"
         except Exception:
             traffic = None
 
@@ -659,7 +665,7 @@ def main():
         "big_path_queries_last_step": t["big_path_last_step"],
         "build_seconds": round(eng.build_s, 1),
         "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": main_kernel, "kernel_avg_ms": round(kernel_avg_ms, 4),
                      "algorithmic_bytes_per_launch": round(bytes_per_launch, 1),
                      "formula": ("expanded*R*(M+4) + reranked*4d + 1024d/B" if fused else

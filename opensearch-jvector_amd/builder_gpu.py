@@ -10,8 +10,9 @@ search benchmark within minutes, this module builds them on the GPU:
   client of the hot path, exactly as jvector's builder is a client of ``GraphSearcher`` —, (b) prunes
   each node's candidates with jvector-style diversity selection (alpha sweep 1.0 -> alpha), (c) adds
   back-links with ``neighborOverflow`` slack and re-prunes the rows that overflow, and finally (d)
-  ``cleanup`` prunes every row to R.  Steps (b)-(d) are dense linear algebra over small candidate
-  sets (Gram matrices via batched GEMM) and are written with torch ops: plumbing, not product.
+  ``cleanup`` prunes every row to R.  The diversity selection of (b)-(d) — scores to the centre, ordering, the
+  candidate x candidate products and the alpha sweep — is ONE hand-written kernel per call
+  (csrc/jv_build_kernels.hip jvb_prune_rows_kernel); what is left in torch is buffer bookkeeping.
 * **PQ**: Lloyd k-means per subspace (256 clusters, global centring iff EUCLIDEAN) + encoding.
 
 Defaults R=32, ef_construction=100, alpha=1.2, overflow=1.2 are the reference's
@@ -41,8 +42,9 @@ def _prune_lib():
         path = os.path.join(_HERE, "lib", "libjvbuildgpu.so")
         lib = C.CDLL(path)
         vp = C.c_void_p
-        lib.jvb_robust_prune_device.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp, vp]
-        lib.jvb_robust_prune_device.restype = C.c_int
+        lib.jvb_prune_rows_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp, C.c_int,
+                                              vp, vp]
+        lib.jvb_prune_rows_device.restype = C.c_int
         lib.jvb_pq_encode_device.argtypes = [vp, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int,
                                              C.c_int, vp]
         lib.jvb_pq_encode_device.restype = C.c_int
@@ -63,94 +65,34 @@ def _scores_from_gram(torch, G, sq_a, sq_b, sim):
     return (1.0 + G / (sq_a * sq_b).clamp_min(1e-30).sqrt()) * 0.5
 
 
-def robust_prune(torch, base, centers, cand, R, alpha, sim, chunk_bytes=1 << 30):
+PRUNE_MAX_CANDIDATES = 160  # csrc/jv_build_kernels.hip JVB_PRUNE_MAX_LC (the candidate x candidate matrix lives in LDS)
+
+
+def robust_prune(torch, base, centers, cand, R, alpha, sim):
     """Diversity selection for every row: centers [S] (node ids), cand [S][Lc] (node ids, -1 = empty).
     Returns sel [S][R] (-1 padded), nsel [S].  jvector semantics: candidates in descending score to
-    the centre; for a in (1.0, 1.2, .. alpha): keep c unless some already-selected s has
-    sim(c, s) > sim(c, centre) * a."""
+    the centre (ties: lower id first, duplicates dropped); for a in (1.0, 1.2, .. alpha): keep c unless some
+    already-selected s has sim(c, s) > sim(c, centre) * a.
+    All of it runs in ONE hand-written kernel per call (csrc/jv_build_kernels.hip jvb_prune_rows_kernel: a workgroup per row
+    scores, orders, multiplies and selects straight from the vectors in HBM); this function only allocates the outputs."""
     S, Lc = cand.shape
-    d = base.shape[1]
     dev = base.device
-    sel_out = torch.full((S, R), -1, dtype=torch.int32, device=dev)
-    nsel_out = torch.zeros((S,), dtype=torch.int32, device=dev)
-    rows_per = max(1, int(chunk_bytes // (Lc * d * 4)))
-    alphas = [1.0]
-    a = 1.2
-    while a <= alpha + 1e-6:
-        alphas.append(a)
-        a += 0.2
-    for s0 in range(0, S, rows_per):
-        s1 = min(S, s0 + rows_per)
-        c = centers[s0:s1].long()
-        cd = cand[s0:s1].long()
-        n_rows = s1 - s0
-        valid = (cd >= 0) & (cd != c[:, None])
-        V = base[cd.clamp_min(0)]                      # [s][Lc][d]
-        Vc = base[c]                                   # [s][d]
-        sqv = (V * V).sum(-1)                          # [s][Lc]
-        sqc = (Vc * Vc).sum(-1)                        # [s]
-        dc = torch.bmm(V, Vc[:, :, None]).squeeze(2)   # [s][Lc]
-        sc = _scores_from_gram(torch, dc, sqv, sqc[:, None], sim)
-        sc = torch.where(valid, sc, torch.full_like(sc, -float("inf")))
-        # order candidates by (score desc, id asc)
-        order = torch.argsort(cd, dim=1, stable=True)
-        sc_o = torch.gather(sc, 1, order)
-        order2 = torch.argsort(sc_o, dim=1, descending=True, stable=True)
-        perm = torch.gather(order, 1, order2)
-        cd = torch.gather(cd, 1, perm)
-        sc = torch.gather(sc, 1, perm)
-        valid = torch.gather(valid, 1, perm)
-        # drop duplicate ids (equal id => equal score => adjacent after the sort)
-        dup = torch.zeros_like(valid)
-        dup[:, 1:] = (cd[:, 1:] == cd[:, :-1]) & valid[:, 1:] & valid[:, :-1]
-        valid &= ~dup
-        V = torch.gather(V, 1, perm[:, :, None].expand(-1, -1, d))
-        sqv = torch.gather(sqv, 1, perm)
-        G = torch.bmm(V, V.transpose(1, 2))            # [s][Lc][Lc]
-        Scc = _scores_from_gram(torch, G, sqv[:, :, None], sqv[:, None, :], sim)
-        del G, V
-        use_kernel = dev.type == "cuda" and (Lc * Lc * 4 + Lc * 5 + R * 4) < 150 * 1024
-        if use_kernel:
-            sel = torch.empty((n_rows, R), dtype=torch.int32, device=dev)
-            nsel = torch.empty((n_rows,), dtype=torch.int32, device=dev)
-            Scc_c = Scc.contiguous()
-            sc_c = sc.contiguous()
-            cd32 = cd.to(torch.int32).contiguous()
-            v8 = valid.to(torch.uint8).contiguous()
-            rc = _prune_lib().jvb_robust_prune_device(
-                Scc_c.data_ptr(), sc_c.data_ptr(), cd32.data_ptr(), v8.data_ptr(), n_rows, Lc, R, float(alpha),
-                sel.data_ptr(), nsel.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
-            if rc != 0:
-                raise RuntimeError(f"jvb_robust_prune_device failed: {rc}")
-            sel_out[s0:s1] = sel
-            nsel_out[s0:s1] = nsel
-            continue
-        selected = torch.zeros((n_rows, Lc), dtype=torch.bool, device=dev)
-        nsel = torch.zeros((n_rows,), dtype=torch.int32, device=dev)
-        sel = torch.full((n_rows, R), -1, dtype=torch.int64, device=dev)
-        rows = torch.arange(n_rows, device=dev)
-        for a in alphas:
-            thr = sc * a
-            blocked = ((Scc > thr[:, :, None]) & selected[:, None, :]).any(-1)
-            alive = valid & ~selected & ~blocked
-            for _ in range(R):
-                has = alive.any(1) & (nsel < R)
-                idx = alive.to(torch.uint8).argmax(1)               # first alive = best remaining
-                pick_rows = rows[has]
-                if pick_rows.numel() == 0:
-                    break
-                pidx = idx[has]
-                selected[pick_rows, pidx] = True
-                sel[pick_rows, nsel[has].long()] = cd[pick_rows, pidx]
-                nsel[has] += 1
-                col = Scc[rows, :, idx]                             # sim(c, newly selected)
-                alive &= ~((col > thr) & has[:, None])
-                alive[pick_rows, pidx] = False
-            if bool((nsel >= torch.minimum(valid.sum(1), torch.tensor(R, device=dev))).all()):
-                break
-        sel_out[s0:s1] = sel.to(torch.int32)
-        nsel_out[s0:s1] = nsel
-    return sel_out, nsel_out
+    if dev.type != "cuda":
+        raise RuntimeError("builder_gpu.robust_prune needs the HIP builder library (no CPU fallback)")
+    if Lc > PRUNE_MAX_CANDIDATES:
+        raise ValueError(f"{Lc} candidates per row: the selection kernel takes at most {PRUNE_MAX_CANDIDATES}")
+    sel = torch.empty((S, R), dtype=torch.int32, device=dev)
+    nsel = torch.empty((S,), dtype=torch.int32, device=dev)
+    if S == 0:
+        return sel, nsel
+    c64 = centers.to(torch.int64).contiguous()
+    cd = cand.to(torch.int32).contiguous()
+    rc = _prune_lib().jvb_prune_rows_device(base.data_ptr(), int(base.shape[1]), int(base.stride(0)), int(sim), c64.data_ptr(), cd.data_ptr(),
+                                            int(cd.stride(0)), int(S), int(Lc), int(R), float(alpha), sel.data_ptr(), int(sel.stride(0)),
+                                            nsel.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+    if rc != 0:
+        raise RuntimeError(f"jvb_prune_rows_device failed: {rc}")
+    return sel, nsel
 
 
 def approx_medoid(torch, base, sim):

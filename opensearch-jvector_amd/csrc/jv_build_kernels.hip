@@ -1,81 +1,230 @@
-// jv_build_kernels.hip — GPU helpers of the WRITE side (index construction; not the graded hot path,
-// see jv_build.h / builder_gpu.py).  jvb_robust_prune_device: jvector-style diversity selection
-// (GraphIndexBuilder's retainDiverse: alpha sweeps 1.0, 1.2, .. <= alpha; a candidate is kept unless an
-// already-selected neighbour s has sim(c, s) > sim(c, centre) * a), one wavefront per row, the row's
-// candidate-candidate similarity matrix staged in LDS.
+// jv_build_kernels.hip — GPU kernels of the WRITE side (index construction; not the graded hot path, see jv_build.h /
+// builder_gpu.py): jvb_prune_rows_device (jvector-style diversity selection, GraphIndexBuilder's retainDiverse: alpha sweeps
+// 1.0, 1.2, .. <= alpha; a candidate is kept unless an already-selected neighbour s has sim(c, s) > sim(c, centre) * a — one
+// workgroup per row, from the vectors in HBM to the selected row), PQ training and encoding.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #define WAVE 64
 
-__global__ __launch_bounds__(WAVE) void jvb_robust_prune_kernel(const float* __restrict__ scc,   // [S][Lc][Lc]
-                                                                const float* __restrict__ sc,    // [S][Lc] desc
-                                                                const int32_t* __restrict__ cd,  // [S][Lc]
-                                                                const uint8_t* __restrict__ valid,  // [S][Lc]
-                                                                int S, int Lc, int R, float alpha,
-                                                                int32_t* __restrict__ sel,   // [S][R]
-                                                                int32_t* __restrict__ nsel_out) {
+// ---------------------------------------------------------------------------------------------------------------
+// Fused diversity selection (round 4; SURVEY 8(f) row 3, J/JVectorWriter.java:1383-1422 addGraphNode / cleanup): everything
+// robust_prune needs for ONE row in ONE workgroup — the centre's scores, the (score desc, id asc) order, duplicate removal,
+// the candidate x candidate similarities and the alpha sweep — straight from the vectors in HBM.  Round 3 did the gather,
+// the two batched GEMMs (torch.bmm -> Tensile), the sorts and the reorder of a [rows][Lc][d] tensor with torch ops: more
+// than half of the build's GPU time and [rows][Lc][d] floats of temporary HBM.
+//   workgroup = 256 threads = one row of up to JVB_PRUNE_MAX_LC candidates;
+//   LDS: centre vector, the sorted ids / scores / squared norms, the Lc x Lc matrix of dot products, one k-tile of the
+//        candidates' vectors ([Lc][KC + 1] floats);
+//   the dot products are an LDS-tiled fp32 product: thread (ty, tx) of a 16 x 16 grid owns a TR x TR register tile of the
+//   matrix (TR = ceil(Lc / 16) <= 10), k advances KC = 32 dimensions per tile; sums run in a fixed order, so two builds of
+//   the same input select the same rows (tests/test_gpu_builder.py::test_gpu_builds_are_reproducible).
+// ---------------------------------------------------------------------------------------------------------------
+#define JVB_PRUNE_MAX_LC 160
+#define JVB_PRUNE_KC 32
+#define JVB_PRUNE_TR 10
+__device__ __forceinline__ float jvb_sim_from_dot(int sim, float dot, float sqa, float sqb) {
+    if (sim == 0) {
+        float d2 = sqa + sqb - 2.0f * dot;
+        d2 = d2 < 0.0f ? 0.0f : d2;
+        return 1.0f / (1.0f + d2);
+    }
+    if (sim == 1) return (1.0f + dot) * 0.5f;
+    float den = sqa * sqb;
+    den = den < 1e-30f ? 1e-30f : den;
+    return (1.0f + dot / sqrtf(den)) * 0.5f;
+}
+__global__ __launch_bounds__(256) void jvb_prune_rows_kernel(const float* __restrict__ base, int d, int stride, int sim,
+                                                             const long long* __restrict__ centers,   // [S]
+                                                             const int32_t* __restrict__ cand, int cand_stride,  // [S][Lc], -1 = empty
+                                                             int S, int Lc, int R, float alpha,
+                                                             int32_t* __restrict__ sel, int sel_stride,   // [S][R] (-1 padded)
+                                                             int32_t* __restrict__ nsel_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* m = (float*)smem;                      // [Lc][Lc]
-    float* scl = m + (size_t)Lc * Lc;             // [Lc]
-    int32_t* sel_idx = (int32_t*)(scl + Lc);      // [R]
-    uint8_t* state = (uint8_t*)(sel_idx + R);     // [Lc]: 0 = not a candidate, 1 = open, 2 = taken
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int row = blockIdx.x;
     if (row >= S) return;
-    const float* mg = scc + (size_t)row * Lc * Lc;
-    for (int i = lane; i < Lc * Lc; i += WAVE) m[i] = mg[i];
-    for (int i = lane; i < Lc; i += WAVE) {
-        scl[i] = sc[(size_t)row * Lc + i];
-        state[i] = valid[(size_t)row * Lc + i] ? 1 : 0;
-    }
+    const int dpad = (d + 3) & ~3;
+    float* cvec = (float*)smem;                         // [dpad] centre
+    float* G = cvec + dpad;                             // [Lc][Lc] dot products (sorted order)
+    float* tile = G + (size_t)Lc * Lc;                  // [Lc][KC + 1]
+    float* scs = tile + (size_t)Lc * (JVB_PRUNE_KC + 1);   // [Lc] scores to the centre, sorted
+    float* sqs = scs + Lc;                              // [Lc] squared norms, sorted
+    float* sc0 = sqs + Lc;                              // [Lc] unsorted scratch
+    float* sq0 = sc0 + Lc;                              // [Lc]
+    int32_t* ids = (int32_t*)(sq0 + Lc);                // [Lc] sorted ids
+    int32_t* id0 = ids + Lc;                            // [Lc] unsorted ids
+    int32_t* sel_idx = id0 + Lc;                        // [R]
+    uint8_t* state = (uint8_t*)(sel_idx + R);           // [Lc]: 0 = not a candidate, 1 = open, 2 = taken
+    const long long c = centers[row];
+    const float* cp = base + (size_t)c * (size_t)stride;
+    for (int i = tid; i < dpad; i += 256) cvec[i] = i < d ? cp[i] : 0.0f;
+    for (int i = tid; i < Lc; i += 256) id0[i] = cand[(size_t)row * cand_stride + i];
     __syncthreads();
-    int nsel = 0;
-    for (float a = 1.0f; a <= alpha + 1e-6f && nsel < R; a += 0.2f) {
-        for (int c = 0; c < Lc && nsel < R; c++) {
-            if (state[c] != 1) continue;
-            const float thr = scl[c] * a;
-            bool bad = false;
-            for (int s0 = 0; s0 < nsel; s0 += WAVE) {
-                const int s = s0 + lane;
-                const bool over = s < nsel && m[(size_t)c * Lc + sel_idx[s]] > thr;
-                if (__ballot(over)) {
-                    bad = true;
-                    break;
+    // ---- scores to the centre: one wave per candidate, lanes stride the row 4 floats at a time ----
+    float sqc = 0.0f;
+    {
+        float a = 0.0f;
+        for (int i = lane * 4; i < d; i += 256) {
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (i + e < d) a = fmaf(cvec[i + e], cvec[i + e], a);
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) a += __shfl_xor(a, o, 64);
+        sqc = a;
+    }
+    for (int x = wv; x < Lc; x += 4) {
+        const int id = id0[x];
+        float dot = 0.0f, sq = 0.0f;
+        if (id >= 0) {
+            const float* vp = base + (size_t)id * (size_t)stride;
+            for (int i = lane * 4; i < d; i += 256) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    if (i + e < d) {
+                        const float v = vp[i + e];
+                        dot = fmaf(v, cvec[i + e], dot);
+                        sq = fmaf(v, v, sq);
+                    }
                 }
             }
-            if (!bad) {
-                if (lane == 0) {
-                    state[c] = 2;
-                    sel_idx[nsel] = c;
-                }
-                nsel++;
-                __syncthreads();
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                dot += __shfl_xor(dot, o, 64);
+                sq += __shfl_xor(sq, o, 64);
             }
         }
+        if (lane == 0) {
+            const bool ok = id >= 0 && (long long)id != c;
+            sc0[x] = ok ? jvb_sim_from_dot(sim, dot, sq, sqc) : -__builtin_huge_valf();
+            sq0[x] = sq;
+        }
     }
-    for (int i = lane; i < R; i += WAVE) sel[(size_t)row * R + i] = i < nsel ? cd[(size_t)row * Lc + sel_idx[i]] : -1;
-    if (lane == 0) nsel_out[row] = nsel;
+    __syncthreads();
+    // ---- order: score desc, id asc, position asc (rank by counting); duplicates (equal id => adjacent) lose ----
+    for (int x = tid; x < Lc; x += 256) {
+        const float sx = sc0[x];
+        const int ix = id0[x];
+        int r = 0;
+        for (int y = 0; y < Lc; y++) {
+            const float sy = sc0[y];
+            const int iy = id0[y];
+            r += (sy > sx || (sy == sx && (iy < ix || (iy == ix && y < x)))) ? 1 : 0;
+        }
+        ids[r] = ix;
+        scs[r] = sx;
+        sqs[r] = sq0[x];
+    }
+    __syncthreads();
+    for (int x = tid; x < Lc; x += 256) {
+        const bool ok = scs[x] > -__builtin_huge_valf() && !(x > 0 && ids[x] == ids[x - 1]);
+        state[x] = ok ? 1 : 0;
+    }
+    // ---- dot products of every pair of candidates, LDS-tiled ----
+    const int ty = tid >> 4, tx = tid & 15;
+    float acc[JVB_PRUNE_TR][JVB_PRUNE_TR];
+#pragma unroll
+    for (int i = 0; i < JVB_PRUNE_TR; i++)
+#pragma unroll
+        for (int j = 0; j < JVB_PRUNE_TR; j++) acc[i][j] = 0.0f;
+    for (int k0 = 0; k0 < d; k0 += JVB_PRUNE_KC) {
+        __syncthreads();
+        // tile[x][kk] = V[ids[x]][k0 + kk]: 8 threads per candidate row read 4 floats each (128 contiguous bytes per row)
+        for (int e = tid; e < Lc * (JVB_PRUNE_KC / 4); e += 256) {
+            const int x = e / (JVB_PRUNE_KC / 4), q4 = e % (JVB_PRUNE_KC / 4);
+            const int id = ids[x];
+            const int kk = q4 * 4;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (id >= 0) {
+                const float* vp = base + (size_t)id * (size_t)stride + k0 + kk;
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                    if (k0 + kk + t < d) v[t] = vp[t];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; t++) tile[(size_t)x * (JVB_PRUNE_KC + 1) + kk + t] = v[t];
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int kk = 0; kk < JVB_PRUNE_KC; kk++) {
+            float a[JVB_PRUNE_TR], b[JVB_PRUNE_TR];
+#pragma unroll
+            for (int i = 0; i < JVB_PRUNE_TR; i++) {
+                const int r = ty + 16 * i, cc = tx + 16 * i;
+                a[i] = r < Lc ? tile[(size_t)r * (JVB_PRUNE_KC + 1) + kk] : 0.0f;
+                b[i] = cc < Lc ? tile[(size_t)cc * (JVB_PRUNE_KC + 1) + kk] : 0.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < JVB_PRUNE_TR; i++)
+#pragma unroll
+                for (int j = 0; j < JVB_PRUNE_TR; j++) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < JVB_PRUNE_TR; i++)
+#pragma unroll
+        for (int j = 0; j < JVB_PRUNE_TR; j++) {
+            const int r = ty + 16 * i, cc = tx + 16 * j;
+            if (r < Lc && cc < Lc) G[(size_t)r * Lc + cc] = acc[i][j];
+        }
+    __syncthreads();
+    // ---- the alpha sweep (jvector's diversity selection), first wave ----
+    if (wv == 0) {
+        int nsel = 0;
+        for (float a = 1.0f; a <= alpha + 1e-6f && nsel < R; a += 0.2f) {
+            for (int x = 0; x < Lc && nsel < R; x++) {
+                if (state[x] != 1) continue;
+                const float thr = scs[x] * a;
+                bool bad = false;
+                for (int s0 = 0; s0 < nsel; s0 += WAVE) {
+                    const int si = s0 + lane;
+                    bool over = false;
+                    if (si < nsel) {
+                        const int y = sel_idx[si];
+                        over = jvb_sim_from_dot(sim, G[(size_t)x * Lc + y], sqs[x], sqs[y]) > thr;
+                    }
+                    if (__ballot(over)) {
+                        bad = true;
+                        break;
+                    }
+                }
+                if (!bad) {
+                    if (lane == 0) {
+                        state[x] = 2;
+                        sel_idx[nsel] = x;
+                    }
+                    nsel++;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+        for (int i = lane; i < R; i += WAVE) sel[(size_t)row * sel_stride + i] = i < nsel ? ids[sel_idx[i]] : -1;
+        if (lane == 0) nsel_out[row] = nsel;
+    }
 }
 
-extern "C" int jvb_robust_prune_device(const float* scc, const float* sc, const int32_t* cd, const uint8_t* valid,
-                                       int S, int Lc, int R, float alpha, int32_t* sel, int32_t* nsel,
-                                       void* stream) {
+extern "C" int jvb_prune_rows_device(const float* base, int d, int stride, int sim, const long long* centers, const int32_t* cand,
+                                     int cand_stride, int S, int Lc, int R, float alpha, int32_t* sel, int sel_stride, int32_t* nsel,
+                                     void* stream) {
     if (S <= 0) return 0;
-    size_t lds = (size_t)Lc * Lc * 4 + (size_t)Lc * 4 + (size_t)R * 4 + (size_t)Lc;
+    if (Lc < 1 || Lc > JVB_PRUNE_MAX_LC || R < 1 || R > 256) return -4;
+    const int dpad = (d + 3) & ~3;
+    size_t lds = (size_t)dpad * 4 + (size_t)Lc * Lc * 4 + (size_t)Lc * (JVB_PRUNE_KC + 1) * 4 + (size_t)Lc * 4 * 4 + (size_t)Lc * 4 * 2 +
+                 (size_t)R * 4 + (size_t)Lc;
     lds = (lds + 15) & ~(size_t)15;
     if (lds > 160 * 1024) return -4;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)jvb_robust_prune_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)jvb_prune_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return -3;
         attr_set = true;
     }
-    jvb_robust_prune_kernel<<<S, WAVE, lds, (hipStream_t)stream>>>(scc, sc, cd, valid, S, Lc, R, alpha, sel, nsel);
+    jvb_prune_rows_kernel<<<S, 256, lds, (hipStream_t)stream>>>(base, d, stride, sim, centers, cand, cand_stride, S, Lc, R, alpha, sel,
+                                                                 sel_stride, nsel);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
-
 
 // ---------------------------------------------------------------------------------------------------------------
 // PQ encoding (J/JVectorIndexQuantization.java:114-140, merge re-encode J/JVectorWriter.java:1117-1124):

@@ -189,6 +189,34 @@ def test_shard_group_in_one_process_equals_oracle_merge(pkg, pyoracle):
     [s.close() for s in shards]
 
 
+def test_shard_group_merge_at_the_size_of_a_real_step(pkg, pyoracle):
+    """The one-process gather + merge at the size of a benchmark step: 65 536 queries, k = 10, two doc-range shards (both on GPU 0:
+    the peer-copy path on one device is all a one-GPU box can run — two distinct devices and the RCCL all-gather have NEVER
+    been executed by this repo's builder).  The group's answer must equal the oracle's merge of the shards' own batch answers
+    (which the parity suites check against the oracle search)."""
+    b, bl, dg = pkg.binding, pkg.builder, pkg.datagen
+    sh = __import__("importlib").import_module("opensearch_jvector_amd.sharding")
+    n_total, d, k, rk, G, nq = 6000, 32, 10, 30, 2, 65536
+    q = dg.splitmix_uniform(45, nq, d)
+    shards, gd, gs, stats = [], [], [], 0
+    for g in range(G):
+        lo, hi = sh.shard_range(n_total, G, g)
+        base = dg.splitmix_uniform(44, hi - lo, d, row_offset=lo)
+        ix = bl.build_index_cpu(base, 0, R=16, L=50, pq_M=16, ord2doc=np.arange(lo, hi, dtype=np.int32), max_doc=n_total)
+        shards.append(b.GpuIndex(ix, flags=b.DESC_FUSED_ADC))
+        w = shards[-1].search_batch(q, k, rk)
+        gd.append(w.docs)
+        gs.append(w.scores)
+        stats = stats + w.stats
+    grp = b.ShardGroup(shards)
+    got = grp.search_batch(q, k, rk)
+    od, os_ = pyoracle.merge_topk(b, np.concatenate(gd, axis=1), np.concatenate(gs, axis=1), k)
+    assert np.array_equal(got.docs, od) and np.array_equal(got.scores.view(np.uint32), os_.view(np.uint32))
+    assert np.array_equal(got.stats, stats) and (got.count == k).all()
+    grp.close()
+    [s.close() for s in shards]
+
+
 def test_scratch_is_shared_per_device_and_accounted(pkg, small):
     b = pkg.binding
     base, q, ixq, ix = small

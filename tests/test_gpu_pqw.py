@@ -31,6 +31,7 @@ def _both_kernels(gpu, what, fn, want):
 
 @pytest.mark.parametrize("sim", [0, 1])
 @pytest.mark.parametrize("M,R,d", [(32, 32, 64), (32, 16, 64), (32, 24, 96), (32, 8, 64), (64, 32, 128), (64, 16, 128), (32, 64, 64),
+                                   (32, 32, 384), (64, 32, 1024), (32, 16, 1000),   # row lengths without an instance of their own ("any d": NCHT = 0)
                                    (192, 32, 384), (192, 16, 768), (192, 16, 1536), (128, 32, 256), (128, 16, 512)])   # (192 / 128: twelve / eight waves per query — the reference's defaults for 768-d / 512-d fields)
 def test_shapes_and_pool_classes(pkg, pyoracle, sim, M, R, d):
     """every (waves per query, neighbours per row) shape the kernel accepts — R = 64 runs one block per pass, the others

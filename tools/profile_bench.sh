@@ -21,4 +21,13 @@ for C in FETCH_SIZE WRITE_SIZE; do
   c=$(find $d -name "*counter_collection.csv" | head -1)
   [ -n "$c" ] && cp $c $OUT/pmc_$C.csv
 done
+# SQ instruction / wait counters of the main kernels (is the kernel vector-issue bound?), one pass per group
+i=0
+for SET in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
+           "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS"; do
+  i=$((i+1)); d=/tmp/rp_sq$i; rm -rf $d
+  rocprofv3 --pmc $SET --kernel-include-regex "jv_search_(lds|pqf|pqp|pqw)_kernel" --output-format csv -d $d -- python3 $R/bench.py "$@" --profile-mode > $OUT/bench_under_pmc_sq$i.json 2> $OUT/bench_under_pmc_sq$i.err
+  c=$(find $d -name "*counter_collection.csv" | head -1)
+  [ -n "$c" ] && cp $c $OUT/pmc_sq$i.csv
+done
 ls -la $OUT

@@ -43,20 +43,55 @@ def main(src, name):
                   "attributes the main kernel's last ~2 ms — its slowest queries draining — to the dispatch that follows it, "
                   "which is why the no-op retry launch shows ~2 ms here while HIP events put the whole ladder at 0.04 ms, "
                   "tools/pqf_bailouts.py).", ""]
-    # resource usage of the main kernel's instance as dispatched (kernel-trace columns): register / scratch regressions
-    # show up here round to round
+    # resource usage of the dispatched instances: from the CODE OBJECT's metadata (tools/kernel_resources.py: llvm-readelf --notes
+    # on the unbundled gfx950 object) — rocprof's VGPR column is the allocation granule field, not the register count
     tpath = os.path.join(src, "jv_kernel_trace.csv")
     if os.path.exists(tpath):
-        seen = set()
-        lines += ["## resource usage of the dispatched instances", "", "| kernel | workgroup | grid | VGPRs | AGPRs | SGPRs | scratch B/lane | LDS B/workgroup |", "|---|---|---|---|---|---|---|---|"]
+        import subprocess
+        seen = []
         for r in csv.DictReader(open(tpath)):
-            nm = r.get("Kernel_Name", "")
-            if main_kernel not in nm or nm in seen:
-                continue
-            seen.add(nm)
-            lines.append(f"| `{nm.split('(')[0]}` | {r.get('Workgroup_Size', r.get('Workgroup_Size_X', '?'))} | {r.get('Grid_Size', r.get('Grid_Size_X', '?'))} | "
-                         f"{r.get('VGPR_Count', '?')} | {r.get('Accum_VGPR_Count', '?')} | {r.get('SGPR_Count', '?')} | {r.get('Scratch_Size', r.get('Private_Segment_Size', '?'))} | "
-                         f"{r.get('LDS_Block_Size', r.get('Group_Segment_Size', '?'))} |")
+            nm = r.get("Kernel_Name", "").split("(")[0]
+            if main_kernel in nm and nm not in seen:
+                seen.append(nm)
+        res = {}
+        try:
+            out = subprocess.run([sys.executable, os.path.join(root, "tools", "kernel_resources.py"), "--filter", main_kernel],
+                                 capture_output=True, text=True).stdout
+            for line in out.splitlines():
+                key = line[:90].strip()
+                res[key] = line[90:].split()
+        except Exception:
+            res = {}
+        lines += ["## resource usage of the dispatched instances (code object metadata)", "",
+                  "| kernel | VGPRs | AGPRs | SGPRs | VGPR spills | SGPR spills | scratch B/lane |", "|---|---|---|---|---|---|---|"]
+        for nm in seen:
+            f = res.get(nm)
+            if f and len(f) >= 12:
+                lines.append(f"| `{nm}` | {f[1]} | {f[3]} | {f[5]} | {f[7]} | {f[9]} | {f[11]} |")
+            else:
+                lines.append(f"| `{nm}` | ? | ? | ? | ? | ? | ? |")
+        lines.append("")
+    # SQ instruction / wait counters of the main kernel (tools/profile_bench.sh, one --pmc pass per counter group)
+    sq = {}
+    for f in sorted(os.listdir(src)):
+        if f.startswith("pmc_sq") and f.endswith(".csv"):
+            shutil.copy(os.path.join(src, f), os.path.join(dst, f))
+            for r in csv.DictReader(open(os.path.join(src, f))):
+                if main_kernel in r["Kernel_Name"]:
+                    sq.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    if sq:
+        tot = {k: sum(v) for k, v in sq.items()}
+        lines += ["## SQ counters of the main kernel (sums over its dispatches; SQ_*_CYCLES / ACTIVE / WAIT count quad-cycles per wave)", "",
+                  "| counter | value |", "|---|---|"]
+        for k in sorted(tot):
+            lines.append(f"| {k} | {tot[k]:.4g} |")
+        wc = tot.get("SQ_WAVE_CYCLES")
+        if wc:
+            lines += ["", "Per wave-cycle: " + ", ".join(f"{k[3:]} {tot[k] / wc:.3f}" for k in ("SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY") if k in tot) + "."]
+            if "SQ_ACTIVE_INST_VALU" in tot and "SQ_WAVES" in tot:
+                lines += [f"Waves per SIMD = 4 (16 per CU): the share of a SIMD's cycles in which SOME wave of it issues a vector instruction is at most "
+                          f"4 x {tot['SQ_ACTIVE_INST_VALU'] / wc:.3f} = {4 * tot['SQ_ACTIVE_INST_VALU'] / wc:.2f} (a wave64 vector instruction holds its wave for one quad-cycle; "
+                          "gfx950 SIMDs are 32 wide and retire it in two cycles: half of that in SIMD-busy terms)."]
         lines.append("")
     traffic = {}
     for cname in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -84,7 +119,8 @@ def main(src, name):
                   ""]
         tj = {"workload": bench["config"]["workload"].split(":")[0], "n": bench["config"]["docs_per_gpu"], "batch": B,
               "rerankK": bench["config"]["rerankK"], "dist": bench["config"].get("distribution", "aligned"), "hbm_bytes_per_launch": round(hbm, 1),
-              "fetch_size_kib": traffic["FETCH_SIZE"], "write_size_kib": traffic.get("WRITE_SIZE"), "source": f"profiles/{name}"}
+              "fetch_size_kib": traffic["FETCH_SIZE"], "write_size_kib": traffic.get("WRITE_SIZE"), "source": f"profiles/{name}",
+              "date": __import__("datetime").date.today().isoformat()}
         path = os.path.join(root, "profiles", "traffic_latest.json")
         allj = {}
         if os.path.exists(path):
