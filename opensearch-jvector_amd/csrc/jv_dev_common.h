@@ -26,6 +26,13 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define STAMP_DIRECT(i) {}
 #endif
 
+// loads of data a launch touches ONCE (full-precision rows of the rerank, fused blocks): non-temporal, so that they do not evict
+// what every query re-reads (the PQ codebook of the table builds: 786 KB per query from L2 instead of HBM)
+#ifndef JV_NO_STREAM_LOADS
+#define JV_STREAM_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define JV_STREAM_LOAD(p) (*(p))
+#endif
 #define KEY_MIN ((int64_t)0x8000000000000000ll)
 #define KEY_MAX ((int64_t)0x7fffffffffffffffll)
 #define HASH_EMPTY 0xFFFFFFFFu
@@ -215,7 +222,7 @@ __device__ __forceinline__ void score_rows_fixed(const JvIndexDev& ix, const flo
                 const float* rp = ix.vectors + (size_t)todo[r] * (size_t)stride + 4 * t;
 #pragma unroll
                 for (int j = 0; j < NCH; j++) {
-                    if (FULL || (j * 64 + 4 * t) < stride) v[u][j] = *(const f32x4*)(rp + j * 64);
+                    if (FULL || (j * 64 + 4 * t) < stride) v[u][j] = JV_STREAM_LOAD((const f32x4*)(rp + j * 64));  // (read once: not worth an L2 line — the codebook and the adjacency rows are)
                     else v[u][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
             } else {

@@ -387,7 +387,7 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
                     } else {
                         const int node = hf ? wy : c;
                         nn = *(const int32_t*)((const unsigned char*)(ix.adj + (size_t)node * (size_t)R) + adj_off);
-                        cw = *(const u32x4*)(ix.pq_fused + (size_t)node * (size_t)R * (size_t)cs + cw_off);
+                        cw = JV_STREAM_LOAD((const u32x4*)(ix.pq_fused + (size_t)node * (size_t)R * (size_t)cs + cw_off));
                     }
                 }
                 if (hl >= R) nn = -1;
@@ -403,7 +403,7 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
                     const int x = bn2 >= 0 ? bn2 : c, y = bn3 >= 0 ? bn3 : x;
                     const int node = hf ? y : x;
                     pf_nn = *(const int32_t*)((const unsigned char*)(ix.adj + (size_t)node * (size_t)R) + adj_off);
-                    pf_cw = *(const u32x4*)(ix.pq_fused + (size_t)node * (size_t)R * (size_t)cs + cw_off);
+                    pf_cw = JV_STREAM_LOAD((const u32x4*)(ix.pq_fused + (size_t)node * (size_t)R * (size_t)cs + cw_off));
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 const float s0 = adc_chunk_regs(cw);
@@ -722,7 +722,7 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
                     cw = pf_cw;
                 } else {
                     const int node = hf ? wy : c;
-                    cw = *(const u32x4*)(ix.pq_fused + (size_t)node * (size_t)R * (size_t)cs + cw_off);
+                    cw = JV_STREAM_LOAD((const u32x4*)(ix.pq_fused + (size_t)node * (size_t)R * (size_t)cs + cw_off));
                 }
             }
             pf_node0 = bn2;
@@ -730,7 +730,7 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
             {
                 const int x = bn2 >= 0 ? bn2 : c, y = bn3 >= 0 ? bn3 : x;
                 const int node = hf ? y : x;
-                pf_cw = *(const u32x4*)(ix.pq_fused + (size_t)node * (size_t)R * (size_t)cs + cw_off);
+                pf_cw = JV_STREAM_LOAD((const u32x4*)(ix.pq_fused + (size_t)node * (size_t)R * (size_t)cs + cw_off));
             }
             __builtin_amdgcn_sched_barrier(0);
             const float s = adc_chunk_regs(cw);
