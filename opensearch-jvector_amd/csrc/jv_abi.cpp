@@ -59,6 +59,13 @@ int jvk_pqw_waves(const JvIndexDev* ix);
 int jvk_pqw_lds_rows(const JvIndexDev* ix, int variant);
 int jvk_pqw_blocks_per_cu(const JvIndexDev* ix, int cap, int lds_bytes, int variant);
 hipError_t jvk_launch_search_pqw(const JvIndexDev* ix, const JvSearchArgs* a, int lds_bytes, int blocks, int variant, hipStream_t s);
+// the same kernel with a doc filter (jv_kernels_pqwf.hip): pools of up to 16 384 entries
+hipError_t jvk_pqwf_set_max_lds(int bytes);
+int jvk_pqwf_ok(const JvIndexDev* ix, int cap);
+int jvk_pqwf_max_entries(void);
+int jvk_pqwf_lds_rows(int cap);
+int jvk_pqwf_blocks_per_cu(const JvIndexDev* ix, int cap, int lds_bytes);
+hipError_t jvk_launch_search_pqwf(const JvIndexDev* ix, const JvSearchArgs* a, int lds_bytes, int blocks, hipStream_t s);
 // device-resident query server (jv_kernels_pqs.hip)
 hipError_t jvk_pqs_set_max_lds(int bytes);
 int jvk_pqs_blocks_per_cu(const JvIndexDev* ix, int cap, int lds_bytes);
@@ -519,13 +526,13 @@ int ensure_spill(jv_index* ix, Ctx* c) {
 
 // LDS plan of the several-waves pool kernel for a pool of x.cand_cap entries:
 // [pool | centred query | table rows | hash set | rerank scratch] + the waves' exchange rows + ctrl words
-int plan_pqw_lds(const jv_index* ix, JvSearchArgs& x, int variant) {
+int plan_pqw_lds(const jv_index* ix, JvSearchArgs& x, int variant, int lds_rows = -1) {
     const int Wn = jvk_pqw_waves(&ix->dev);
     const int qc_b = ix->dev.nch * 64 * 4;
     const int pool_b = (x.cand_cap + 1) * 8;
-    const int rr_b = qc_b + Wn * JV_TODO * 8 + (x.cand_cap + 64) * 8;
+    const int rr_b = qc_b + Wn * JV_TODO * 8 + (std::min(x.cand_cap, 2048) + 64) * 8;  // (what is reranked fits the waves' registers: <= 2 048 entries)
     x.pqw_lut_off = (std::max(pool_b, qc_b) + 15) & ~15;  // table rows kept in LDS, behind the pool / the centred query
-    const int lut_end = x.pqw_lut_off + Wn * jvk_pqw_lds_rows(&ix->dev, variant) * 1024;
+    const int lut_end = x.pqw_lut_off + Wn * (lds_rows >= 0 ? lds_rows : jvk_pqw_lds_rows(&ix->dev, variant)) * 1024;
     const int front = (std::max(std::max(16384, lut_end), std::max(qc_b, rr_b)) + 15) & ~15;
     x.pqp_pool_off = 0;
     x.pqp_qc_off = 0;
@@ -749,7 +756,17 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
             if (jvk_pqw_ok(&ix->dev, wide.cand_cap) && klass(wide.cand_cap) == klass(ap.cand_cap) && kMaxLds / lds_wide == kMaxLds / lds_now)
                 ap.cand_cap = wide.cand_cap;
         }
-        const int lds = pqw ? plan_pqw_lds(ix, ap, pqw_variant) : plan(ap, lutr != 0);
+        // Doc filters on the several-waves kernel (jv_kernels_pqwf.hip, round 4): the same launches and rungs as the one-wave
+        // filtered kernel below — 2 x the pool first, then the largest pools that keep 4, 3, 2, 1 workgroups per CU — with two /
+        // four waves per query, two fused blocks per scoring pass and the table's rows in registers + LDS.
+        const bool pqwf = filtered && OPT(ix, OPT_NO_PQW) == 0 && jvk_pqwf_ok(&ix->dev, ap.cand_cap) && nq >= OPT(ix, OPT_PQW_MIN_QUERIES);
+        auto planF = [&](JvSearchArgs& x, bool regs) { return pqwf ? plan_pqw_lds(ix, x, 0, jvk_pqwf_lds_rows(x.cand_cap)) : plan(x, regs); };
+        auto blocksF = [&](int cap, int lds_b, int lutr_) { return pqwf ? jvk_pqwf_blocks_per_cu(&ix->dev, cap, lds_b) : jvk_pqp_blocks_per_cu(&ix->dev, cap, lds_b, lutr_, 1); };
+        auto launchF = [&](const JvSearchArgs& x, int lds_b, int blocks_, int lutr_) {
+            return pqwf ? jvk_launch_search_pqwf(&ix->dev, &x, lds_b, blocks_, stream) : jvk_launch_search_pqp(&ix->dev, &x, lds_b, blocks_, lutr_, stream);
+        };
+        const int max_entries_f = pqwf ? jvk_pqwf_max_entries() : jvk_pqp_max_entries_filtered();
+        const int lds = pqw ? plan_pqw_lds(ix, ap, pqw_variant) : (pqwf ? planF(ap, false) : plan(ap, lutr != 0));
         // second launch for what outgrows the first (more than 63 ties at the rerankK boundary, a longer expansion log):
         // table in LDS, as many tie slots as the largest pool class allows, 4x the log; walks the flag array
         JvSearchArgs ap2 = ap;
@@ -759,15 +776,16 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
         ap2.retry_counter = c->work_counter + 5;
         // (filtered: the later launches keep the table in registers too — twice the resident queries per CU at these pool sizes)
         const int lutr2 = filtered && OPT(ix, OPT_NO_LUTR) == 0 && jvk_pqpf_lutr_ok(&ix->dev, jvk_pqp_max_entries_filtered()) && nq > lutr_min_q ? 1 : 0;
-        const int lds2 = plan(ap2, lutr2 != 0);
+        const int lds2 = pqwf ? planF(ap2, false) : plan(ap2, lutr2 != 0);
         const bool second = lds2 <= kMaxLds && ap2.cand_cap > ap.cand_cap && OPT(ix, OPT_PQF_ONLY) == 0;
         if (lds <= kMaxLds) {
-            int per_cu = pqw ? jvk_pqw_blocks_per_cu(&ix->dev, ap.cand_cap, lds, pqw_variant) : jvk_pqp_blocks_per_cu(&ix->dev, ap.cand_cap, lds, lutr, filtered ? 1 : 0);
+            int per_cu = pqw ? jvk_pqw_blocks_per_cu(&ix->dev, ap.cand_cap, lds, pqw_variant)
+                             : (pqwf ? blocksF(ap.cand_cap, lds, 0) : jvk_pqp_blocks_per_cu(&ix->dev, ap.cand_cap, lds, lutr, filtered ? 1 : 0));
             if (OPT(ix, OPT_PQP_BLOCKS_PER_CU) > 0) per_cu = (int)std::min<int64_t>(per_cu, OPT(ix, OPT_PQP_BLOCKS_PER_CU));  // diagnostics
             int blocks = ix->cu_count * per_cu;
             if (blocks > nq) blocks = nq;
             // (unfiltered: a handful of flagged queries; filtered: a selective filter sends the whole batch here)
-            const int per_cu2 = filtered && second ? jvk_pqp_blocks_per_cu(&ix->dev, ap2.cand_cap, lds2, lutr2, 1) : 1;
+            const int per_cu2 = filtered && second ? blocksF(ap2.cand_cap, lds2, lutr2) : 1;
             const int blocks2 = std::min(ix->cu_count * per_cu2, (nq + 7) / 8);
             // Filtered searches: a pool of ~ rerankK / selectivity entries.  What a launch costs is decided by how many of its
             // queries a CU keeps resident, and that is LDS / (pool bytes + fixed part).  Behind the second launch (twice the
@@ -788,26 +806,26 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
                 rungs[nrungs++] = r0;
                 JvSearchArgs probe = ap2;
                 probe.cand_cap = 4096;
-                const int fixed = plan(probe, lutr2 != 0) - 4097 * 8;  // LDS bytes besides the pool (class 3 / 4 layout)
+                const int fixed = planF(probe, lutr2 != 0) - 4097 * 8;  // LDS bytes besides the pool (class 3 / 4 layout)
                 int prev = ap2.cand_cap;
                 for (int per = 4; per >= 1 && nrungs < 8; per--) {  // (these instances take 512 registers: one wave per SIMD)
                     // (measured with tools/lds_residency.hip: workgroups of 7 x 23 040 B and 3 x 53 248 B are resident together on a
                     //  gfx950 CU, 5 x 32 768 B, 10 x 16 384 B and 3 x 54 528 B are NOT although the occupancy API says so: what
                     //  several workgroups can share is a little less than 160 KB — budget 157.5 KB)
                     const int share = ((161280 / per) & ~255);
-                    int cap = std::min(((share - fixed) / 8 - 1) & ~63, jvk_pqp_max_entries_filtered());
+                    int cap = std::min(((share - fixed) / 8 - 1) & ~63, max_entries_f);
                     if (cap < prev + 512 || cap < rk + 64 + ix->dev.R) continue;  // (not worth a launch of its own)
                     Rung r;
                     r.a = ap2;
                     r.a.cand_cap = cap;
-                    r.lds = plan(r.a, lutr2 != 0);
+                    r.lds = planF(r.a, lutr2 != 0);
                     if (r.lds > kMaxLds) continue;
                     r.a.pqp_log_cap = 3 * cap;
                     r.a.retry_counter = c->work_counter + 8 + nrungs;
-                    r.blocks = std::min(ix->cu_count * std::min(per, jvk_pqp_blocks_per_cu(&ix->dev, cap, r.lds, lutr2, 1)), (nq + 1) / 2);
+                    r.blocks = std::min(ix->cu_count * std::min(per, blocksF(cap, r.lds, lutr2)), (nq + 1) / 2);
                     rungs[nrungs++] = r;
                     prev = cap;
-                    if (cap >= jvk_pqp_max_entries_filtered()) break;
+                    if (cap >= max_entries_f) break;
                 }
                 rungs[nrungs - 1].a.retry_only = 2;  // the last on-chip rung never skips on the selectivity estimate
             }
@@ -830,16 +848,18 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
                 servers_yield_lds(ix->device, lds_max);
             }
             if (pqw) HIPCHK(jvk_launch_search_pqw(&ix->dev, &ap, lds, blocks, pqw_variant, stream));
+            else if (pqwf) HIPCHK(launchF(ap, lds, blocks, 0));
             else HIPCHK(jvk_launch_search_pqp(&ix->dev, &ap, lds, blocks, lutr, stream));
-            ix->launches[pqw ? LAUNCH_PQW : LAUNCH_PQP]++;
+            ix->launches[(pqw || pqwf) ? LAUNCH_PQW : LAUNCH_PQP]++;
             trace_point(c, 5, stream);
             if (second_now) {
                 ap2.pqp_log = c->pqp_log;
-                HIPCHK(jvk_launch_search_pqp(&ix->dev, &ap2, lds2, blocks2, lutr2, stream));
+                if (pqwf) HIPCHK(launchF(ap2, lds2, blocks2, lutr2));
+                else HIPCHK(jvk_launch_search_pqp(&ix->dev, &ap2, lds2, blocks2, lutr2, stream));
             }
             for (int i = 0; i < nrungs; i++) {
                 rungs[i].a.pqp_log = c->pqp_log;
-                HIPCHK(jvk_launch_search_pqp(&ix->dev, &rungs[i].a, rungs[i].lds, rungs[i].blocks, lutr2, stream));
+                HIPCHK(launchF(rungs[i].a, rungs[i].lds, rungs[i].blocks, lutr2));
             }
             pqf = true;
         }
@@ -1705,6 +1725,7 @@ int jv_index_create(const jv_index_desc* desc, jv_index** out) {
         TRYHIP(jvk_set_max_lds(kMaxLds));
         TRYHIP(jvk_pqp_set_max_lds(kMaxLds));
         TRYHIP(jvk_pqw_set_max_lds(kMaxLds));
+        TRYHIP(jvk_pqwf_set_max_lds(kMaxLds));
         TRYHIP(jvk_pqs_set_max_lds(kMaxLds));
         TRYHIP(jvk_pqsf_set_max_lds(kMaxLds));
         {

@@ -75,7 +75,11 @@ enum { PQW_C = 0, PQW_C2 = 1, PQW_WHY = 2, PQW_NP = 3, PQW_NEXP = 4, PQW_EXPANDE
 // W:    waves per query = pq_M / 16 (2, 4; 12 = the reference's default 192 subspaces for 768-d .. 1 536-d fields)
 // NL:   the first NL of a wave's 16 subspaces keep their table rows in LDS (plain gathers) instead of registers: every
 //       look-up served from LDS saves four ds_bpermute — the LDS unit is this kernel's busiest resource — and four VGPRs
-template <int NCHT, int CAPK, int W, int NL>
+// FILT: the query has a doc filter (J/JVectorReader.java:157-163; round 4 — filtered searches ran one wave per query on
+//       jv_pqp_body.h until now).  As there: every scored node is traversed, only accepted ones enter jvector's result queue, so
+//       the pool holds every scored node whose score >= the rk-th best ACCEPTED one (~ rk / selectivity entries: capacity classes
+//       up to 16 384 entries); key bit 2 = accepted, `bpos` tracks the rk-th best accepted entry.
+template <int NCHT, int CAPK, int W, int NL, bool FILT = false>
 __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSearchArgs& a, const int qi, unsigned char* smem, int32_t* explog) {
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -88,6 +92,43 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
     int32_t* o_nodes = a.out_nodes + (size_t)qi * topK;
     int32_t* o_docs = a.out_docs ? a.out_docs + (size_t)qi * topK : nullptr;
     float* o_scores = a.out_scores + (size_t)qi * topK;
+    const uint64_t* const accw = FILT ? a.accept + (size_t)qi * (size_t)a.accept_stride : nullptr;
+    auto accepts = [&](int node) -> bool {  // the reference's acceptOrds lambda
+        if (a.accept_ord) return (a.accept_ord[node >> 6] >> (node & 63)) & 1ull;  // (batch-wide filter, translated by the host's pre-pass)
+        const int doc = ix.ord2doc ? ix.ord2doc[node] : node;
+        return doc >= 0 && (int64_t)doc < a.accept_docs && ((accw[doc >> 6] >> (doc & 63)) & 1ull);
+    };
+    if (FILT) {
+        // Rung choice only (never results), as in jv_pqp_body.h: the filter's selectivity from 256 sampled words; a pool of
+        // ~ rerankK / selectivity entries that cannot fit this launch's capacity is handed on at once.  Every wave of the
+        // workgroup computes the same estimate from the same words, so they all leave or all stay.
+        const int64_t nwords = (a.accept_docs + 63) >> 6;
+        int bits = 0;
+        if (nwords > 0) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint64_t h = ((uint64_t)(u * JV_WAVE + lane + 1) * 0x9E3779B97F4A7C15ull) >> 20;
+                bits += __popcll(accw[nwords <= 4 * JV_WAVE ? (int64_t)((u * JV_WAVE + lane) % (int)nwords) : (int64_t)(h % (uint64_t)nwords)]);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) bits += __shfl_xor(bits, o, JV_WAVE);
+        const float sel = fmaxf((float)bits, 1.0f) * (1.0f / 16384.0f);
+        const float need = (float)rk / sel * 1.05f + 64.0f + (float)R;
+        if (need > (float)a.cand_cap && (a.retry_only == 1 || (a.retry_only == 0 && a.cand_cap < 8 * rk + 256))) {
+            if (threadIdx.x == 0) {
+                a.out_flags[qi] = (int32_t)(JV_FLAG_OVERFLOW | (9u << 8));  // (9: estimated pool beyond this launch's)
+                a.out_count[qi] = 0;
+            }
+            if (wv == 0)
+                for (int i = lane; i < topK; i += JV_WAVE) {
+                    o_nodes[i] = -1;
+                    if (o_docs) o_docs[i] = -1;
+                    o_scores[i] = 0.0f;
+                }
+            return;
+        }
+    }
 
     // ---- centred query -> this wave's 16 subspaces of the look-up table, in registers ----
     const float* qg = a.queries + (size_t)qi * ix.d;
@@ -202,6 +243,7 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
     int np = 0, nexp = 0, expanded = 0;
     int why = 0;
     int nrej = 0;         // rejected entries in the pool (all at the boundary score)
+    int bpos = -1, nacc = 0;  // FILT: position of the rk-th best accepted entry (-1: fewer than rk so far), accepted entries in the pool
     float bscore = 0.0f;  // score of the rk-th best entry once np >= rk
     {
         const int ep = ix.entry;
@@ -213,8 +255,14 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
         if (wv == 0) {
             float sc = map_score(ix.sim == 0 ? 0 : 1, combine(s, 0));
             sc = __shfl(sc, 0, JV_WAVE);
-            if (lane == 0) pool[0] = pqp_key<false>(sc, ep, true);
-            if (rk <= 1) bscore = sc;
+            const bool acc_ep = FILT ? accepts(ep) : true;
+            if (lane == 0) pool[0] = pqp_key<FILT>(sc, ep, acc_ep);
+            if (FILT) {
+                nacc = acc_ep ? 1 : 0;
+                if (nacc >= rk) bpos = 0, bscore = sc;
+            } else if (rk <= 1) {
+                bscore = sc;
+            }
         }
         np = 1;
         __syncthreads();
@@ -253,6 +301,7 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
         int pf_node0 = -1, pf_node1 = -1;  // nodes whose blocks were requested ahead into the lower / upper lanes
         float score = 0.0f;
         int nn = -1;
+        bool accn = true;  // FILT: this lane's neighbour is accepted by the query's doc filter
         int64_t pv = KEY_MIN;  // lane t: last key of pool chunk t (low bits may be stale: they never decide a comparison with a new key)
         // ranks of BOTH halves' keys are taken in the pass iteration (the per-lane search costs the same for 32 or 64 keys); the
         // runner-up's half keeps them for its own expansion, corrected there for the keys the first half inserted meanwhile
@@ -263,12 +312,13 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
         // chunk read away wherever it is — a key that lands far ahead of the frontier no longer costs a walk through every
         // fully expanded chunk in between once it has been expanded itself (that walk was most of the "find" step)
         unsigned long long um = 1ull;
+        constexpr int UGS = CAPK >= 5 ? 2 : (CAPK >= 4 ? 1 : 0);  // log2(pool chunks per mask bit): 64 bits cover every capacity class
         unsigned long long ins_lo = 0ull;  // lanes (lower half) whose keys went into the pool in the pass iteration
         while (true) {
             // (wave-uniform state, said so: the compiler's divergence analysis gives up on values that pass through LDS loads and
             //  the joins behind lane-level branches, and then runs this whole loop with vector compares and exec masks)
 #define PQW_UNI(x) x = __builtin_amdgcn_readfirstlane(x)
-            PQW_UNI(np); PQW_UNI(nexp); PQW_UNI(expanded); PQW_UNI(why); PQW_UNI(nrej);
+            PQW_UNI(np); PQW_UNI(nexp); PQW_UNI(expanded); PQW_UNI(why); PQW_UNI(nrej); PQW_UNI(bpos); PQW_UNI(nacc);
             um = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(um >> 32)) << 32) | (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)um);
             PQW_UNI(sc_node0); PQW_UNI(sc_node1); PQW_UNI(pf_node0); PQW_UNI(pf_node1); PQW_UNI(ru_pos); PQW_UNI(ru_lo); PQW_UNI(ru_hi);
             bscore = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(bscore)));
@@ -278,9 +328,15 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
             int64_t e1 = 0;
             unsigned long long m1 = 0ull;
             while (um) {
-                t1 = __ffsll((long long)um) - 1;
-                e1 = pool[min((t1 << 6) + lane, cap)];
-                m1 = __ballot((e1 & 1ll) != 0);
+                const int g1 = __ffsll((long long)um) - 1;
+#pragma unroll
+                for (int cc = 0; cc < (1 << UGS); cc++) {  // (pools beyond 4 096 entries: a mask bit stands for 2 / 4 chunks)
+                    if (!m1) {
+                        t1 = (g1 << UGS) + cc;
+                        e1 = pool[min((t1 << 6) + lane, cap)];
+                        m1 = __ballot((e1 & 1ll) != 0);
+                    }
+                }
                 if (m1) break;
                 um &= um - 1ull;
             }
@@ -293,14 +349,37 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
                 pk_lo = __builtin_amdgcn_readlane(e1lo, b1);
                 pk_hi = __builtin_amdgcn_readlane(e1hi, b1);
                 const float sc = hi_score(pk_hi);
-                c = lo_node<false>(pk_lo);
+                c = lo_node<FILT>(pk_lo);
                 if (sc < a.threshold) why = 1;  // a node the two-queue form would expand but not collect: general path
                 else if (nexp >= log_cap) why = 2;
                 else if (a.visit_limit > 0 && expanded >= a.visit_limit) why = 15;  // Lucene discards this search
                 // strict admission (DESIGN.md "Single-pool search"): when the ADMITTED entries scoring >= the candidate
                 // already fill the result queue (the worst result ties with the candidate), jvector expands the candidate
                 // without admitting it
-                if (why == 0 && expanded >= rk && idx < rk + nrej) {
+                if (FILT) {
+                    // the same rule over ACCEPTED entries (jv_pqp_body.h): with t = accepted entries of the boundary's equal-score
+                    // run at or ahead of bpos, rk - t accepted entries score higher; the candidate is rejected when those + the
+                    // accepted, expanded entries of the run (minus the rejected ones) already fill rerankK.  A candidate the
+                    // filter does not accept is expanded and never admitted.
+                    if (why == 0 && (pk_lo & 4) && bpos >= 0 && sc == bscore) {
+                        int tt = bpos >> 6;
+                        while (tt > 0 && __builtin_amdgcn_readfirstlane((int)(pool[tt << 6] >> 32)) == pk_hi) tt--;
+                        int t_le = 0, ex_acc = 0;
+                        for (;;) {
+                            const int64_t ee = pool[min((tt << 6) + lane, cap)];
+                            const unsigned long long eq = __ballot((int)(ee >> 32) == pk_hi);
+                            const unsigned long long am = eq & __ballot((ee & 4ll) != 0);
+                            const unsigned long long un = __ballot((ee & 1ll) != 0);
+                            const int last_in = bpos - (tt << 6);  // lanes <= last_in are at or ahead of bpos
+                            const unsigned long long le = last_in >= 63 ? ~0ull : (last_in < 0 ? 0ull : ((2ull << last_in) - 1ull));
+                            t_le += __popcll(am & le);
+                            ex_acc += __popcll(am & ~un);
+                            if (((tt + 1) << 6) >= np || (tt >= (bpos >> 6) && !(eq >> 63))) break;
+                            tt++;
+                        }
+                        reject = ex_acc - nrej >= t_le;
+                    }
+                } else if (why == 0 && expanded >= rk && idx < rk + nrej) {
                     int ge = idx;
                     int64_t ee = e1;
                     for (int tt = t1;;) {
@@ -333,9 +412,9 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
                     bool second = false;
 #pragma unroll
                     for (int k = 1; k < 4; k++) {
-                        const unsigned long long um2 = um & ~((2ull << t1) - 1ull);  // chunks behind the first that may hold more
+                        const unsigned long long um2 = UGS == 0 ? (um & ~((2ull << t1) - 1ull)) : ((((t1 + 1) << 6) < np) ? 1ull : 0ull);  // chunks behind the first that may hold more
                         if (!mm && !second && um2) {
-                            t2 = __ffsll((long long)um2) - 1;
+                            t2 = UGS == 0 ? __ffsll((long long)um2) - 1 : t1 + 1;
                             const int64_t e2 = pool[min((t2 << 6) + lane, cap)];
                             mm = __ballot((e2 & 1ll) != 0);
                             elo = (int)(uint32_t)(e2 & 0xFFFFFFFFll);
@@ -346,7 +425,7 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
                         if (mm) {
                             const int ln = __ffsll((long long)mm) - 1;
                             const int klo = __builtin_amdgcn_readlane(elo, ln);
-                            nb = lo_node<false>(klo);
+                            nb = lo_node<FILT>(klo);
                             if (k == 1) {  // the runner-up's entry: its key and position decide whether both entries are expanded at once
                                 ru_lo = klo;
                                 ru_hi = __builtin_amdgcn_readlane(ehi, ln);
@@ -391,6 +470,12 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
                     }
                 }
                 if (hl >= R) nn = -1;
+                // FILT: the neighbours' accept bits are requested BEFORE the next pair's blocks — vmcnt retires in order, so a wait
+                // for an accept word issued behind the prefetch would drain the prefetch on every pass
+                if (FILT) {
+                    accn = nn >= 0 ? accepts(nn) : false;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #ifdef JV_STAMPS
                 asm volatile("" ::"v"(nn), "v"(cw));  // (diagnostic) the wait for this pass's blocks lands in phase 9
 #endif
@@ -427,26 +512,32 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
             if (half == 0) sc_node0 = -1;
             else sc_node1 = -1;
             PQW_STAMP(1)
-            const int64_t v = pqp_key<false>(score, nn, true);
+            const int64_t v = pqp_key<FILT>(score, nn, accn);
             bool keep, dual = false;
             int rold;
+            const bool have_b = FILT ? bpos >= 0 : np >= rk;  // a boundary exists
             if (fresh) {
                 bool cand = nn >= 0;
-                if (np >= rk && score < bscore) cand = false;  // below the boundary for good
+                if (have_b && score < bscore) cand = false;  // below the boundary for good
                 // ---- rank of the surviving keys in the pool; "same node" = equal up to the low bits ----
                 int rold_a = 0;
                 unsigned long long todo_m = __ballot(cand);
-                if (__popcll(todo_m) > 6) {
+                if (__popcll(todo_m) > 6 || CAPK >= 4) {  // (pools beyond 4 096 entries: the chunk pivots do not fit one register across the wave)
                     // many survivors (the pool is still filling: every neighbour is a candidate): per-lane 8-ary search, all
                     // lanes at once, cost independent of their number
                     if (cand) {
                         int lo = 0;
+                        if (CAPK == 5) lo = rank_level<2048, 8>(pool, lo, cap, v);
+                        if (CAPK == 5) lo = rank_level<128, 16>(pool, lo, cap, v);
+                        if (CAPK == 4) lo = rank_level<1024, 8>(pool, lo, cap, v);
                         if (CAPK == 3) lo = rank_level<512, 8>(pool, lo, cap, v);
                         if (CAPK == 2) lo = rank_level<512, 4>(pool, lo, cap, v);
                         if (CAPK == 1) lo = rank_level<256, 4>(pool, lo, cap, v);
                         if (CAPK == 1) lo = rank_level<64, 4>(pool, lo, cap, v);
-                        else lo = rank_level<64, 8>(pool, lo, cap, v);
-                        lo = rank_level<8, 8>(pool, lo, cap, v);
+                        else if (CAPK == 4) lo = rank_level<64, 16>(pool, lo, cap, v);
+                        else if (CAPK != 5) lo = rank_level<64, 8>(pool, lo, cap, v);
+                        if (CAPK == 5) lo = rank_level<8, 16>(pool, lo, cap, v);
+                        else lo = rank_level<8, 8>(pool, lo, cap, v);
                         int64_t p3[9];
     #pragma unroll
                         for (int k2 = 0; k2 < 9; k2++) p3[k2] = pool[min(lo + k2, cap)];
@@ -504,7 +595,9 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
                 // can apply to the runner-up: result queue not full (no strict admission), inside the best rerankK, score
                 // above the threshold, room in the log and in the pool, no visit limit in reach.
                 // (`expanded` and `nexp` already count this iteration's entry: they are what the runner-up's own pop would see)
-                if (sc_node1 >= 0 && ru_pos >= 0 && ru_pos < rk && nrej == 0 && expanded < rk && nexp < log_cap &&
+                // (FILT: only while fewer than rerankK accepted entries exist — afterwards the runner-up's pop can meet the boundary's
+                //  equal-score run, whose bookkeeping wants one insert at a time)
+                if ((!FILT || bpos < 0) && sc_node1 >= 0 && ru_pos >= 0 && ru_pos < rk && nrej == 0 && expanded < rk && nexp < log_cap &&
                     hi_score(ru_hi) >= a.threshold && (a.visit_limit <= 0 || expanded < a.visit_limit)) {
                     const int64_t ruk = (int64_t)(((uint64_t)(uint32_t)ru_hi << 32) | (uint64_t)(uint32_t)ru_lo);
                     const unsigned long long all = __ballot(cand);
@@ -524,7 +617,7 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
             } else {
                 // the runner-up's half: ranked against the pool as it was before the first half's keys went in
                 keep = cand_s && hf == 1;
-                if (np >= rk && score < bscore) keep = false;  // (the boundary may have risen since)
+                if (have_b && score < bscore) keep = false;  // (the boundary may have risen since)
                 rold = rold_s;
                 unsigned long long it = ins_lo;
                 const int vlo2 = (int)(uint32_t)(v & 0xFFFFFFFFll), vhi2 = (int)(v >> 32);
@@ -618,21 +711,97 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
                 {
                     // entries from the first insertion point on moved up by at most nk <= 64 positions: into their own chunk or
                     // the next; the new keys are unexpanded where they landed
-                    const unsigned long long lowm = (1ull << (r_min >> 6)) - 1ull;
+                    const unsigned long long lowm = (1ull << ((r_min >> 6) >> UGS)) - 1ull;
                     um = (um & lowm) | ((um | (um << 1)) & ~lowm);
                     const int npos = rold + rnew;
                     unsigned long long it = km;
                     while (it) {
                         const int j = __ffsll((long long)it) - 1;
                         it &= it - 1ull;
-                        um |= 1ull << (__builtin_amdgcn_readlane(npos, j) >> 6);
+                        um |= 1ull << ((__builtin_amdgcn_readlane(npos, j) >> 6) >> UGS);
                     }
                 }
                 PQW_STAMP(4)  // ranks among the new keys + shift + insert
                 // boundary = the rk-th best entry; entries behind it stay only while they tie with its score
                 const int ntot = np + nk;
                 np = ntot;
-                if (ntot >= rk) {
+                if (FILT) {
+                    // (jv_pqp_body.h's bookkeeping of the rk-th best ACCEPTED entry, on wave-uniform values)
+                    const unsigned long long kacc = __ballot(keep && accn);
+                    if (bpos >= 0) {
+                        // new keys that landed ahead of the old boundary entry push it back; the accepted ones among them make
+                        // the rk-th best accepted entry one of its predecessors: walk back over that many accepted entries
+                        const unsigned long long before = __ballot(keep && rold <= bpos);
+                        const int P = bpos + __popcll(before);
+                        int need = __popcll(before & kacc);
+                        bpos = P;
+                        if (need > 0) {
+                            int tt = P >> 6;
+                            unsigned long long lim = (P & 63) ? ((1ull << (P & 63)) - 1ull) : 0ull;  // positions < P
+                            if (!lim) tt--, lim = ~0ull;
+                            for (;;) {
+                                const int64_t ee = pool[(tt << 6) + lane];
+                                const unsigned long long am = __ballot((ee & 4ll) != 0) & lim;
+                                const int cnt = __popcll(am);
+                                if (cnt >= need) {
+                                    bpos = (tt << 6) + pqp_select_nth_bit(am, cnt - need + 1);
+                                    break;
+                                }
+                                need -= cnt;
+                                tt--;
+                                lim = ~0ull;
+                            }
+                        }
+                    } else {
+                        nacc += __popcll(kacc);
+                        if (nacc >= rk) {  // the pool holds rk accepted entries for the first time: find the rk-th from the front
+                            int need = rk;
+                            for (int tt = 0;; tt++) {
+                                const int64_t ee = pool[min((tt << 6) + lane, cap)];
+                                const unsigned long long am = __ballot((tt << 6) + lane < ntot && (ee & 4ll) != 0);
+                                const int cnt = __popcll(am);
+                                if (cnt >= need) {
+                                    bpos = (tt << 6) + pqp_select_nth_bit(am, need);
+                                    break;
+                                }
+                                need -= cnt;
+                            }
+                        }
+                    }
+                    if (bpos >= 0) {
+                        const int bhi = __builtin_amdgcn_readfirstlane((int)(pool[bpos] >> 32));
+                        const float nb = hi_score(bhi);
+                        if (nb != bscore) nrej = 0;
+                        bscore = nb;
+                        // ties behind the boundary stay (slots left: cap - (bpos + 1) - R; none left = this launch's pool is too
+                        // small for this filter's selectivity), everything below goes
+                        const int slack = cap - (bpos + 1) - R;  // (with a boundary in place one expansion's keys arrive per insert)
+                        int run = 0, acc_t = 0;
+                        for (int p0 = bpos + 1; run < slack; p0 += JV_WAVE) {
+                            const int64_t eb = pool[min(p0 + lane, cap)];
+                            const unsigned long long mt = __ballot((int)(eb >> 32) == bhi);  // (a sentinel never matches)
+                            const unsigned long long am = __ballot((eb & 4ll) != 0);
+                            if (~mt) {
+                                const int r = __ffsll((long long)~mt) - 1;
+                                run += r;
+                                acc_t += __popcll(am & ((1ull << r) - 1ull));
+                                break;
+                            }
+                            run += JV_WAVE;
+                            acc_t += __popcll(am);
+                        }
+                        if (run >= slack) {
+                            why = 3;
+                        } else {
+                            np = bpos + 1 + run;
+                            nacc = rk + acc_t;
+                            for (int p0 = np; p0 < ntot; p0 += JV_WAVE)
+                                if (p0 + lane < ntot) pool[p0 + lane] = pqw_key_min();
+                        }
+                    } else if (ntot > cap - 2 * R) {
+                        why = 3;  // fewer than rk accepted entries among more scored nodes than this launch's pool holds
+                    }
+                } else if (ntot >= rk) {
                     const int bhi = __builtin_amdgcn_readfirstlane((int)(pool[rk - 1] >> 32));  // (wave-uniform, and said so: the boundary and the rejected count steer wave-level branches)
                     const float nb = hi_score(bhi);
                     if (nb != bscore) nrej = 0;  // the boundary rose: every rejected entry (they tied with the old one) falls off below
@@ -660,7 +829,7 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
                     }
                 }
                 if (lane >= (r_min >> 6)) pv = pool[min((lane << 6) + 63, cap)];  // chunks from the first insertion point on changed
-                um &= (2ull << ((np - 1) >> 6)) - 1ull;  // (nothing behind the pool's last chunk)
+                um &= (2ull << (((np - 1) >> 6) >> UGS)) - 1ull;  // (nothing behind the pool's last chunk)
                 PQW_STAMP(5)  // boundary + trim
                 if (why != 0) {  // (why = 3) leave through the common exit so that every wave sees it
                     if (W > 1) {
@@ -672,13 +841,13 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
             }
         }
         PQW_STAMP(5)
-        if (why == 0 && nrej > 0) {
-            // take the rejected entries out: what remains in front is jvector's result queue
+        if (why == 0 && (FILT || nrej > 0)) {
+            // take the rejected entries out (FILT: what the filter does not accept goes too): what remains in front is jvector's result queue
             int carry = 0;
             for (int t = 0; (t << 6) < np; t++) {
                 const int pos = (t << 6) + lane;
                 const int64_t e = pool[min(pos, cap)];
-                const bool rej = pos < np && !(e & 2ll);
+                const bool rej = pos < np && (!(e & 2ll) || (FILT && !(e & 4ll)));
                 const unsigned long long rm = __ballot(rej);
                 const int shift = carry + __popcll(rm & ((1ull << lane) - 1ull));
                 if (pos < np && !rej && shift > 0) pool[pos - shift] = e;
@@ -689,6 +858,7 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
             np -= carry;
         }
         if (lane == 0) {
+            if (why == 0 && np > (((32 + W - 1) / W) * W) * 64) why = 4;  // (a boundary tie storm: more results than the waves can park in registers — next rung)
             ctrl[PQW_WHY] = why;
             ctrl[PQW_NP] = np;
             ctrl[PQW_NEXP] = nexp;
@@ -953,7 +1123,7 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
         int node = 0;
         if (i < nres) {
             const int64_t k = fin[i];
-            node = lo_node<false>((int)(uint32_t)(k & 0xFFFFFFFFll));
+            node = lo_node<FILT>((int)(uint32_t)(k & 0xFFFFFFFFll));
             take = above > 0 ? key_score(k) >= a.rerank_floor : i == 0;  // position 0 is the best approximate entry
         }
         const unsigned long long tm = __ballot(take);
@@ -1060,7 +1230,7 @@ __global__ __launch_bounds__(JV_WAVE * W, OCC) void jv_serve_pqw_kernel(const Jv
     jv_serve_leave(a);
 }
 
-template <int NCHT, int CAPK, int W, int OCC, int NL = 4>
+template <int NCHT, int CAPK, int W, int OCC, int NL = 4, bool FILT = false>
 __global__ __launch_bounds__(JV_WAVE * W, OCC) void jv_search_pqw_kernel(const JvIndexDev ix, const JvSearchArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int32_t* explog = a.pqp_log + (size_t)blockIdx.x * (size_t)a.pqp_log_cap;
@@ -1068,12 +1238,37 @@ __global__ __launch_bounds__(JV_WAVE * W, OCC) void jv_search_pqw_kernel(const J
 #ifdef JV_STAMPS
     if (threadIdx.x < 16) ((unsigned long long*)(smem + a.pqp_scratch_off + W * 256 + 64))[threadIdx.x] = 0ull;
 #endif
+    // later launches (a.retry_only: wider pool — the filtered rungs): only the queries an earlier one flagged, found up to 8 flags
+    // at a time by the first wave (as jv_search_pqp_kernel does; the chunk shrinks with the number of flags per workgroup)
+    const int chunk = max(1, min(8, a.nq / ((int)gridDim.x * 8)));
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    unsigned long long todo = 0ull;
     for (;;) {
-        if (threadIdx.x == 0) ctrl[PQW_QI] = atomicAdd(a.pqp_counter, 1);
+        if (a.retry_only) {
+            if (threadIdx.x < JV_WAVE) {
+                int next = a.nq;
+                for (;;) {
+                    if (todo) {
+                        next = base + __ffsll((long long)todo) - 1;
+                        todo &= todo - 1ull;
+                        break;
+                    }
+                    if (lane == 0) base = atomicAdd(a.retry_counter, chunk);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base >= a.nq) break;
+                    const int qf = (lane < chunk && base + lane < a.nq) ? a.out_flags[base + lane] : 0;
+                    todo = __ballot(((uint32_t)qf & JV_FLAG_OVERFLOW) != 0);
+                }
+                if (lane == 0) ctrl[PQW_QI] = next;
+            }
+        } else if (threadIdx.x == 0) {
+            ctrl[PQW_QI] = atomicAdd(a.pqp_counter, 1);
+        }
         __syncthreads();
         const int qi = __builtin_amdgcn_readfirstlane(ctrl[PQW_QI]);
         if (qi >= a.nq) break;
-        search_one_pqw<NCHT, CAPK, W, NL>(ix, a, qi, smem, explog);
+        search_one_pqw<NCHT, CAPK, W, NL, FILT>(ix, a, qi, smem, explog);
         __syncthreads();
     }
 }
