@@ -710,8 +710,10 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
                            (rk + 64 + ix->dev.R > 256 || OPT(ix, OPT_LUTR_MIN_QUERIES) == 0 || lutr_applies || pqw_applies);
     // (measured at rerankK = 160, 2M docs, 65 536 queries per launch, selectivity 0.9 / 0.5 / 0.3 / 0.15: round 1's filtered
     //  kernel 1.33 M / 0.90 M / 0.27 M / 37 k QPS, this kernel's register-table variant 1.64 M / 1.07 M / 0.68 M / 227 k)
-    const bool pqp_filt = filtered && pqf_shape && ix->dev.n < (1 << 29) &&
-                          (rk + 64 + ix->dev.R > 256 || OPT(ix, OPT_LUTR_MIN_QUERIES) == 0 || lutr_applies);
+    const bool pqwf_applies = filtered && OPT(ix, OPT_NO_PQW) == 0 && jvk_pqwf_ok(&ix->dev, rk + 64 + ix->dev.R) && nq >= OPT(ix, OPT_PQW_MIN_QUERIES);
+    // (the several-waves filtered kernel also takes PQ-64 — four lanes per neighbour do not fit the one-wave kernel's single pass)
+    const bool pqp_filt = filtered && thr <= 0.0f && (pqf_shape || pqwf_applies) && ix->dev.n < (1 << 29) &&
+                          (rk + 64 + ix->dev.R > 256 || OPT(ix, OPT_LUTR_MIN_QUERIES) == 0 || lutr_applies || pqwf_applies);
     // (shapes whose table leaves the GENERIC kernel no room — g.fast_ok false, e.g. PQ-128 at wide beams — still run the
     //  several-waves kernel, which keeps the table in registers + LDS rows)
     if ((!force_big || (OPT(ix, OPT_FORCE_BIG) == 0 && !g.lutg && pqw_applies)) && (pqp_plain || pqp_filt) && pqf_index && rk + 64 + ix->dev.R <= jvk_pqp_max_entries() && OPT(ix, OPT_NO_PQF) == 0 &&

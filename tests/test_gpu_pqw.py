@@ -333,3 +333,47 @@ def test_batch_calls_do_not_wait_for_a_starting_server_grid(pkg):
     p99 = float(np.percentile(np.array(lat), 99))
     assert len(lat) > 200 and p99 < 10.0, f"batch calls next to {starts} grid starts: p99 {p99:.1f} ms, max {max(lat):.1f} ms over {len(lat)} calls"
     gpu.close()
+
+
+@pytest.mark.parametrize("pq_M,sim", [(32, 0), (32, 1), (64, 0)])
+def test_doc_filters_on_the_several_waves_kernel(pkg, pyoracle, pq_M, sim):
+    """Round 4: filtered fused-PQ searches run two / four waves per query too (jv_kernels_pqwf.hip: key bit "accepted",
+    tracked rk-th best accepted entry, pools of ~ rerankK / selectivity entries up to class 5).  Every filter / beam must
+    equal the oracle on BOTH kernel families — several waves (proved by the launch counter) and, with no_pqw, the one-wave
+    filtered kernels it replaced — with permuted sparse doc ids, deleted ordinals and rerank floors; selective filters at
+    wide beams must be answered on chip (pool classes 3 - 5), not by the HBM-scratch rung."""
+    b, bl = pkg.binding, pkg.builder
+    rng = np.random.default_rng(97 + pq_M + sim)
+    n, d = 24000, 64 if pq_M == 32 else 128
+    centers = rng.standard_normal((64, d)).astype(np.float32)
+    base = (centers[rng.integers(0, 64, n)] + 0.6 * rng.standard_normal((n, d))).astype(np.float32)
+    if sim == 1:
+        base /= np.linalg.norm(base, axis=1, keepdims=True)
+    q = (centers[rng.integers(0, 64, 24)] + 0.6 * rng.standard_normal((24, d))).astype(np.float32)
+    max_doc = 3 * n
+    ord2doc = rng.permutation(max_doc)[:n].astype(np.int32)
+    ord2doc[rng.random(n) < 0.03] = -1   # deleted ordinals
+    ix = bl.build_index_cpu(base, sim, R=32, L=80, pq_M=pq_M, ord2doc=ord2doc, max_doc=max_doc)
+    gpu = b.GpuIndex(ix, flags=b.DESC_FUSED_ADC)
+    orc = pyoracle.Oracle(b, ix)
+    cases = [(0.95, 10, 10, 0.0), (0.7, 10, 64, 0.0), (0.5, 10, 200, 0.0), (0.5, 1, 1, 0.0), (0.3, 20, 400, 0.0), (0.3, 10, 120, 0.52),
+             (0.2, 10, 1000, 0.0), (0.12, 10, 700, 0.0), (0.1, 10, 1200, 0.0), (0.05, 10, 300, 0.0)]
+    for frac, k, rk, floor in cases:
+        docs = np.nonzero(rng.random(max_doc) < frac)[0]
+        words = b.accept_words(docs, max_doc)
+        want = orc.search_batch(q, k, rk, rerank_floor=floor, accept=words, accept_num_docs=max_doc)
+        big = {}
+        for no_pqw in (0, 1):
+            gpu.set_option("no_pqw", no_pqw)
+            before = gpu.counter("launches_pqw")
+            got, _, flags, rc = gpu.search_batch_ex(q, k, rk, rerank_floor=floor, accept=words, accept_num_docs=max_doc)
+            assert rc == 0
+            _assert_same(got, want, f"M={pq_M} sim={sim} frac={frac} k={k} rk={rk} floor={floor} no_pqw={no_pqw}")
+            assert (gpu.counter("launches_pqw") > before) == (no_pqw == 0), "the wrong kernel family answered"
+            big[no_pqw] = int((np.asarray(flags).astype(np.uint32) & 1).sum())
+        gpu.set_option("no_pqw", 0)
+        # (a query whose approximate scores drop below the threshold leaves BOTH families for the two-queue form: what must
+        #  not happen is that the several-waves rungs hand on more than the one-wave rungs did)
+        if rk / frac < 14000:
+            assert big[0] <= big[1] + 2, f"frac={frac} rk={rk}: {big[0]} queries fell to the HBM-scratch rung (one-wave kernels: {big[1]})"
+    gpu.close()
