@@ -6,6 +6,10 @@ import numpy as np, torch
 import __graft_entry__ as g
 g.load_package()
 b = importlib.import_module("opensearch_jvector_amd.binding")
+stamps = os.environ.get("STAMPS", "0") == "1"   # diagnostic build (make stamps): cycles per expansion by phase of the pool wave
+if stamps:
+    b.LIB_PATH = os.path.join(os.path.dirname(b.LIB_PATH), "libjvgpu_stamps.so")
+    b.load_library(b.LIB_PATH)
 gb = importlib.import_module("opensearch_jvector_amd.builder_gpu")
 import bench
 n = int(os.environ.get("N", 2_000_000)); d = 768; M = 32; rk = int(os.environ.get("RK", 160)); B = int(os.environ.get("B", 16384))
@@ -32,11 +36,22 @@ for sel in [None if x == "None" else float(x) for x in os.environ.get("SELS", "N
         words = np.concatenate([words, np.zeros((-len(words)) % 8, np.uint8)]).view(np.uint64)
         acc = torch.from_numpy(words.view(np.int64)).to(dev)
         acc_ptr = acc.data_ptr()
+    if stamps:
+        dbg = torch.zeros(16, dtype=torch.int64, device=dev)
+        ix.set_option("dbg_ptr", dbg.data_ptr())
     for it in range(3):
+        if stamps:
+            dbg.zero_()
         torch.cuda.synchronize(); t = time.time()
         ix.search_batch_device(q.data_ptr(), B, 10, rk, *[t_.data_ptr() for t_ in o], d_accept=acc_ptr, accept_num_docs=(n if acc_ptr else 0))
         torch.cuda.synchronize(); dt = time.time() - t
     st = o[4].cpu().numpy().astype(np.float64).mean(0)
     fl = o[5].cpu().numpy().astype(np.uint32)
     print(f"selectivity {sel}: {B / dt:9.0f} QPS  visited {st[0]:.0f} expanded {st[2]:.0f}  big-path {int((fl & 1).sum())}  count<10: {int((o[3].cpu().numpy() < 10).sum())}", flush=True)
+    if stamps:
+        v = dbg.cpu().numpy().astype(np.float64); ne = max(st[2], 1) * B
+        names = {15: "find", 0: "candidates + barrier A", 9: "wait for blocks", 1: "mark + log", 2: "ADC + exchange", 3: "boundary + rank + dedupe", 14: "ranks among new keys",
+                 4: "shift + insert (incl. 14)", 5: "boundary tracking + trim", 6: "visited-count pass", 13: "rerank + top-K"}
+        print("   cycles per expansion (pool wave): " + ", ".join(f"{nm} {v[i] / ne:.0f}" for i, nm in names.items()) + f"; passes/exp {v[8] / ne:.2f} dual/exp {v[10] / ne:.2f}", flush=True)
+        ix.set_option("dbg_ptr", 0)
 print("done")
