@@ -74,6 +74,11 @@ int jvk_pqsf_max_entries(void);
 hipError_t jvk_pqsf_set_max_lds(int bytes);
 int jvk_pqsf_blocks_per_cu(const JvIndexDev* ix, int lds_bytes, int lutr);
 hipError_t jvk_launch_serve_pqpf(const JvIndexDev* ix, const JvSearchArgs* a, int lds_bytes, int blocks, int lutr, hipStream_t s);
+// the filtered server on the several-waves kernel (jv_kernels_pqs.hip, round 4)
+int jvk_pqswf_max_entries(void);
+hipError_t jvk_pqswf_set_max_lds(int bytes);
+int jvk_pqswf_blocks_per_cu(const JvIndexDev* ix, int lds_bytes);
+hipError_t jvk_launch_serve_pqwf(const JvIndexDev* ix, const JvSearchArgs* a, int lds_bytes, int blocks, hipStream_t s);
 }
 
 namespace {
@@ -1027,6 +1032,7 @@ struct JvQueryServer {
     int slots = 0, slot_bytes = 0, cap_max = 0, blocks = 0, lds = 0;
     int kind = 0;                   // 0: unfiltered queries on the several-waves kernel; 1: queries with a doc filter (one-wave filtered pool kernel)
     int lutr = 0;                   // kind 1: look-up table in registers
+    int waves_f = 0;                // kind 1: the several-waves filtered kernel serves (PQ-32 / PQ-64), else the one-wave one
     hipStream_t up_stream = nullptr;  // kind 1: filter uploads of cache misses (the grid's own stream never drains)
     JvSearchArgs args{};
     std::atomic<uint32_t> reserve{0};
@@ -1165,7 +1171,8 @@ int server_launch_locked(Server* sv) {  // sv->mu held, grid not alive
     HIPCHK(hipMemsetAsync(sv->d_words + JV_SV_LOCK, 0, 4 * sizeof(int32_t), sv->stream));  // LOCK, EXITED, LAST_CLAIM, STOP_SEEN
     __atomic_store_n(&sv->h_words[JV_SH_ALIVE], 1, __ATOMIC_RELEASE);
     hipError_t e = sv->kind == 0 ? jvk_launch_serve_pqw(&ix->dev, &sv->args, sv->lds, sv->blocks, sv->stream)
-                                 : jvk_launch_serve_pqpf(&ix->dev, &sv->args, sv->lds, sv->blocks, sv->lutr, sv->stream);
+                   : (sv->waves_f ? jvk_launch_serve_pqwf(&ix->dev, &sv->args, sv->lds, sv->blocks, sv->stream)
+                                  : jvk_launch_serve_pqpf(&ix->dev, &sv->args, sv->lds, sv->blocks, sv->lutr, sv->stream));
     if (e != hipSuccess) {
         __atomic_store_n(&sv->h_words[JV_SH_ALIVE], 0, __ATOMIC_RELEASE);
         return fail(JV_EDEVICE, "query server launch failed: %s", hipGetErrorString(e));
@@ -1230,27 +1237,32 @@ Server* server_get(jv_index* ix, int kind, int need_cap, int* rc) {
         // one wave gathers from an LDS table 1.4x faster than it permutes registers (measured: 7.4 vs 10.4 ms per query at
         // selectivity 0.5, rerankK 1 200) — two resident queries per CU instead of four, which only matters beyond 512 callers
         sv->lutr = 0;
+        // Round 4: PQ-32 / PQ-64 indexes are served by the several-waves filtered kernel (two / four waves per query, whole table
+        // in LDS: its latency variant) — the same one pool, sized the same way.
+        sv->waves_f = (OPT(ix, OPT_NO_PQW) == 0 && jvk_pqwf_ok(&ix->dev, 4097)) ? 1 : 0;
+        auto plan_f = [&](JvSearchArgs& x, int rk_) { return sv->waves_f ? plan_pqw_lds(ix, x, 1) : plan_pqp_lds(ix, x, false, rk_); };
         {
             // the largest pool that keeps TWO queries resident per CU next to this index's table (one if even 4 097 entries do not)
             JvSearchArgs probe = a;
             probe.cand_cap = 4097;
-            const int fixed = plan_pqp_lds(ix, probe, false, 4097 - 64 - R) - 4098 * 8;
+            const int fixed = plan_f(probe, 4097 - 64 - R) - 4098 * 8;
             int cap = 0;
-            for (int per = 2; per >= 1 && cap < 4097; per--) cap = std::min(((161280 / per - fixed - 256) / 8 - 1) & ~63, jvk_pqsf_max_entries());
+            for (int per = 2; per >= 1 && cap < 4097; per--)
+                cap = std::min(((161280 / per - fixed - 256) / 8 - 1) & ~63, sv->waves_f ? jvk_pqswf_max_entries() : jvk_pqsf_max_entries());
             sv->cap_max = cap;
         }
         a.cand_cap = sv->cap_max;
         a.rk = sv->cap_max - 64 - R;
         a.pqp_log_cap = 3 * sv->cap_max;
-        sv->lds = sv->cap_max >= 4097 ? plan_pqp_lds(ix, a, false, a.rk) : kMaxLds + 1;
+        sv->lds = sv->cap_max >= 4097 ? plan_f(a, a.rk) : kMaxLds + 1;
         if (sv->lds > kMaxLds) {
             delete sv;
             *rc = JV_OK;
             return nullptr;  // (this PQ shape's table leaves no room for the pool: launch path)
         }
         // (what a CU really keeps resident: tools/lds_residency.hip — a little less than 160 KB can be shared)
-        per_cu = std::max(1, std::min<int>(std::min(jvk_pqsf_blocks_per_cu(&ix->dev, sv->lds, sv->lutr), 161280 / sv->lds),
-                                           (int)std::max<int64_t>(1, 2 * OPT(ix, OPT_SERVE_WGS_PER_CU))));  // (one wave per query here: twice the workgroups)
+        per_cu = std::max(1, std::min<int>(std::min(sv->waves_f ? jvk_pqswf_blocks_per_cu(&ix->dev, sv->lds) : jvk_pqsf_blocks_per_cu(&ix->dev, sv->lds, sv->lutr), 161280 / sv->lds),
+                                           (int)std::max<int64_t>(1, 2 * OPT(ix, OPT_SERVE_WGS_PER_CU))));  // (twice the unfiltered server's workgroups where the LDS allows)
     }
     sv->blocks = ix->cu_count * per_cu;
     sv->slots = next_pow2(std::max(1024, 2 * sv->blocks));
@@ -1312,7 +1324,8 @@ int serve_query(jv_index* ix, const float* query, int32_t topK, int32_t rerankK,
     } else {
         // the shapes the filtered pool kernel takes (enqueue_batch): single-pass fused blocks, flat graph, ordinals below 2^29
         const JvIndexDev& dv = ix->dev;
-        if (OPT(ix, OPT_FILTER_CACHE) <= 0 || accept_docs <= 0 || dv.num_upper != 0 || dv.R > JV_WAVE || dv.R * dv.pq_lanes > JV_WAVE ||
+        const bool wf = OPT(ix, OPT_NO_PQW) == 0 && jvk_pqwf_ok(&ix->dev, 4097);  // (the several-waves filtered server also takes PQ-64)
+        if (OPT(ix, OPT_FILTER_CACHE) <= 0 || accept_docs <= 0 || dv.num_upper != 0 || dv.R > JV_WAVE || (!wf && dv.R * dv.pq_lanes > JV_WAVE) ||
             dv.n >= (1 << 29) || cap > jvk_pqsf_max_entries())
             return 1;
         if (ix->server_f && cap > ix->server_f->cap_max) return 1;  // (a beam wider than the server's pool: launch path)
@@ -1730,6 +1743,7 @@ int jv_index_create(const jv_index_desc* desc, jv_index** out) {
         TRYHIP(jvk_pqwf_set_max_lds(kMaxLds));
         TRYHIP(jvk_pqs_set_max_lds(kMaxLds));
         TRYHIP(jvk_pqsf_set_max_lds(kMaxLds));
+        TRYHIP(jvk_pqswf_set_max_lds(kMaxLds));
         {
             hipDeviceProp_t prop;
             if (hipGetDeviceProperties(&prop, desc->device) == hipSuccess && prop.multiProcessorCount > 0) ix->cu_count = prop.multiProcessorCount;

@@ -50,3 +50,29 @@ extern "C" hipError_t jvk_launch_serve_pqw(const JvIndexDev* ix, const JvSearchA
     pqs_pick(ix, a->cand_cap)<<<blocks, JV_WAVE * (ix->pq_M / 16), lds_bytes, stream>>>(*ix, *a);
     return hipGetLastError();
 }
+
+// ---- one-query calls WITH a doc filter on the several-waves kernel (round 4; the one-wave filtered server is jv_kernels_pqsf.hip) ----
+// pool class 4 (<= 8 192 entries: the host sizes the pool to what keeps two queries resident per CU next to the table in LDS)
+#define JV_PQSWF_ROW(W, OCC) \
+    { jv_serve_pqw_kernel<0, 4, W, OCC, 16, true>, jv_serve_pqw_kernel<2, 4, W, OCC, 16, true>, jv_serve_pqw_kernel<12, 4, W, OCC, 16, true>, jv_serve_pqw_kernel<24, 4, W, OCC, 16, true> }
+static const pqs_kernel_t g_pqswf_kernels[2][4] = {JV_PQSWF_ROW(2, 2), JV_PQSWF_ROW(4, 2)};
+static pqs_kernel_t pqswf_pick(const JvIndexDev* ix) { return g_pqswf_kernels[ix->pq_M == 64 ? 1 : 0][pqs_nch_slot(ix)]; }
+extern "C" int jvk_pqswf_max_entries(void) { return 8192; }
+extern "C" hipError_t jvk_pqswf_set_max_lds(int bytes) {
+    for (int w = 0; w < 2; w++)
+        for (int s = 0; s < 4; s++) {
+            hipError_t e = hipFuncSetAttribute((const void*)g_pqswf_kernels[w][s], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            if (e != hipSuccess) return e;
+        }
+    return hipSuccess;
+}
+extern "C" int jvk_pqswf_blocks_per_cu(const JvIndexDev* ix, int lds_bytes) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)pqswf_pick(ix), JV_WAVE * (ix->pq_M / 16), (size_t)lds_bytes) != hipSuccess) return 1;
+    return nb < 1 ? 1 : nb;
+}
+// a->cand_cap = the server's pool (4 097 .. 8 192 entries)
+extern "C" hipError_t jvk_launch_serve_pqwf(const JvIndexDev* ix, const JvSearchArgs* a, int lds_bytes, int blocks, hipStream_t stream) {
+    pqswf_pick(ix)<<<blocks, JV_WAVE * (ix->pq_M / 16), lds_bytes, stream>>>(*ix, *a);
+    return hipGetLastError();
+}

@@ -120,12 +120,17 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
                 a.out_flags[qi] = (int32_t)(JV_FLAG_OVERFLOW | (9u << 8));  // (9: estimated pool beyond this launch's)
                 a.out_count[qi] = 0;
             }
-            if (wv == 0)
+            if (wv == 0) {
                 for (int i = lane; i < topK; i += JV_WAVE) {
                     o_nodes[i] = -1;
                     if (o_docs) o_docs[i] = -1;
                     o_scores[i] = 0.0f;
                 }
+                if (a.done && a.done_all) {  // (server mode: the caller redoes a flagged row on the launch path)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+                    if (lane == 0) __hip_atomic_store(&a.done[qi], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
             return;
         }
     }
@@ -1186,7 +1191,7 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
 // few hardware queues.  Callers publish slots in ticket order (host word TAIL); workgroups claim tickets with a
 // compare-and-swap on HEAD once PUBLISHED has caught up with TAIL (one workgroup at a time reads the host word), answer into
 // the slot and set its completion word.  The grid leaves when the host says STOP or nothing was claimed for serve_idle_ticks.
-template <int NCHT, int CAPK, int W, int OCC, int NL = 4>
+template <int NCHT, int CAPK, int W, int OCC, int NL = 4, bool FILT = false>
 __global__ __launch_bounds__(JV_WAVE * W, OCC) void jv_serve_pqw_kernel(const JvIndexDev ix, const JvSearchArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int32_t* explog = a.pqp_log + (size_t)blockIdx.x * (size_t)a.pqp_log_cap;
@@ -1216,6 +1221,16 @@ __global__ __launch_bounds__(JV_WAVE * W, OCC) void jv_serve_pqw_kernel(const Jv
         aq.visit_limit = __builtin_amdgcn_readfirstlane(slot->visit_limit);
         aq.rerank_floor = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(slot->rerank_floor)));
         aq.cand_cap = aq.rk + 64 + ix.R;  // (the pool a batch launch of this rerankK would use; the LDS plan covers the largest)
+        if (FILT) {
+            // a query with a doc filter: every request runs in the server's ONE pool (a.cand_cap); a filter whose estimated pool
+            // does not fit is handed back at once (retry_only = 1 = "a wider rung follows": the caller takes the launch path)
+            aq.cand_cap = a.cand_cap;
+            aq.accept = (const uint64_t*)(uintptr_t)slot->accept;
+            aq.accept_docs = slot->accept_docs;
+            aq.accept_stride = 0;
+            aq.accept_ord = nullptr;
+            aq.retry_only = 1;
+        }
         aq.out_nodes = slot->nodes;
         aq.out_docs = slot->docs;
         aq.out_scores = slot->scores;
@@ -1224,7 +1239,7 @@ __global__ __launch_bounds__(JV_WAVE * W, OCC) void jv_serve_pqw_kernel(const Jv
         aq.out_flags = &slot->flags;
         aq.done = &slot->done;
         aq.done_all = 1;
-        search_one_pqw<NCHT, CAPK, W, NL>(ix, aq, 0, smem, explog);
+        search_one_pqw<NCHT, CAPK, W, NL, FILT>(ix, aq, 0, smem, explog);
         __syncthreads();
     }
     jv_serve_leave(a);
