@@ -45,6 +45,8 @@ def _prune_lib():
         lib.jvb_prune_rows_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp, C.c_int,
                                               vp, vp]
         lib.jvb_prune_rows_device.restype = C.c_int
+        lib.jvb_backlinks_device.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]
+        lib.jvb_backlinks_device.restype = C.c_int
         lib.jvb_pq_encode_device.argtypes = [vp, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int,
                                              C.c_int, vp]
         lib.jvb_pq_encode_device.restype = C.c_int
@@ -268,41 +270,52 @@ def merge_leading_segment_gpu(torch, base, lead_adj, lead_entry, lead_live, sim,
     return out, int(mid_to_final[entry_mid]), final_to_mid
 
 
+_BL_STATE = {}
+
+
 def _add_backlinks(torch, base, adj, deg, u, sel, R, Rcap, alpha, sim):
-    """for every new edge u -> s add s -> u; rows that would exceed Rcap are re-pruned to R."""
+    """for every new edge u -> s add s -> u; rows that would exceed Rcap are re-pruned to R.
+    Grouping, ordering and the append run in csrc/jv_build_kernels.hip (jvb_backlinks_device: per-target lists, sources sorted
+    by id — reproducible); this function owns the scratch buffers and hands the overflowing rows to the selection kernel."""
     dev = base.device
-    B = u.shape[0]
-    src = sel.reshape(-1).long()
-    dst = u[:, None].expand(B, sel.shape[1]).reshape(-1)
-    m = src >= 0
-    src, dst = src[m], dst[m]
-    if src.numel() == 0:
+    B = int(u.shape[0])
+    if B == 0:
         return
-    src, perm = torch.sort(src, stable=True)
-    dst = dst[perm]
-    uniq, counts = torch.unique_consecutive(src, return_counts=True)
-    starts = torch.cumsum(counts, 0) - counts
-    rank = torch.arange(src.numel(), device=dev) - torch.repeat_interleave(starts, counts)
-    dcur = deg[uniq].long()
-    total = dcur + counts
-    fits = total <= Rcap
-    fits_pair = torch.repeat_interleave(fits, counts)
-    col = torch.repeat_interleave(dcur, counts) + rank
-    adj[src[fits_pair], col[fits_pair]] = dst[fits_pair].to(torch.int32)
-    deg[uniq[fits]] = total[fits].to(torch.int32)
-    ov = uniq[~fits]
-    if ov.numel() == 0:
+    n = int(adj.shape[0])
+    key = (dev.index, n)
+    stt = _BL_STATE.get(key)
+    if stt is None:
+        _BL_STATE.clear()   # (one graph under construction at a time)
+        stt = dict(head=torch.full((n,), -1, dtype=torch.int32, device=dev), counters=torch.zeros((2,), dtype=torch.int32, device=dev))
+        _BL_STATE[key] = stt
+    E = B * int(sel.shape[1])
+    if stt.get("E", 0) < E:
+        stt["next"] = torch.empty((E,), dtype=torch.int32, device=dev)
+        stt["touched"] = torch.empty((E,), dtype=torch.int32, device=dev)
+        stt["E"] = E
+    Lc = min(PRUNE_MAX_CANDIDATES, 2 * int(Rcap))   # the row + as many new sources again (the smallest ids when a target has more)
+    ov_rows = min(E, n)
+    if stt.get("ov_rows", 0) < ov_rows:
+        stt["ov_nodes"] = torch.empty((ov_rows,), dtype=torch.int32, device=dev)
+        stt["ov_cand"] = torch.empty((ov_rows, Lc), dtype=torch.int32, device=dev)
+        stt["ov_rows"] = ov_rows
+    u64 = u.to(torch.int64).contiguous()
+    sel32 = sel.contiguous()
+    lib = _prune_lib()
+    rc = lib.jvb_backlinks_device(u64.data_ptr(), B, sel32.data_ptr(), int(sel32.stride(0)), int(sel32.shape[1]), adj.data_ptr(), int(Rcap),
+                                  deg.data_ptr(), stt["head"].data_ptr(), stt["next"].data_ptr(), stt["touched"].data_ptr(),
+                                  stt["counters"].data_ptr(), stt["ov_nodes"].data_ptr(), stt["ov_cand"].data_ptr(), int(stt["ov_rows"]), Lc,
+                                  torch.cuda.current_stream(dev).cuda_stream)
+    if rc != 0:
+        raise RuntimeError(f"jvb_backlinks_device failed: {rc}")
+    nov = int(stt["counters"][1].item())
+    if nov == 0:
         return
-    m_new = int(min(Rcap, int(counts[~fits].max())))
-    cand = torch.full((ov.numel(), Rcap + m_new), -1, dtype=torch.int32, device=dev)
-    cand[:, :Rcap] = adj[ov]
-    ov_pair = ~fits_pair & (rank < m_new)
-    group_of_pair = torch.repeat_interleave(torch.cumsum((~fits).long(), 0) - 1, counts)
-    cand[group_of_pair[ov_pair], Rcap + rank[ov_pair]] = dst[ov_pair].to(torch.int32)
+    assert nov <= stt["ov_rows"]
     ch = 8192
-    for s in range(0, ov.numel(), ch):
-        o = ov[s:s + ch]
-        sel2, nsel2 = robust_prune(torch, base, o, cand[s:s + ch], R, alpha, sim)
+    for s0 in range(0, nov, ch):
+        o = stt["ov_nodes"][s0:min(nov, s0 + ch)].long()
+        sel2, nsel2 = robust_prune(torch, base, o, stt["ov_cand"][s0:min(nov, s0 + ch)], R, alpha, sim)
         adj[o, :R] = sel2
         adj[o, R:] = -1
         deg[o] = nsel2

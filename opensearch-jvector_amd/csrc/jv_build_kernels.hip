@@ -22,7 +22,6 @@
 // ---------------------------------------------------------------------------------------------------------------
 #define JVB_PRUNE_MAX_LC 160
 #define JVB_PRUNE_KC 32
-#define JVB_PRUNE_TR 10
 __device__ __forceinline__ float jvb_sim_from_dot(int sim, float dot, float sqa, float sqb) {
     if (sim == 0) {
         float d2 = sqa + sqb - 2.0f * dot;
@@ -34,6 +33,7 @@ __device__ __forceinline__ float jvb_sim_from_dot(int sim, float dot, float sqa,
     den = den < 1e-30f ? 1e-30f : den;
     return (1.0f + dot / sqrtf(den)) * 0.5f;
 }
+template <int JVB_PRUNE_TR>  // register tile edge: 16 * TR >= Lc (5: <= 80 candidates, 7: <= 112, 10: <= 160)
 __global__ __launch_bounds__(256) void jvb_prune_rows_kernel(const float* __restrict__ base, int d, int stride, int sim,
                                                              const long long* __restrict__ centers,   // [S]
                                                              const int32_t* __restrict__ cand, int cand_stride,  // [S][Lc], -1 = empty
@@ -217,12 +217,117 @@ extern "C" int jvb_prune_rows_device(const float* base, int d, int stride, int s
     if (lds > 160 * 1024) return -4;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)jvb_prune_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)jvb_prune_rows_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)jvb_prune_rows_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)jvb_prune_rows_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return -3;
         attr_set = true;
     }
-    jvb_prune_rows_kernel<<<S, 256, lds, (hipStream_t)stream>>>(base, d, stride, sim, centers, cand, cand_stride, S, Lc, R, alpha, sel,
-                                                                 sel_stride, nsel);
+    hipStream_t st = (hipStream_t)stream;
+    if (Lc <= 80) jvb_prune_rows_kernel<5><<<S, 256, lds, st>>>(base, d, stride, sim, centers, cand, cand_stride, S, Lc, R, alpha, sel, sel_stride, nsel);
+    else if (Lc <= 112) jvb_prune_rows_kernel<7><<<S, 256, lds, st>>>(base, d, stride, sim, centers, cand, cand_stride, S, Lc, R, alpha, sel, sel_stride, nsel);
+    else jvb_prune_rows_kernel<10><<<S, 256, lds, st>>>(base, d, stride, sim, centers, cand, cand_stride, S, Lc, R, alpha, sel, sel_stride, nsel);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Back-links of one insertion batch (round 4; J/JVectorWriter.java:1383-1422: addGraphNode links both ways): for every new
+// edge u -> s add s -> u.  Round 3 grouped the edges by target with a torch stable sort + unique_consecutive +
+// repeat_interleave.  Here: (1) every edge pushes itself onto its target's list (atomicExch on a per-node head word; the
+// first edge of a target also appends the target to a work list), (2) one wave per touched target walks its list, SORTS the
+// sources by id — the order the atomics happened in is gone, two builds give the same rows — and either appends them to the
+// row (it has room: neighborOverflow slack) or emits the row + the (smallest-id) new sources as candidates for a re-prune.
+// ---------------------------------------------------------------------------------------------------------------
+#define JVB_BL_MAX 1024  // sources of one target held in LDS for the sort (more than that: the smallest ids are kept)
+__global__ __launch_bounds__(256) void jvb_backlink_push_kernel(const int32_t* __restrict__ sel, int sel_stride, int B, int R,
+                                                                int32_t* __restrict__ head, int32_t* __restrict__ next,
+                                                                int32_t* __restrict__ touched, int32_t* __restrict__ counters) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long long)B * R) return;
+    const int p = (int)(e / R), j = (int)(e % R);
+    const int s = sel[(size_t)p * sel_stride + j];
+    if (s < 0) return;
+    const int old = atomicExch(&head[s], (int)e);
+    next[e] = old;
+    if (old < 0) touched[atomicAdd(&counters[0], 1)] = s;
+}
+__global__ __launch_bounds__(64) void jvb_backlink_apply_kernel(const long long* __restrict__ u, int R, int32_t* __restrict__ adj, int Rcap,
+                                                                int32_t* __restrict__ deg, int32_t* __restrict__ head,
+                                                                const int32_t* __restrict__ next, const int32_t* __restrict__ touched,
+                                                                int32_t* __restrict__ counters, int32_t* __restrict__ ov_nodes,
+                                                                int32_t* __restrict__ ov_cand, int ov_rows, int Lc) {
+    __shared__ int32_t src[JVB_BL_MAX];
+    __shared__ int32_t srt[JVB_BL_MAX];
+    const int lane = threadIdx.x;
+    const int ntouched = counters[0];
+    for (int t = blockIdx.x; t < ntouched; t += gridDim.x) {
+        const int s = touched[t];
+        // walk the list (one lane: a pointer chase), keep the sources; beyond the LDS array only the smallest ids stay
+        int c = 0;
+        if (lane == 0) {
+            int e = head[s];
+            head[s] = -1;
+            int worst = -1, worst_i = -1;
+            while (e >= 0) {
+                const int su = (int)u[e / R];
+                if (c < JVB_BL_MAX) {
+                    src[c++] = su;
+                } else {  // (rare: a hub node met by more than 1 024 sources of one batch)
+                    if (worst_i < 0) {
+                        for (int i = 0; i < JVB_BL_MAX; i++)
+                            if (src[i] > worst) worst = src[i], worst_i = i;
+                    }
+                    if (su < worst) {
+                        src[worst_i] = su;
+                        worst = -1;
+                        worst_i = -1;
+                    }
+                }
+                e = next[e];
+            }
+        }
+        c = __shfl(c, 0, 64);
+        __syncthreads();
+        // sort by id (rank by counting: ids of one target's sources are distinct)
+        for (int i = lane; i < c; i += 64) {
+            const int v = src[i];
+            int r = 0;
+            for (int k = 0; k < c; k++) r += src[k] < v ? 1 : 0;
+            srt[r] = v;
+        }
+        __syncthreads();
+        const int d0 = deg[s];
+        if (d0 + c <= Rcap) {
+            for (int i = lane; i < c; i += 64) adj[(size_t)s * Rcap + d0 + i] = srt[i];
+            if (lane == 0) deg[s] = d0 + c;
+        } else {
+            int row = 0;
+            if (lane == 0) row = atomicAdd(&counters[1], 1);
+            row = __shfl(row, 0, 64);
+            if (row < ov_rows) {
+                if (lane == 0) ov_nodes[row] = s;
+                for (int i = lane; i < Lc; i += 64) {
+                    int v = -1;
+                    if (i < Rcap) v = adj[(size_t)s * Rcap + i];
+                    else if (i - Rcap < c) v = srt[i - Rcap];
+                    ov_cand[(size_t)row * Lc + i] = v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+// counters[0] = touched targets, counters[1] = rows that need a re-prune (both zeroed here); head[] must be -1 everywhere on
+// entry and is -1 everywhere on return.  Returns 0; the caller reads counters[1] and prunes ov_cand's rows.
+extern "C" int jvb_backlinks_device(const long long* u, int B, const int32_t* sel, int sel_stride, int R, int32_t* adj, int Rcap,
+                                    int32_t* deg, int32_t* head, int32_t* next, int32_t* touched, int32_t* counters,
+                                    int32_t* ov_nodes, int32_t* ov_cand, int ov_rows, int Lc, void* stream) {
+    if (B <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(counters, 0, 2 * sizeof(int32_t), st) != hipSuccess) return -3;
+    const long long E = (long long)B * R;
+    jvb_backlink_push_kernel<<<(unsigned)((E + 255) / 256), 256, 0, st>>>(sel, sel_stride, B, R, head, next, touched, counters);
+    jvb_backlink_apply_kernel<<<4096, 64, 0, st>>>(u, R, adj, Rcap, deg, head, next, touched, counters, ov_nodes, ov_cand, ov_rows, Lc);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

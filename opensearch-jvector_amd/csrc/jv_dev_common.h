@@ -206,7 +206,9 @@ __device__ __forceinline__ void score_rows_t(const JvIndexDev& ix, const float* 
 
 // Same arithmetic, specialised for rows of exactly NCH 64-float chunks: every 16-B load of U row-groups
 // (4U rows) is issued before the first fma, so one pass costs one HBM round trip.
-template <int SIM, int NCH, int U, bool FULL>
+// STREAM: the rows are read once per launch (the rerank of a PQ search over a corpus far beyond the caches): non-temporal loads.
+// The exact kernels re-read hot rows from L2 / MALL (C2: every row ~90 times per launch) and keep the default policy.
+template <int SIM, int NCH, int U, bool FULL, bool STREAM = false>
 __device__ __forceinline__ void score_rows_fixed(const JvIndexDev& ix, const float* q_lds, const int32_t* todo,
                                                  int m, float* todo_score, float qnorm2, float scale, int lane) {
     const int g = lane >> 4, t = lane & 15;
@@ -222,7 +224,7 @@ __device__ __forceinline__ void score_rows_fixed(const JvIndexDev& ix, const flo
                 const float* rp = ix.vectors + (size_t)todo[r] * (size_t)stride + 4 * t;
 #pragma unroll
                 for (int j = 0; j < NCH; j++) {
-                    if (FULL || (j * 64 + 4 * t) < stride) v[u][j] = JV_STREAM_LOAD((const f32x4*)(rp + j * 64));  // (read once: not worth an L2 line — the codebook and the adjacency rows are)
+                    if (FULL || (j * 64 + 4 * t) < stride) v[u][j] = STREAM ? JV_STREAM_LOAD((const f32x4*)(rp + j * 64)) : *(const f32x4*)(rp + j * 64);
                     else v[u][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
             } else {
@@ -374,7 +376,7 @@ __device__ __forceinline__ void score_rows_nvq_t(const JvIndexDev& ix, const flo
 template <int NCHT>
 struct RowsInFlight { static constexpr int U = NCHT <= 6 ? 4 : (NCHT <= 12 ? 2 : 1); };
 
-template <int NCHT, int UMUL = 1>
+template <int NCHT, int UMUL = 1, bool STREAM = false>
 __device__ __forceinline__ void score_rows(const JvIndexDev& ix, const float* q_lds, const int32_t* todo, int m,
                                            float* todo_score, float qnorm2, float scale, int lane) {
     // NVQ-inline field: exact scores against the dequantised records.  Only the "any d" instances (NCHT = 0) carry the
@@ -393,9 +395,9 @@ __device__ __forceinline__ void score_rows(const JvIndexDev& ix, const float* q_
     } else {
         constexpr int N = NCHT == 0 ? 1 : NCHT;
         constexpr int U = RowsInFlight<N>::U * UMUL;
-        if (ix.sim == 0) score_rows_fixed<0, N, U, true>(ix, q_lds, todo, m, todo_score, qnorm2, scale, lane);
-        else if (ix.sim == 1) score_rows_fixed<1, N, U, true>(ix, q_lds, todo, m, todo_score, qnorm2, scale, lane);
-        else score_rows_fixed<2, N, U, true>(ix, q_lds, todo, m, todo_score, qnorm2, scale, lane);
+        if (ix.sim == 0) score_rows_fixed<0, N, U, true, STREAM>(ix, q_lds, todo, m, todo_score, qnorm2, scale, lane);
+        else if (ix.sim == 1) score_rows_fixed<1, N, U, true, STREAM>(ix, q_lds, todo, m, todo_score, qnorm2, scale, lane);
+        else score_rows_fixed<2, N, U, true, STREAM>(ix, q_lds, todo, m, todo_score, qnorm2, scale, lane);
     }
 }
 

@@ -901,7 +901,7 @@ __device__ __forceinline__ void search_one_pqp(const JvIndexDev& ix, const JvSea
         if (take) todo[__popcll(tm & ((1ull << lane) - 1ull))] = node;
         __syncthreads();
         if (m > 0) {
-            score_rows<NCHT, JV_PQF_RERANK_UMUL>(ix, q_lds, todo, m, todo_score, qnorm2, 1.0f, lane);
+            score_rows<NCHT, JV_PQF_RERANK_UMUL, true>(ix, q_lds, todo, m, todo_score, qnorm2, 1.0f, lane);
             __syncthreads();
             if (lane < m) fin[nfin + lane] = make_key(todo_score[lane], todo[lane]);
             nfin += m;

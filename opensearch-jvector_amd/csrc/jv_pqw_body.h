@@ -1137,7 +1137,7 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
         if (take) todo[slot] = node;
         pqw_wave_sync();
         if (m > 0) {
-            score_rows<NCHT, 1>(ix, q_lds, todo, m, todo_score, qnorm2, 1.0f, lane);  // (rows in flight sized for 128 VGPRs)
+            score_rows<NCHT, 1, true>(ix, q_lds, todo, m, todo_score, qnorm2, 1.0f, lane);  // (rows in flight sized for 128 VGPRs)
             pqw_wave_sync();
         }
         if (i < nres) fin[i] = take ? make_key(todo_score[slot], node) : KEY_MIN;
