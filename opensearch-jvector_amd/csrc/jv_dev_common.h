@@ -208,12 +208,20 @@ __device__ __forceinline__ void score_rows_t(const JvIndexDev& ix, const float* 
 // (4U rows) is issued before the first fma, so one pass costs one HBM round trip.
 // STREAM: the rows are read once per launch (the rerank of a PQ search over a corpus far beyond the caches): non-temporal loads.
 // The exact kernels re-read hot rows from L2 / MALL (C2: every row ~90 times per launch) and keep the default policy.
+// the lane id, computed where it is used: a volatile asm cannot be hoisted, so nothing derived from it lives across a kernel's
+// register peaks (a spilled lane constant reloaded between two row groups is a vmcnt(0): it waits for the first group's loads)
+__device__ __forceinline__ int jv_lane_now() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
 template <int SIM, int NCH, int U, bool FULL, bool STREAM = false>
 __device__ __forceinline__ void score_rows_fixed(const JvIndexDev& ix, const float* q_lds, const int32_t* todo,
                                                  int m, float* todo_score, float qnorm2, float scale, int lane) {
-    const int g = lane >> 4, t = lane & 15;
     const int stride = ix.stride;  // FULL: stride == NCH * 64, no partial chunk
     for (int base = 0; base < m; base += 4 * U) {
+        const int ln = jv_lane_now();
+        const int g = ln >> 4, t = ln & 15;
         f32x4 v[U][NCH];
         bool val[U];
 #pragma unroll

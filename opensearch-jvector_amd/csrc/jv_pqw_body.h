@@ -1260,7 +1260,7 @@ __global__ __launch_bounds__(JV_WAVE * W, OCC) void jv_search_pqw_kernel(const J
     int base = 0;
     unsigned long long todo = 0ull;
     for (;;) {
-        if (a.retry_only) {
+        if (FILT && a.retry_only) {  // (only the filtered rungs walk flags: the unfiltered instances do not carry this state across queries)
             if (threadIdx.x < JV_WAVE) {
                 int next = a.nq;
                 for (;;) {

@@ -190,3 +190,57 @@ def test_leading_segment_merge_on_the_gpu(pkg):
         gpu.close()
     for oqf in (5, 20):
         assert recs["merged", oqf] >= recs["scratch", oqf] - 0.02, recs
+
+
+def test_fused_prune_kernel_equals_a_float64_reference(pkg):
+    """Round 4: the diversity selection runs in ONE hand-written kernel per call (csrc/jv_build_kernels.hip
+    jvb_prune_rows_kernel: scores to the centre, (score desc, id asc) order, duplicate removal, LDS-tiled candidate x candidate
+    products, jvector's alpha sweep).  Every row must equal a float64 restatement of the rule on generic data: L2 / dot /
+    cosine, row lengths 32 .. 768, 40 .. 160 candidates with holes, duplicates and the centre itself among them."""
+    torch, gb = _gb()
+    dev = torch.device("cuda", 0)
+
+    def ref_prune(b, c, cand, R, alpha, sim):
+        def simf(x, y):
+            dot = float(b[x] @ b[y])
+            if sim == 0:
+                return 1.0 / (1.0 + max(0.0, float(b[x] @ b[x] + b[y] @ b[y] - 2 * dot)))
+            if sim == 1:
+                return (1.0 + dot) / 2
+            return (1.0 + dot / np.sqrt(max(1e-30, float(b[x] @ b[x]) * float(b[y] @ b[y])))) / 2
+        ids = sorted({int(x) for x in cand if x >= 0 and x != c}, key=lambda x: (-simf(x, c), x))
+        sel, taken, a = [], set(), 1.0
+        while a <= alpha + 1e-6 and len(sel) < R:
+            for x in ids:
+                if len(sel) >= R:
+                    break
+                if x in taken or any(simf(x, s) > simf(x, c) * a for s in sel):
+                    continue
+                sel.append(x)
+                taken.add(x)
+            a += 0.2
+        return sel
+
+    rng = np.random.default_rng(3)
+    for sim in (0, 1, 2):
+        for d in (32, 100, 768):
+            n = 2000
+            centers = rng.standard_normal((40, d)).astype(np.float32)
+            base = (centers[rng.integers(0, 40, n)] + 0.5 * rng.standard_normal((n, d))).astype(np.float32)
+            if sim == 1:
+                base /= np.linalg.norm(base, axis=1, keepdims=True)
+            tb = torch.from_numpy(base).to(dev)
+            b64 = base.astype(np.float64)
+            for Lc in (40, 100, 160):
+                S = 24
+                cen = rng.integers(0, n, S)
+                cand = rng.integers(0, n, (S, Lc)).astype(np.int32)
+                cand[rng.random((S, Lc)) < 0.1] = -1
+                cand[:, 5] = cand[:, 4]
+                cand[:, 7] = cen
+                sel, nsel = gb.robust_prune(torch, tb, torch.from_numpy(cen).to(dev), torch.from_numpy(cand).to(dev), 32, 1.2, sim)
+                sel, nsel = sel.cpu().numpy(), nsel.cpu().numpy()
+                for i in range(S):
+                    want = ref_prune(b64, int(cen[i]), cand[i], 32, 1.2, sim)
+                    got = [int(x) for x in sel[i][:nsel[i]]]
+                    assert got == want and (sel[i][nsel[i]:] == -1).all(), f"sim={sim} d={d} Lc={Lc} row {i}: {got} != {want}"
