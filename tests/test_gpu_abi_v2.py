@@ -298,6 +298,26 @@ def test_shard_group_on_two_devices(pkg, pyoracle):
     [s.close() for s in shards]
 
 
+def test_rccl_gather_executes_with_one_shard(pkg, pyoracle):
+    """One-GPU boxes cannot run the shard group's RCCL gather between devices; a group of ONE shard can still take that path:
+    librccl.so is opened, `ncclCommInitAll` builds a one-rank communicator, `ncclGroupStart / ncclAllGather / ncclGroupEnd` run on
+    the shard's stream and the merge reads the gathered buffer — every RCCL entry point the library resolves has then executed."""
+    b, bl, dg = pkg.binding, pkg.builder, pkg.datagen
+    n, d, k, rk = 5000, 64, 10, 60
+    base = dg.splitmix_uniform(42, n, d)
+    q = dg.splitmix_uniform(43, 64, d)
+    ix = bl.build_index_cpu(base, 0, R=32, L=60, pq_M=32, ord2doc=np.arange(n, dtype=np.int32) + 7, max_doc=n + 7)
+    shard = b.GpuIndex(ix, flags=b.DESC_FUSED_ADC)
+    want = pyoracle.Oracle(b, ix).search_batch(q, k, rk)
+    grp = b.ShardGroup([shard])
+    for gather in (0, 1, 1, 0):
+        grp.set_option("gather", gather)
+        got = grp.search_batch(q, k, rk)
+        assert np.array_equal(got.docs, want.docs) and np.array_equal(got.scores.view(np.uint32), want.scores.view(np.uint32)), gather
+    grp.close()
+    shard.close()
+
+
 def test_rccl_gather_is_refused_when_shards_share_a_device(pkg):
     b, bl, dg = pkg.binding, pkg.builder, pkg.datagen
     base = dg.splitmix_uniform(1, 500, 16)

@@ -93,3 +93,43 @@ def test_two_rank_hip_engine_sharded_search_equals_oracle_merge(tmp_path, pkg, p
     od, os_ = pyoracle.merge_topk(pkg.binding, gd, gs, k)
     assert np.array_equal(od, r[0]["docs"]) and np.array_equal(os_.view(np.uint32), r[0]["scores"].view(np.uint32))
     assert (r[0]["ldocs"] < n_total // 2).all() and (r[1]["ldocs"] >= n_total // 2).all()
+
+
+def _rccl_one_rank_worker(rank, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as graft
+    graft.load_package()
+    sh = importlib.import_module("opensearch_jvector_amd.sharding")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)   # exactly bench.py's call
+    g = torch.Generator(device="cpu").manual_seed(5)
+    docs = torch.randint(0, 1 << 30, (96, 10), generator=g, dtype=torch.int32).to(dev)
+    scores = torch.randn((96, 10), generator=g).to(dev)
+    gd, gs = sh.gather_topk(dist, torch, docs, scores, 1)                        # all_gather_into_tensor on RCCL
+    tmax = torch.tensor([1.25], device=dev, dtype=torch.float64)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)                                   # bench.py's max-over-ranks timing
+    lst = [torch.empty_like(docs)]
+    dist.all_gather(lst, docs)                                                    # bench.py's ground-truth gather
+    dist.barrier()
+    torch.cuda.synchronize()
+    np.savez(os.path.join(out_dir, "rccl1.npz"), gd=gd.cpu().numpy(), gs=gs.cpu().numpy(), docs=docs.cpu().numpy(),
+             scores=scores.cpu().numpy(), tmax=tmax.cpu().numpy(), lst=lst[0].cpu().numpy(), backend=np.array([dist.get_backend()]))
+    dist.destroy_process_group()
+
+
+def test_rccl_backend_executes_with_one_rank(tmp_path):
+    """The boxes this repo is built on have ONE GPU, so no N > 1 RCCL run exists.  This runs the same torch.distributed calls
+    bench.py makes (`init_process_group("nccl", device_id=…)`, `all_gather_into_tensor` of the pair buffer, `all_gather`, `all_reduce(MAX)`,
+    `barrier`) on a one-rank RCCL communicator: librccl loads, the communicator comes up on this image and the calls execute."""
+    import torch.multiprocessing as mp
+    mp.spawn(_rccl_one_rank_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    r = np.load(tmp_path / "rccl1.npz")
+    assert str(r["backend"][0]) == "nccl"
+    assert np.array_equal(r["gd"], r["docs"]) and np.array_equal(r["gs"].view(np.uint32), r["scores"].view(np.uint32))
+    assert np.array_equal(r["lst"], r["docs"]) and float(r["tmax"][0]) == 1.25
