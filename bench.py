@@ -392,6 +392,36 @@ class Engine:
         return dict(elapsed=elapsed, qps=steps * B / elapsed, kernel_avg_ms=kernel_avg_ms, visited=st[0], reranked=st[1],
                     expanded=st[2], total_queries=steps * B, big_path_last_step=big)
 
+    def timed_in_flight(self, rk, steps, streams):
+        """small-batch workloads (c5): `streams` batches of B queries in flight at once — successive batches of a server arrive
+        while the previous ones are still being answered; every stream is an independent caller with its own outputs.  A
+        report next to `value` (which stays one batch at a time), never `value` itself."""
+        torch, B, k, dev = self.torch, self.B, self.k, self.device
+        nq_pool = self.queries.shape[0]
+        batches = [self.queries[i * B:(i + 1) * B] for i in range(nq_pool // B)]
+        ss = [torch.cuda.Stream(device=dev) for _ in range(streams)]
+        outs = [[torch.empty((B, k), dtype=torch.int32, device=dev), torch.empty((B, k), dtype=torch.int32, device=dev),
+                 torch.empty((B, k), dtype=torch.float32, device=dev), torch.empty((B,), dtype=torch.int32, device=dev),
+                 torch.empty((B, 4), dtype=torch.int32, device=dev), torch.zeros((B,), dtype=torch.int32, device=dev)] for _ in range(streams)]
+        bad = [torch.zeros((1,), dtype=torch.int64, device=dev) for _ in range(streams)]
+
+        def go(n_steps):
+            for s_ in range(n_steps):
+                for i in range(streams):
+                    q = batches[(s_ * streams + i) % len(batches)]
+                    self.index.search_batch_device(q.data_ptr(), B, k, rk, *[t.data_ptr() for t in outs[i]], stream=ss[i].cuda_stream)
+                    with torch.cuda.stream(ss[i]):
+                        bad[i] += ((outs[i][5] & JV_FLAG_FAILED) != 0).sum() + (outs[i][5] < 0).sum()
+        go(2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        go(steps)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if sum(int(b_.item()) for b_ in bad):
+            raise SystemExit("bench: queries of the in-flight leg were flagged FAILED/OVERFLOW (results invalid)")
+        return dict(batches_in_flight=streams, qps=round(steps * streams * B / el, 1), ms_per_batch=round(el * 1e3 / steps, 3))
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -613,6 +643,9 @@ def main():
         except Exception as e:  # pragma: no cover
             filtered_rows = f"unavailable: {e!r}"
 
+    in_flight = None
+    if not args.profile_mode and world == 1 and eng.B <= 1024:
+        in_flight = [eng.timed_in_flight(rk, max(args.steps, 10), S) for S in (int(x) for x in os.environ.get("JV_BENCH_IN_FLIGHT", "1,2,4,8").split(","))]
     # the kernel that carries the step (csrc/jv_abi.cpp enqueue_batch): the persistent jv_search_pqp_kernel for pools beyond
     # 256 entries and wherever its register-table variant applies (PQ-32, not cosine, more than 4 x CUs queries per launch),
     # else round 1's jv_search_pqf_kernel; exact indexes run on jv_search_lds_kernel
@@ -658,6 +691,7 @@ def main():
         "p50_latency_ms": (None if p50 is None else round(p50, 4)),
         "host_api_qps_pcie_inclusive": pcie_qps,
         "single_query_api": caller_rows,
+        "batches_in_flight": in_flight,
         "single_query_api_filtered": filtered_rows,
         "per_query": {"visited": round(t["visited"] / total_queries, 1), "expanded": round(t["expanded"] / total_queries, 1),
                       "reranked": round(t["reranked"] / total_queries, 1),

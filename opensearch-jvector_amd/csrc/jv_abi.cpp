@@ -115,13 +115,14 @@ int fail(int code, const char* fmt, ...) {
 //   big_blocks / big_cand_cap / big_budget_mb   HBM-scratch rung: resident blocks (0 = as many as fit the budget), candidate slots
 //   combine / combine_leaders / combine_max_batch   group commit of concurrent jv_search calls
 //   max_contexts                         cap of per-index launch contexts (callers beyond it wait)
+//   async_contexts                       device-pointer API: contexts (scratch + counters) its calls on different streams may use side by side
 //   filter_cache                         device-resident doc-filter bitsets kept per index (0 = off)
 //   serve / serve_wgs_per_cu / serve_idle_ms   device-resident query servers for one-query calls — one grid for unfiltered calls, one for calls with a doc filter (resident workgroups per CU, idle time before they leave)
 //   lazy_big_rung                        host-pointer calls enqueue the HBM-scratch rung only when a row came back flagged (it serialises batches otherwise)
 //   direct_completion                    combined one-query calls: rows land in pinned memory, every caller is woken by its own query's completion word
 //   lutr_min_queries                     launches with more queries keep the PQ look-up table in registers (-1 = 4 per CU)
 //   dbg_ptr                              diagnostic build only
-enum OptId { OPT_LDS_VISITED_SLOTS, OPT_LDS_CANDIDATES, OPT_FORCE_BIG, OPT_FORCE_GENERAL, OPT_NO_ESCALATION, OPT_DBG_PTR, OPT_NO_PQF, OPT_NO_PQP, OPT_NO_LUTR, OPT_LUTR_MIN_QUERIES, OPT_PQP_BLOCKS_PER_CU, OPT_NO_PQW, OPT_PQW_MIN_QUERIES, OPT_PQW_LAT_QUERIES, OPT_PQF_ONLY, OPT_SPILL_TABLES, OPT_SPILL_SLOTS, OPT_BIG_BLOCKS, OPT_BIG_CAND_CAP, OPT_BIG_BUDGET_MB, OPT_COMBINE, OPT_COMBINE_LEADERS, OPT_COMBINE_MAX_BATCH, OPT_MAX_CONTEXTS, OPT_FILTER_CACHE, OPT_DIRECT_COMPLETION, OPT_LAZY_BIG, OPT_SERVE, OPT_SERVE_WGS_PER_CU, OPT_SERVE_IDLE_MS, OPT_COUNT };
+enum OptId { OPT_LDS_VISITED_SLOTS, OPT_LDS_CANDIDATES, OPT_FORCE_BIG, OPT_FORCE_GENERAL, OPT_NO_ESCALATION, OPT_DBG_PTR, OPT_NO_PQF, OPT_NO_PQP, OPT_NO_LUTR, OPT_LUTR_MIN_QUERIES, OPT_PQP_BLOCKS_PER_CU, OPT_NO_PQW, OPT_PQW_MIN_QUERIES, OPT_PQW_LAT_QUERIES, OPT_PQF_ONLY, OPT_SPILL_TABLES, OPT_SPILL_SLOTS, OPT_BIG_BLOCKS, OPT_BIG_CAND_CAP, OPT_BIG_BUDGET_MB, OPT_COMBINE, OPT_COMBINE_LEADERS, OPT_COMBINE_MAX_BATCH, OPT_MAX_CONTEXTS, OPT_FILTER_CACHE, OPT_DIRECT_COMPLETION, OPT_LAZY_BIG, OPT_SERVE, OPT_SERVE_WGS_PER_CU, OPT_SERVE_IDLE_MS, OPT_ASYNC_CONTEXTS, OPT_COUNT };
 struct OptName { const char* name; int64_t def; };
 const OptName kOptNames[OPT_COUNT] = {
     {"lds_visited_slots", 0},
@@ -154,6 +155,7 @@ const OptName kOptNames[OPT_COUNT] = {
     {"serve", 1},
     {"serve_wgs_per_cu", 2},
     {"serve_idle_ms", 100},
+    {"async_contexts", 4},
 };
 struct Opts {
     std::atomic<int64_t> v[OPT_COUNT];
@@ -181,6 +183,7 @@ struct Ctx {
     hipStream_t stream = nullptr;
     hipEvent_t last_use = nullptr;
     hipStream_t last_stream = nullptr;
+    uint64_t last_clock = 0;  // (device-pointer API: least-recently-used choice among its contexts)
     // device staging for the host-pointer API
     float* d_queries = nullptr;
     size_t queries_cap = 0;  // floats
@@ -298,7 +301,9 @@ struct jv_index {
     std::vector<FilterEntry> filters;  // device-side doc-filter cache
     uint64_t filter_clock = 0;
     int64_t filter_hits = 0, filter_misses = 0;
-    Ctx* async_ctx = nullptr;
+    Ctx* async_ctx = nullptr;           // the device-pointer API's first context ...
+    std::vector<Ctx*> async_ctxs;       // ... and the others: calls on DIFFERENT streams run side by side, each in a context of its own
+    uint64_t async_clock = 0;
     std::mutex async_mu;
     // launches per kernel family since creation (jv_index_get_counter): which rung served a call is observable
     std::atomic<int64_t> launches[8] = {};
@@ -388,7 +393,7 @@ int ctx_acquire(jv_index* ix, Ctx** out) {
             return JV_OK;
         }
         const size_t cap = (size_t)std::max<int64_t>(1, OPT(ix, OPT_MAX_CONTEXTS));
-        if (ix->all_ctx.size() < cap + 1) return ctx_create(ix, out);  // (+1: the device-pointer API's own context)
+        if (ix->all_ctx.size() < cap + std::max<size_t>(1, ix->async_ctxs.size())) return ctx_create(ix, out);  // (+ the device-pointer API's own contexts)
         ix->ctx_cv.wait(lk);
     }
 }
@@ -1749,6 +1754,7 @@ int jv_index_create(const jv_index_desc* desc, jv_index** out) {
             if (hipGetDeviceProperties(&prop, desc->device) == hipSuccess && prop.multiProcessorCount > 0) ix->cu_count = prop.multiProcessorCount;
         }
         TRY(ctx_create(ix, &ix->async_ctx));
+        ix->async_ctxs.push_back(ix->async_ctx);
     }
     ix->info.n = n;
     ix->info.d = d;
@@ -1826,8 +1832,33 @@ static int search_batch_device_impl(jv_index* index, const float* d_queries, int
     if (!d_out_nodes || !d_out_scores || !d_out_count || !d_out_stats) return fail(JV_EINVAL, "output pointer is NULL");
     HIPCHK(hipSetDevice(index->device));
     std::lock_guard<std::mutex> lk(index->async_mu);
+    // Which context: the one this stream used last (its work is already ordered behind that use); else one whose last use has
+    // completed; else a new one below the cap (async_contexts: batches on different streams then run side by side — a server that
+    // receives the next batch of 256 queries while the previous one is being answered); else the least recently used one, ordered
+    // behind its last use.
     Ctx* c = index->async_ctx;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    if (hip_stream) {
+        c = nullptr;
+        for (Ctx* x : index->async_ctxs)
+            if (x->last_stream == s) { c = x; break; }
+        if (!c)
+            for (Ctx* x : index->async_ctxs)
+                if (!x->last_stream || hipEventQuery(x->last_use) == hipSuccess) { c = x; break; }
+        (void)hipGetLastError();  // (hipErrorNotReady of the queries above is not an error)
+        if (!c && (int64_t)index->async_ctxs.size() < std::max<int64_t>(1, OPT(index, OPT_ASYNC_CONTEXTS))) {
+            std::lock_guard<std::mutex> lk2(index->mu);
+            rc = ctx_create(index, &c);
+            if (rc != JV_OK) return rc;
+            index->async_ctxs.push_back(c);
+        }
+        if (!c) {
+            c = index->async_ctxs[0];
+            for (Ctx* x : index->async_ctxs)
+                if (x->last_clock < c->last_clock) c = x;
+        }
+    }
+    c->last_clock = ++index->async_clock;
     if (c->last_stream && c->last_stream != s) HIPCHK(hipStreamWaitEvent(s, c->last_use, 0));
     // whatever happens below (also a failure after a partial enqueue), the next call on another stream must be ordered
     // behind the kernels that may already use this context's counters and scratch

@@ -332,3 +332,40 @@ def test_rccl_gather_is_refused_when_shards_share_a_device(pkg):
     grp.close()
     s1.close()
     s2.close()
+
+
+def test_device_batches_on_several_streams_use_their_own_contexts(pkg, pyoracle):
+    """jv_search_batch_device from several streams at once (a server that receives the next batch of 256 queries while the previous
+    ones are being answered: BASELINE config 5's shape, pipelined): every stream's calls run in a launch context of their own
+    (`async_contexts`, default 4; more streams than contexts share, ordered behind the context's last use).  Every batch equals
+    the oracle — ids, score bits, counters — whatever ran beside it."""
+    import torch
+    b, bl, dg = pkg.binding, pkg.builder, pkg.datagen
+    n, d, k, rk, B, S, rounds = 20000, 64, 10, 120, 256, 6, 3
+    base = dg.splitmix_uniform(42, n, d)
+    ix = bl.build_index_cpu(base, 0, R=32, L=60, pq_M=32)
+    gpu = b.GpuIndex(ix, flags=b.DESC_FUSED_ADC)
+    dev = torch.device("cuda", 0)
+    q = dg.splitmix_uniform(43, B * S * rounds, d)
+    want = pyoracle.Oracle(b, ix).search_batch(q, k, rk)
+    tq = torch.from_numpy(q).to(dev)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+    outs = [[(torch.full((B, k), -7, dtype=torch.int32, device=dev), torch.full((B, k), -7, dtype=torch.int32, device=dev),
+              torch.zeros((B, k), dtype=torch.float32, device=dev), torch.zeros((B,), dtype=torch.int32, device=dev),
+              torch.zeros((B, 4), dtype=torch.int32, device=dev), torch.zeros((B,), dtype=torch.int32, device=dev)) for _ in range(rounds)] for _ in range(S)]
+    torch.cuda.synchronize()
+    for r in range(rounds):
+        for s_ in range(S):
+            o = outs[s_][r]
+            lo = (r * S + s_) * B
+            gpu.search_batch_device(tq[lo:lo + B].data_ptr(), B, k, rk, *[t.data_ptr() for t in o], stream=streams[s_].cuda_stream)
+    torch.cuda.synchronize()
+    for r in range(rounds):
+        for s_ in range(S):
+            o = outs[s_][r]
+            lo = (r * S + s_) * B
+            assert np.array_equal(o[0].cpu().numpy(), want.nodes[lo:lo + B]), (r, s_)
+            assert np.array_equal(o[2].cpu().numpy().view(np.uint32), want.scores[lo:lo + B].view(np.uint32)), (r, s_)
+            assert np.array_equal(o[4].cpu().numpy(), want.stats[lo:lo + B]), (r, s_)
+            assert (o[5].cpu().numpy() >= 0).all()
+    gpu.close()
