@@ -202,7 +202,9 @@ int jv_search_batch(jv_index* index, const float* queries, int32_t nq, int32_t t
  * With a caller stream the call returns after enqueueing; results are valid after the caller
  * synchronises that stream.  The whole ladder (on-chip kernels, retry, HBM-scratch rung) is enqueued without host
  * round trips; d_out_flags (strongly recommended) receives per query JV_QFLAG_* in the low bits and 0x40000000 if the
- * query exhausted even the HBM scratch (its row is then empty) — without d_out_flags such a failure is invisible. */
+ * query exhausted even the HBM scratch (its row is then empty) — without d_out_flags such a failure is invisible.
+ * Calls on DIFFERENT streams run side by side, each in a launch context (scratch, counters) of its own, up to the index's
+ * "async_contexts" option (default 4); further streams share a context and are ordered behind its previous use. */
 int jv_search_batch_device(jv_index* index, const float* d_queries, int32_t nq, int32_t topK,
                            int32_t rerankK, float threshold, float rerankFloor,
                            const uint64_t* d_accept_doc_words, int64_t accept_num_docs,
@@ -243,7 +245,8 @@ int jv_index_get_counter(const jv_index* index, const char* name, int64_t* out);
 /* Tunables are PER INDEX: jv_index_set_option changes one handle; jv_set_option only changes the defaults that indexes
  * created afterwards start from (nothing process-wide is read at call time).  Names: "lds_visited_slots",
  * "lds_candidates", "force_big_path", "force_general_path", "big_blocks", "big_cand_cap", "big_budget_mb",
- * "spill_tables", "spill_slots", "combine", "combine_leaders", "combine_max_batch", "max_contexts", "filter_cache"
+ * "spill_tables", "spill_slots", "combine", "combine_leaders", "combine_max_batch", "max_contexts", "async_contexts", "filter_cache",
+ * "serve", "serve_wgs_per_cu", "serve_idle_ms", "direct_completion", "lazy_big_rung"
  * (+ diagnostics: "no_escalation", "no_pqf", "no_pqp", "no_pqw", "pqw_min_queries", "no_lutr", "lutr_min_queries",
  * "pqf_only", "dbg_ptr").
  * JV_EINVAL for unknown names. */
