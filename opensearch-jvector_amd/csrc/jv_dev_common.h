@@ -71,6 +71,15 @@ __device__ __forceinline__ float row16_tree_sum(float v) {
     return v;
 }
 
+// sum of an int over the 64 lanes, wave-uniform result: four DPP steps inside each row of 16, then the four row sums by readlane
+__device__ __forceinline__ int jv_wave_sum_int(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+}
+
 __device__ __forceinline__ void wave_argmax(int64_t& k, int& idx) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {

@@ -67,6 +67,7 @@ __device__ __forceinline__ int64_t pqw_key_min() {
     return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint64_t)(uint32_t)lo);
 }
 
+typedef int i32x16 __attribute__((ext_vector_type(16)));
 // ctrl words (ints) behind the exchange area
 enum { PQW_C = 0, PQW_C2 = 1, PQW_WHY = 2, PQW_NP = 3, PQW_NEXP = 4, PQW_EXPANDED = 5, PQW_QI = 6, PQW_AGAIN = 7, PQW_C3 = 12, PQW_C4 = 13, PQW_CNT = 48 /* [W <= 16]: behind the diagnostic build's accumulators */ };
 
@@ -951,30 +952,46 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
         const int vlimit_w = vlimit / W;  // fresh entries one wave may add per class
         int parts = 1;
         while (parts < 64 && (long long)nexp * 7 > (long long)vlimit * parts * 2) parts <<= 1;
-        const int rows_per = JV_WAVE / R;
-        constexpr int VB = 8;             // adjacency batches per group
-        const int G = rows_per * VB;      // log entries per group: 16 at R = 32 (divides 64: one log chunk)
+        constexpr int VB = 8;             // neighbour ids per lane and group
+        // Adjacency rows as 16-byte pieces where the shape allows it (R % 4 == 0, rows 16-byte aligned): R / 4 lanes per row,
+        // 64 / (R / 4) rows per load instruction, two instructions per group (R = 32: 16 log entries, one bpermute + one load
+        // per 8 rows instead of one per 2); else one id per lane and load, VB loads per group.
+        const int lpr4 = max(1, R >> 2);
+        const bool vec = (R & 3) == 0 && (64 % (2 * (JV_WAVE / lpr4))) == 0 && (((uintptr_t)ix.adj) & 15) == 0;
+        const int lpr = vec ? lpr4 : R;                  // lanes per adjacency row
+        const int rpl = JV_WAVE / lpr;                   // rows per load instruction
+        const int G = vec ? rpl * 2 : rpl * VB;          // log entries per group (divides 64: a group sits in one log chunk)
+        const int lrow = lane / lpr, lcol = (lane % lpr) * (vec ? 4 : 1);
+        const bool lane_ok = lane < rpl * lpr;
         bool again = true;
         while (again && why == 0) {
             again = false;
             visited = 0;
+            int plog = 0;
+            while ((1 << plog) < parts) plog++;
+            const int pshift = vshift - plog;            // the class = the hash bits right below the slot index
+            const uint32_t pmask = (uint32_t)parts - 1u;
             for (int p = 0; p < parts && !again; p++) {
                 __syncthreads();
                 for (int i = threadIdx.x; i < vslots; i += JV_WAVE * W) vh[i] = HASH_EMPTY;
                 if (threadIdx.x == 0) ctrl[PQW_AGAIN] = 0;
                 __syncthreads();
-                auto part_of = [&](uint32_t node) -> int { return (int)(((node * 0x85EBCA6Bu) >> 20) & (uint32_t)(parts - 1)); };
-                if (threadIdx.x == 0 && part_of((uint32_t)ix.entry) == p) visited_insert_lds(vh, vmask, vshift, (uint32_t)ix.entry);
+                if (threadIdx.x == 0 && ((((uint32_t)ix.entry * 0x9E3779B1u) >> pshift) & pmask) == (uint32_t)p)
+                    visited_insert_lds(vh, vmask, vshift, (uint32_t)ix.entry);
                 __syncthreads();
-                int cnt = 0;
+                int cntl = 0;  // fresh entries, counted per lane
                 bool over = false;
-                // The log is pulled into registers 2 048 entries at a time; this wave takes every W-th group of rows; two
-                // groups are kept in flight ahead of the one that probes.  Loads are unconditional with clamped indices.
-                for (int blk0 = 0; blk0 < nexp && !over; blk0 += 2048) {
-                    const int nblk = min(2048, nexp - blk0);
-                    i32x32 logv;
+                // The log is pulled into registers 1 024 entries at a time; this wave takes every W-th group of rows.  NPF groups
+                // are in flight, each in registers of its own (the loop is unrolled NPF times: a copy from one group's registers
+                // to the next waits for the YOUNGEST load, and the pass then ran one memory round trip per group; measured
+                // NPF = 2 / 3 / 4: 3.12 / 3.10 / 2.81 M QPS at rerankK 160, 566 / 568 / 567 k at 1 200).  Loads are unconditional
+                // with clamped indices.
+                constexpr int NPF = 2;
+                for (int blk0 = 0; blk0 < nexp && !over; blk0 += 1024) {
+                    const int nblk = min(1024, nexp - blk0);
+                    i32x16 logv;
 #pragma unroll
-                    for (int g = 0; g < 32; g++) {
+                    for (int g = 0; g < 16; g++) {
                         logv[g] = 0;
                         if (g * 64 < nblk)
                             logv[g] = __hip_atomic_load(&explog[blk0 + min(g * 64 + lane, nblk - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -983,59 +1000,92 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
                     auto load_group = [&](int e0, int (&dst)[VB]) {
                         const int e0c = min(e0, e_last);
                         const int cur = logv[__builtin_amdgcn_readfirstlane(e0c >> 6)];
+                        if (vec) {
 #pragma unroll
-                        for (int u = 0; u < VB; u++) {
-                            const int e = min(e0c + u * rows_per + lane / R, nblk - 1);
-                            const int node = __builtin_amdgcn_ds_bpermute((e & 63) << 2, cur);
-                            dst[u] = ix.adj[(size_t)node * R + (lane % R)];
+                            for (int h = 0; h < 2; h++) {
+                                const int e = min(e0c + h * rpl + lrow, nblk - 1);
+                                const int node = __builtin_amdgcn_ds_bpermute((e & 63) << 2, cur);
+                                const u32x4 v = *(const u32x4*)(ix.adj + (size_t)node * R + lcol);
+                                dst[4 * h] = (int)v.x, dst[4 * h + 1] = (int)v.y, dst[4 * h + 2] = (int)v.z, dst[4 * h + 3] = (int)v.w;
+                            }
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < VB; u++) {
+                                const int e = min(e0c + u * rpl + lrow, nblk - 1);
+                                const int node = __builtin_amdgcn_ds_bpermute((e & 63) << 2, cur);
+                                dst[u] = ix.adj[(size_t)node * R + lcol];
+                            }
                         }
                     };
-                    int q0[VB], q1[VB];
-                    const int step = G * W;
-                    load_group(wv * G, q0);
-                    load_group(wv * G + step, q1);
-                    for (int e0 = wv * G; e0 < nblk; e0 += step) {
-                        int nb[VB];
-#pragma unroll
-                        for (int u = 0; u < VB; u++) {
-                            const int e = e0 + u * rows_per + lane / R;
-                            nb[u] = (e < nblk && lane < rows_per * R) ? q0[u] : -1;
-                            if (nb[u] >= 0 && parts > 1 && part_of((uint32_t)nb[u]) != p) nb[u] = -1;
-                            q0[u] = q1[u];
-                        }
-                        load_group(e0 + 2 * step, q1);
-                        int pending = 0;
-#pragma unroll
-                        for (int u = 0; u < VB; u++) pending += __popcll(__ballot(nb[u] >= 0));
-                        if (cnt + pending > vlimit_w) {
-                            over = true;
-                            break;
-                        }
+                    // one group's ids into the set; false when the table's fill limit would be passed
+                    auto probe_group = [&](const int (&q)[VB], int e0) -> bool {
                         uint32_t hh[VB];
                         bool pend[VB];
+                        int pl = 0;
+                        {
+                            // which of this lane's ids exist: entry e0 + (u / 4 or u) * rpl + lrow of the block
+                            const bool ok_a = lane_ok && e0 + lrow < nblk, ok_b = lane_ok && e0 + rpl + lrow < nblk;
 #pragma unroll
-                        for (int u = 0; u < VB; u++) {
-                            pend[u] = nb[u] >= 0;
-                            hh[u] = ((uint32_t)nb[u] * 0x9E3779B1u) >> vshift;
+                            for (int u = 0; u < VB; u++) {
+                                const bool ok = vec ? (u < 4 ? ok_a : ok_b) : (lane_ok && e0 + u * rpl + lrow < nblk);
+                                const uint32_t prod = (uint32_t)q[u] * 0x9E3779B1u;   // one product: slot index on top, class below
+                                hh[u] = prod >> vshift;
+                                pend[u] = ok && q[u] >= 0 && ((prod >> pshift) & pmask) == (uint32_t)p;   // (rows are padded with -1)
+                                pl += pend[u] ? 1 : 0;
+                            }
                         }
-                        for (;;) {
+                        // (fresh entries so far + the ids about to probe, one sum over the wave)
+                        if (jv_wave_sum_int(cntl + pl) > vlimit_w) return false;
+                        // Round one probes all VB batches (the compare-and-swaps overlap); most lanes are done after it — nine of
+                        // ten neighbours are re-encounters that sit at or next to their home slot — and the later rounds only
+                        // touch the batches that still have a lane on its way down a probe chain.
+                        uint32_t live = 0;
+                        {
                             uint32_t oldv[VB];
 #pragma unroll
-                            for (int u = 0; u < VB; u++) oldv[u] = pend[u] ? atomicCAS(&vh[hh[u]], HASH_EMPTY, (uint32_t)nb[u]) : 0u;
-                            bool more = false;
+                            for (int u = 0; u < VB; u++) oldv[u] = pend[u] ? atomicCAS(&vh[hh[u]], HASH_EMPTY, (uint32_t)q[u]) : 0u;
 #pragma unroll
                             for (int u = 0; u < VB; u++) {
                                 const bool fresh = pend[u] && oldv[u] == HASH_EMPTY;
-                                cnt += __popcll(__ballot(fresh));
-                                if (pend[u]) {
-                                    if (fresh || oldv[u] == (uint32_t)nb[u]) pend[u] = false;
-                                    else hh[u] = (hh[u] + 1) & vmask, more = true;
-                                }
+                                cntl += fresh ? 1 : 0;
+                                pend[u] = pend[u] && !fresh && oldv[u] != (uint32_t)q[u];
+                                hh[u] = (hh[u] + 1) & vmask;
+                                if (__any(pend[u])) live |= 1u << u;
                             }
-                            if (!__any(more)) break;
+                        }
+                        while (live) {
+                            uint32_t oldv[VB];
+#pragma unroll
+                            for (int u = 0; u < VB; u++)
+                                if (live & (1u << u)) oldv[u] = pend[u] ? atomicCAS(&vh[hh[u]], HASH_EMPTY, (uint32_t)q[u]) : 0u;
+#pragma unroll
+                            for (int u = 0; u < VB; u++)
+                                if (live & (1u << u)) {
+                                    const bool fresh = pend[u] && oldv[u] == HASH_EMPTY;
+                                    cntl += fresh ? 1 : 0;
+                                    pend[u] = pend[u] && !fresh && oldv[u] != (uint32_t)q[u];
+                                    hh[u] = (hh[u] + 1) & vmask;
+                                    if (!__any(pend[u])) live &= ~(1u << u);
+                                }
+                        }
+                        return true;
+                    };
+                    int qq[NPF][VB];
+                    const int step = G * W;
+#pragma unroll
+                    for (int k = 0; k < NPF; k++) load_group(wv * G + k * step, qq[k]);
+                    for (int e0 = wv * G; e0 < nblk && !over; e0 += NPF * step) {
+#pragma unroll
+                        for (int k = 0; k < NPF; k++) {
+                            const int ek = e0 + k * step;
+                            if (ek < nblk && !over) {
+                                if (!probe_group(qq[k], ek)) over = true;
+                                else load_group(ek + NPF * step, qq[k]);
+                            }
                         }
                     }
                 }
+                const int cnt = jv_wave_sum_int(cntl);
                 if (over && lane == 0) ctrl[PQW_AGAIN] = 1;
                 visited += cnt;
                 __syncthreads();

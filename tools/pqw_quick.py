@@ -2,7 +2,7 @@
 """Development check of the several-waves-per-query kernel (jv_kernels_pqw.hip) against the one-wave kernel on a
 C3-shaped index: identical ids / score bits / counters / flags, and the throughput of both.
 env: N (docs, default 2M), B (queries per launch), RKS (comma list), DIST, STAMPS=1 (diagnostic build + phase shares),
-JV_OPT_<name>=<int> per-index options applied to both runs."""
+JV_OPT_<name>=<int> per-index options applied to both runs, JV_LIB=<path> another build of libjvgpu.so."""
 import importlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -13,6 +13,9 @@ b = importlib.import_module("opensearch_jvector_amd.binding")
 stamps = os.environ.get("STAMPS", "0") == "1"
 if stamps:
     b.LIB_PATH = os.path.join(os.path.dirname(b.LIB_PATH), "libjvgpu_stamps.so")
+    b.load_library(b.LIB_PATH)
+elif os.environ.get("JV_LIB"):  # an experimental build of the library (A/B runs)
+    b.LIB_PATH = os.path.abspath(os.environ["JV_LIB"])
     b.load_library(b.LIB_PATH)
 gb = importlib.import_module("opensearch_jvector_amd.builder_gpu")
 import bench
