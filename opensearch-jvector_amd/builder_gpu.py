@@ -161,6 +161,12 @@ def build_graph_gpu(torch, base, sim, R=32, L=100, alpha=1.2, overflow=1.2, devi
         o_flags = torch.empty((max_batch,), dtype=torch.int32, device=dev)
 
         def search_fn(q, B):
+            # torch's default stream has handle 0, and jv_search_batch_device reads a NULL stream as "the library's own stream,
+            # synchronous": NOT ordered behind the gather that is still writing q on torch's stream.  (Round 4: at d = 1 536 the
+            # 84 MB gather of a 13 655-row batch lost that race now and then — searches with half-written queries, builds that
+            # differed from run to run, C4's recall at rerankK 1 200 anywhere between 0.940 and 0.952.)
+            if stream.cuda_stream == 0:
+                stream.synchronize()
             index.search_batch_device(q.data_ptr(), B, L, L, o_nodes.data_ptr(), 0, o_scores.data_ptr(),
                                       o_count.data_ptr(), o_stats.data_ptr(), o_flags.data_ptr(),
                                       stream=stream.cuda_stream)

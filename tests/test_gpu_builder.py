@@ -61,6 +61,22 @@ def test_gpu_builds_are_reproducible(pkg):
     assert e1 == e2 and torch.equal(adj1, adj2)
 
 
+def test_wide_rows_build_reproducibly_on_the_default_stream(pkg):
+    """Round 4 regression: the batched builder gathers a batch's query rows on torch's current stream and searches them through
+    jv_search_batch_device.  On torch's DEFAULT stream the handle is 0, which that call reads as "the library's own stream" — not
+    ordered behind the gather.  With 1 536-d rows (a 13 655-row batch is an 84 MB gather) searches started on half-written queries
+    now and then: every build of C4's shard was a different graph (recall@10 at rerankK 1 200 between 0.940 and 0.952).  Three
+    builds of a 60 000 x 1 536 corpus must be the same graph, and its searches must score against the real query."""
+    torch, gb = _gb()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    base = torch.randn((60000, 1536), generator=g, device=dev, dtype=torch.float32)
+    outs = [gb.build_graph_gpu(torch, base, 0, R=32, L=100, verbose=False) for _ in range(3)]
+    assert outs[0][1] == outs[1][1] == outs[2][1]
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][0], outs[2][0])
+
+
 @pytest.mark.parametrize("d,M,sim", [(96, 16, 0), (100, 7, 1), (768, 8, 0)])
 def test_pq_training_is_lloyd_and_improves_on_its_start(pkg, d, M, sim):
     """jvb_pq_train_device (csrc/jv_build_kernels.hip): every centroid is the mean of the sample rows the ENCODER assigns to
