@@ -198,7 +198,8 @@ int jv_search_batch(jv_index* index, const float* queries, int32_t nq, int32_t t
                     int32_t* out_count, int32_t* out_stats);
 
 /* Same, but every pointer is a DEVICE pointer on the index's device and the work is enqueued on
- * `hip_stream` (a hipStream_t passed as void*; NULL = the library's own stream, synchronous).
+ * `hip_stream` (a hipStream_t passed as void*; NULL = the library's own stream, synchronous, ordered behind what the legacy
+ * default stream — handle 0 — has in flight at call time, NOT behind other streams' work).
  * With a caller stream the call returns after enqueueing; results are valid after the caller
  * synchronises that stream.  The whole ladder (on-chip kernels, retry, HBM-scratch rung) is enqueued without host
  * round trips; d_out_flags (strongly recommended) receives per query JV_QFLAG_* in the low bits and 0x40000000 if the

@@ -205,6 +205,7 @@ struct Ctx {
     uint8_t* h_direct = nullptr;
     size_t direct_cap = 0;
     hipEvent_t ev_direct = nullptr;
+    hipEvent_t ev_null = nullptr;  // device-pointer API without a caller stream: what the legacy default stream had in flight at call time
     int32_t* h_mark = nullptr;   // pinned: stream marker written by jv_mark_kernel, polled by the host (see wait_mark)
     int32_t mark_seq = 0;
     int32_t* work_counter = nullptr;  // 16 words: [0] big-path dequeue, [1] spill-table allocator, [2..7] rung counters, [8..15] filtered pool rungs
@@ -375,6 +376,7 @@ void ctx_destroy(Ctx* c) {
     jv_host_free(c->h_query);
     jv_host_free(c->h_direct);
     if (c->ev_direct) hipEventDestroy(c->ev_direct);
+    if (c->ev_null) hipEventDestroy(c->ev_null);
     jv_free(c->work_counter);
     jv_free(c->spill);
     jv_free(c->pqp_log);
@@ -1860,6 +1862,15 @@ static int search_batch_device_impl(jv_index* index, const float* d_queries, int
     }
     c->last_clock = ++index->async_clock;
     if (c->last_stream && c->last_stream != s) HIPCHK(hipStreamWaitEvent(s, c->last_use, 0));
+    if (!hip_stream) {
+        // No caller stream: the library's own (non-blocking) stream.  A caller that produced the queries on the legacy default
+        // stream (handle 0 — what a CUDA-style runtime hands out as "the current stream") expects to be ordered behind that work:
+        // wait for whatever the default stream has in flight right now.  (Round 4's graph builder searched half-written query
+        // rows without this.)
+        if (!c->ev_null) HIPCHK(hipEventCreateWithFlags(&c->ev_null, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(c->ev_null, nullptr));
+        HIPCHK(hipStreamWaitEvent(s, c->ev_null, 0));
+    }
     // whatever happens below (also a failure after a partial enqueue), the next call on another stream must be ordered
     // behind the kernels that may already use this context's counters and scratch
     struct UseGuard {

@@ -369,3 +369,33 @@ def test_device_batches_on_several_streams_use_their_own_contexts(pkg, pyoracle)
             assert np.array_equal(o[4].cpu().numpy(), want.stats[lo:lo + B]), (r, s_)
             assert (o[5].cpu().numpy() >= 0).all()
     gpu.close()
+
+
+def test_null_stream_call_is_ordered_behind_the_default_stream(pkg):
+    """jv_search_batch_device without a caller stream runs on the library's own non-blocking stream.  A caller that has just
+    produced the queries on the legacy default stream (handle 0: torch's current stream unless told otherwise) must still be
+    searched with the FINISHED queries: the call waits for what the default stream has in flight.  (Round 4: the graph builder
+    handed stream handle 0 over and now and then searched half-written 1 536-d rows.)"""
+    import torch
+    b, bl, dg = pkg.binding, pkg.builder, pkg.datagen
+    n, d, k, rk, B = 4000, 1536, 10, 40, 16384
+    base = dg.splitmix_uniform(7, n, d)
+    ix = bl.build_index_cpu(base, 0, R=16, L=40)
+    gpu = b.GpuIndex(ix)
+    dev = torch.device("cuda", 0)
+    pool = torch.from_numpy(dg.splitmix_uniform(8, 20000, d)).to(dev)
+    o = [torch.empty((B, k), dtype=torch.int32, device=dev), torch.empty((B, k), dtype=torch.int32, device=dev),
+         torch.empty((B, k), dtype=torch.float32, device=dev), torch.empty((B,), dtype=torch.int32, device=dev),
+         torch.zeros((B, 4), dtype=torch.int32, device=dev), torch.empty((B,), dtype=torch.int32, device=dev)]
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    for it in range(6):
+        u = torch.randint(0, pool.shape[0], (B,), generator=g, device=dev)
+        q = pool[u].contiguous()            # a 100 MB gather on the default stream, still running when the call below is made
+        gpu.search_batch_device(q.data_ptr(), B, k, rk, *[t.data_ptr() for t in o])   # no stream: the library's own
+        got = [t.clone() for t in o[:5]]
+        torch.cuda.synchronize()
+        gpu.search_batch_device(q.data_ptr(), B, k, rk, *[t.data_ptr() for t in o])   # the same call on finished queries
+        torch.cuda.synchronize()
+        assert torch.equal(got[0], o[0]) and torch.equal(got[2], o[2]) and torch.equal(got[4], o[4]), it
+    gpu.close()
