@@ -728,7 +728,7 @@ __device__ __forceinline__ void search_one_pqp(const JvIndexDev& ix, const JvSea
                 auto part_of = [&](uint32_t node) -> int { return (int)(((node * 0x85EBCA6Bu) >> 20) & (uint32_t)(parts - 1)); };
                 if (lane == 0 && part_of((uint32_t)ix.entry) == p) visited_insert_lds(vh, vmask, vshift, (uint32_t)ix.entry);
                 __syncthreads();
-                int cnt = 0;
+                int cnt = 0, cntl = 0;  // (cntl: fresh entries of the grouped form, per lane)
                 if (R <= JV_WAVE && 64 % (rows_per * 8) == 0) {  // (a group of 8 batches must not straddle two 64-entry log chunks)
                     // The log is pulled into registers 2 048 entries at a time (coalesced loads, one latency), so a row
                     // fetch depends on ONE global load; two groups of rows are kept in flight ahead of the one that
@@ -755,51 +755,71 @@ __device__ __forceinline__ void search_one_pqp(const JvIndexDev& ix, const JvSea
                                 dst[u] = ix.adj[(size_t)node * R + (lane % R)];
                             }
                         };
-                        int q0[VB], q1[VB];
-                        load_group(0, q0);
-                        load_group(G, q1);
-                        for (int e0 = 0; e0 < nblk; e0 += G) {
+                        // one group's ids into the set; false when the table's fill limit would be passed.  (Round 4, as in
+                        // jv_pqw_body.h: fresh entries counted per lane and summed once per group, the probe rounds after the first
+                        // only for batches that still have a lane on its way down a chain, and two groups in flight in registers of
+                        // their own — the old `q0 = q1` hand-over was a copy that waits for the YOUNGEST load.)
+                        auto probe_group = [&](const int (&q)[VB], int e0) -> bool {
                             int nb[VB];
+                            uint32_t hh[VB];
+                            bool pend[VB];
+                            int pl = 0;
 #pragma unroll
                             for (int u = 0; u < VB; u++) {
                                 const int e = e0 + u * rows_per + lane / R;
-                                nb[u] = (e < nblk && lane < rows_per * R) ? q0[u] : -1;
+                                nb[u] = (e < nblk && lane < rows_per * R) ? q[u] : -1;
                                 if (nb[u] >= 0 && parts > 1 && part_of((uint32_t)nb[u]) != p) nb[u] = -1;
-                                q0[u] = q1[u];
-                            }
-                            load_group(e0 + 2 * G, q1);
-                            int pending = 0;
-#pragma unroll
-                            for (int u = 0; u < VB; u++) pending += __popcll(__ballot(nb[u] >= 0));
-                            if (cnt + pending > vlimit) {
-                                again = true;
-                                break;
-                            }
-                            uint32_t hh[VB];
-                            bool pend[VB];
-#pragma unroll
-                            for (int u = 0; u < VB; u++) {
                                 pend[u] = nb[u] >= 0;
                                 hh[u] = ((uint32_t)nb[u] * 0x9E3779B1u) >> vshift;
+                                pl += pend[u] ? 1 : 0;
                             }
-                            for (;;) {
+                            if (jv_wave_sum_int(cntl + pl) > vlimit) return false;
+                            uint32_t live = 0;
+                            {
                                 uint32_t oldv[VB];
 #pragma unroll
                                 for (int u = 0; u < VB; u++) oldv[u] = pend[u] ? atomicCAS(&vh[hh[u]], HASH_EMPTY, (uint32_t)nb[u]) : 0u;
-                                bool more = false;
 #pragma unroll
                                 for (int u = 0; u < VB; u++) {
                                     const bool fresh = pend[u] && oldv[u] == HASH_EMPTY;
-                                    cnt += __popcll(__ballot(fresh));
-                                    if (pend[u]) {
-                                        if (fresh || oldv[u] == (uint32_t)nb[u]) pend[u] = false;
-                                        else hh[u] = (hh[u] + 1) & vmask, more = true;
-                                    }
+                                    cntl += fresh ? 1 : 0;
+                                    pend[u] = pend[u] && !fresh && oldv[u] != (uint32_t)nb[u];
+                                    hh[u] = (hh[u] + 1) & vmask;
+                                    if (__any(pend[u])) live |= 1u << u;
                                 }
-                                if (!__any(more)) break;
+                            }
+                            while (live) {
+                                uint32_t oldv[VB];
+#pragma unroll
+                                for (int u = 0; u < VB; u++)
+                                    if (live & (1u << u)) oldv[u] = pend[u] ? atomicCAS(&vh[hh[u]], HASH_EMPTY, (uint32_t)nb[u]) : 0u;
+#pragma unroll
+                                for (int u = 0; u < VB; u++)
+                                    if (live & (1u << u)) {
+                                        const bool fresh = pend[u] && oldv[u] == HASH_EMPTY;
+                                        cntl += fresh ? 1 : 0;
+                                        pend[u] = pend[u] && !fresh && oldv[u] != (uint32_t)nb[u];
+                                        hh[u] = (hh[u] + 1) & vmask;
+                                        if (!__any(pend[u])) live &= ~(1u << u);
+                                    }
+                            }
+                            return true;
+                        };
+                        int qq[2][VB];
+                        load_group(0, qq[0]);
+                        load_group(G, qq[1]);
+                        for (int e0 = 0; e0 < nblk && !again; e0 += 2 * G) {
+#pragma unroll
+                            for (int k = 0; k < 2; k++) {
+                                const int ek = e0 + k * G;
+                                if (ek < nblk && !again) {
+                                    if (!probe_group(qq[k], ek)) again = true;
+                                    else load_group(ek + 2 * G, qq[k]);
+                                }
                             }
                         }
                     }
+                    cnt += jv_wave_sum_int(cntl);
                 } else {
                     for (int e0 = 0; e0 < nexp && !again; e0++) {  // (other row lengths: one row at a time)
                         for (int cb = 0; cb < R; cb += JV_WAVE) {
