@@ -645,7 +645,10 @@ def main():
 
     in_flight = None
     if not args.profile_mode and world == 1 and eng.B <= 1024:
-        in_flight = [eng.timed_in_flight(rk, max(args.steps, 10), S) for S in (int(x) for x in os.environ.get("JV_BENCH_IN_FLIGHT", "1,2,3,4,8").split(","))]
+        try:
+            in_flight = [eng.timed_in_flight(rk, max(args.steps, 10), S) for S in (int(x) for x in os.environ.get("JV_BENCH_IN_FLIGHT", "1,2,3,4,8").split(","))]
+        except (Exception, SystemExit) as e:  # pragma: no cover - a side report never costs the line its headline number
+            in_flight = f"unavailable: {e!r}"
     # the kernel that carries the step (csrc/jv_abi.cpp enqueue_batch): the persistent jv_search_pqp_kernel for pools beyond
     # 256 entries and wherever its register-table variant applies (PQ-32, not cosine, more than 4 x CUs queries per launch),
     # else round 1's jv_search_pqf_kernel; exact indexes run on jv_search_lds_kernel
