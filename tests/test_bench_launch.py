@@ -32,3 +32,29 @@ def test_single_gpu_invocation_does_not_spawn():
 def test_world_size_mismatch_is_an_error():
     r = _run(["--gpus", "4"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode == 3
+
+
+def test_kept_bench_line_has_the_contract_fields():
+    """the line `bench.py` printed on the final tree (kept under profiles/ next to the rocprofv3 summary of the same command)
+    carries what the driver's contract names: metric / value / unit / n_gpus / steps / warmup / ms_per_step / higher_is_better /
+    scaling / vs_baseline / dtype / data / config.workload, a roofline object whose fraction is achieved / peak, and a CPU
+    baseline with its unit, core count, kind and sample."""
+    import glob
+    import json
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_c3_10m", "bench_final_tree.json")))
+    assert paths, "no kept bench line"
+    line = open(paths[-1]).read().strip().splitlines()[-1]
+    j = json.loads(line)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in j, key
+    assert j["n_gpus"] == 1 and j["higher_is_better"] is True and j["vs_baseline"] is None and j["data"].startswith("synthetic")
+    assert "workload" in j["config"] and "model" not in j["config"]
+    r = j["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["traffic"] is None or r["traffic"] > r["algorithmic_bytes_per_launch"] * 0.9
+    c = j["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == j["unit"] and c["sample"]
+    # value = queries of the timed steps / time: steps x batch / (steps x ms_per_step)
+    assert abs(j["value"] - j["config"]["queries_per_step"] / (j["ms_per_step"] * 1e-3)) / j["value"] < 0.01
