@@ -90,7 +90,7 @@ def test_hardware_probes_cross_compile(tmp_path):
     if not os.path.exists(hipcc):
         pytest.skip("no hipcc")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for src in ("lds_residency.hip", "hwq_probe.hip"):
+    for src in ("lds_residency.hip", "hwq_probe.hip", "start_overlap_probe.hip", "wave_placement_probe.hip"):   # (+ round 4's probes)
         out = tmp_path / (src + ".o")
         r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-c", "-o", str(out), os.path.join(root, "tools", src)],
                            capture_output=True, text=True, timeout=600)
