@@ -70,19 +70,57 @@ def _scores_from_gram(torch, G, sq_a, sq_b, sim):
 PRUNE_MAX_CANDIDATES = 160  # csrc/jv_build_kernels.hip JVB_PRUNE_MAX_LC (the candidate x candidate matrix lives in LDS)
 
 
+_TRUNC_WARNED = [False]
+
+
+def _truncate_candidates(torch, base, centers, cand, keep, sim):
+    """Rows with more candidates than the selection kernel takes (ef_construction > 160, or ef_construction + row in a
+    refine pass / merge): keep the `keep` best by score to the centre (ties: lower id first; empty slots last).  jvector's
+    RobustPrune walks ALL candidates in that order and stops at R selected ones, so the tail beyond the best 160 only matters
+    when fewer than R of the first 160 survive the diversity test — logged once, measured by the L = 200 test."""
+    S, Lc = cand.shape
+    out = torch.empty((S, keep), dtype=torch.int32, device=cand.device)
+    d = int(base.shape[1])
+    rows = max(1, (64 << 20) // (Lc * d * 4))
+    for s0 in range(0, S, rows):
+        c = cand[s0:s0 + rows].long()
+        ok = c >= 0
+        v = base[c.clamp_min(0)]                                   # [rows][Lc][d]
+        q = base[centers[s0:s0 + rows].long()].unsqueeze(1)          # [rows][1][d]
+        dots = (v * q).sum(2)
+        sc = _scores_from_gram(torch, dots, (v * v).sum(2), (q * q).sum(2), sim)
+        sc = torch.where(ok, sc, torch.full_like(sc, -float("inf")))
+        # (score desc, id asc): stable sort by id first, then stable by score
+        o1 = torch.argsort(torch.where(ok, c, torch.full_like(c, 1 << 40)), dim=1, stable=True)
+        sc1 = torch.gather(sc, 1, o1)
+        o2 = torch.argsort(sc1, dim=1, descending=True, stable=True)
+        pick = torch.gather(o1, 1, o2)[:, :keep]
+        out[s0:s0 + rows] = torch.gather(cand[s0:s0 + rows], 1, pick).to(torch.int32)
+    return out
+
+
 def robust_prune(torch, base, centers, cand, R, alpha, sim):
     """Diversity selection for every row: centers [S] (node ids), cand [S][Lc] (node ids, -1 = empty).
     Returns sel [S][R] (-1 padded), nsel [S].  jvector semantics: candidates in descending score to
     the centre (ties: lower id first, duplicates dropped); for a in (1.0, 1.2, .. alpha): keep c unless some
     already-selected s has sim(c, s) > sim(c, centre) * a.
     All of it runs in ONE hand-written kernel per call (csrc/jv_build_kernels.hip jvb_prune_rows_kernel: a workgroup per row
-    scores, orders, multiplies and selects straight from the vectors in HBM); this function only allocates the outputs."""
+    scores, orders, multiplies and selects straight from the vectors in HBM); this function only allocates the outputs.
+    More than PRUNE_MAX_CANDIDATES candidates per row (ef_construction is a user-facing mapping parameter of the reference,
+    K/common/KNNConstants.java METHOD_PARAMETER_EF_CONSTRUCTION): the best 160 by score are handed to the kernel."""
     S, Lc = cand.shape
     dev = base.device
     if dev.type != "cuda":
         raise RuntimeError("builder_gpu.robust_prune needs the HIP builder library (no CPU fallback)")
+    if R > PRUNE_MAX_CANDIDATES:
+        raise ValueError(f"R = {R}: the selection kernel keeps at most {PRUNE_MAX_CANDIDATES} candidates per row")
     if Lc > PRUNE_MAX_CANDIDATES:
-        raise ValueError(f"{Lc} candidates per row: the selection kernel takes at most {PRUNE_MAX_CANDIDATES}")
+        if not _TRUNC_WARNED[0]:
+            _TRUNC_WARNED[0] = True
+            print(f"[builder_gpu] {Lc} candidates per row: the selection kernel takes {PRUNE_MAX_CANDIDATES}; "
+                  "keeping the best by score to the centre", file=sys.stderr, flush=True)
+        cand = _truncate_candidates(torch, base, centers, cand, PRUNE_MAX_CANDIDATES, sim)
+        Lc = PRUNE_MAX_CANDIDATES
     sel = torch.empty((S, R), dtype=torch.int32, device=dev)
     nsel = torch.empty((S,), dtype=torch.int32, device=dev)
     if S == 0:
@@ -129,6 +167,11 @@ def build_graph_gpu(torch, base, sim, R=32, L=100, alpha=1.2, overflow=1.2, devi
     n, d = base.shape
     dev = base.device
     assert d % 4 == 0, "GPU builder needs 16-B aligned rows (d % 4 == 0)"
+    if not (1 <= R <= 128):
+        raise ValueError(f"R = {R}: the GPU builder takes 1 <= R <= 128 (row + overflow slack must fit the selection kernel)")
+    if L < 1:
+        raise ValueError(f"ef_construction = {L} < 1")
+    bl_state = {}   # back-link scratch of THIS build (head / next / overflow rows): never shared between builds or threads
     Rcap = int(math.ceil(R * overflow))
     Rcap = (Rcap + 3) & ~3
     adj = torch.full((n, Rcap), -1, dtype=torch.int32, device=dev)
@@ -184,7 +227,7 @@ def build_graph_gpu(torch, base, sim, R=32, L=100, alpha=1.2, overflow=1.2, devi
         adj[u, :R] = sel
         adj[u, R:] = -1
         deg[u] = nsel
-        _add_backlinks(torch, base, adj, deg, u, sel, R, Rcap, alpha, sim)
+        _add_backlinks(torch, base, adj, deg, u, sel, R, Rcap, alpha, sim, bl_state)
         pos += B
         it += 1
         if verbose and (it % 50 == 0 or pos >= n):
@@ -200,7 +243,7 @@ def build_graph_gpu(torch, base, sim, R=32, L=100, alpha=1.2, overflow=1.2, devi
             adj[u, :R] = sel
             adj[u, R:] = -1
             deg[u] = nsel
-            _add_backlinks(torch, base, adj, deg, u, sel, R, Rcap, alpha, sim)
+            _add_backlinks(torch, base, adj, deg, u, sel, R, Rcap, alpha, sim, bl_state)
         if verbose:
             torch.cuda.synchronize() if dev.type == "cuda" else None
             print(f"[builder_gpu] refine pass {rp + 1}/{refine_passes} done ({time.time() - t0:.1f}s)", file=sys.stderr, flush=True)
@@ -276,24 +319,19 @@ def merge_leading_segment_gpu(torch, base, lead_adj, lead_entry, lead_live, sim,
     return out, int(mid_to_final[entry_mid]), final_to_mid
 
 
-_BL_STATE = {}
-
-
-def _add_backlinks(torch, base, adj, deg, u, sel, R, Rcap, alpha, sim):
+def _add_backlinks(torch, base, adj, deg, u, sel, R, Rcap, alpha, sim, stt):
     """for every new edge u -> s add s -> u; rows that would exceed Rcap are re-pruned to R.
     Grouping, ordering and the append run in csrc/jv_build_kernels.hip (jvb_backlinks_device: per-target lists, sources sorted
-    by id — reproducible); this function owns the scratch buffers and hands the overflowing rows to the selection kernel."""
+    by id — reproducible); `stt` is the calling build's scratch dict (allocated once per build_graph_gpu call and dropped with
+    it: two builds — another field's with a different m, or another thread's — never share head / next / overflow buffers)."""
     dev = base.device
     B = int(u.shape[0])
     if B == 0:
         return
     n = int(adj.shape[0])
-    key = (dev.index, n)
-    stt = _BL_STATE.get(key)
-    if stt is None:
-        _BL_STATE.clear()   # (one graph under construction at a time)
-        stt = dict(head=torch.full((n,), -1, dtype=torch.int32, device=dev), counters=torch.zeros((2,), dtype=torch.int32, device=dev))
-        _BL_STATE[key] = stt
+    if "head" not in stt:
+        stt["head"] = torch.full((n,), -1, dtype=torch.int32, device=dev)
+        stt["counters"] = torch.zeros((2,), dtype=torch.int32, device=dev)
     E = B * int(sel.shape[1])
     if stt.get("E", 0) < E:
         stt["next"] = torch.empty((E,), dtype=torch.int32, device=dev)
@@ -301,7 +339,9 @@ def _add_backlinks(torch, base, adj, deg, u, sel, R, Rcap, alpha, sim):
         stt["E"] = E
     Lc = min(PRUNE_MAX_CANDIDATES, 2 * int(Rcap))   # the row + as many new sources again (the smallest ids when a target has more)
     ov_rows = min(E, n)
-    if stt.get("ov_rows", 0) < ov_rows:
+    if stt.get("ov_rows", 0) < ov_rows or stt.get("Lc") != Lc:
+        ov_rows = max(ov_rows, stt.get("ov_rows", 0))
+        stt["Lc"] = Lc
         stt["ov_nodes"] = torch.empty((ov_rows,), dtype=torch.int32, device=dev)
         stt["ov_cand"] = torch.empty((ov_rows, Lc), dtype=torch.int32, device=dev)
         stt["ov_rows"] = ov_rows

@@ -162,6 +162,42 @@ def test_gpu_builder_matches_sequential_insertion_quality(pkg):
         assert recs["gpu", oqf] >= recs["sequential", oqf] - 0.02, recs
 
 
+def test_wide_ef_construction_and_back_to_back_builds_with_different_degrees(pkg):
+    """(1) ef_construction is a user-facing mapping parameter — 128 with a refine pass is 128 + Rcap = 168 candidates
+    per row, 200 is beyond the selection kernel's 160 outright: both must build (the best 160 by score go to the kernel) and
+    search as well as the L = 100 graph; (2) two builds in one process with the SAME n but different degrees (two fields with
+    different m in one segment) own their back-link scratch: the second equals a build of its own in a fresh state."""
+    torch, gb = _gb()
+    b = pkg.binding
+    dev = torch.device("cuda", 0)
+    n, nq = 12000, 200
+    base = pkg.datagen.java_random_vectors(42, n, 64)
+    q = pkg.datagen.java_random_vectors(43, nq, 64)
+    bt, qt = torch.from_numpy(base).to(dev), torch.from_numpy(q).to(dev)
+    d2 = (qt * qt).sum(1)[:, None] + (bt * bt).sum(1)[None, :] - 2 * qt @ bt.T
+    truth = torch.topk(-d2, 10, dim=1).indices.cpu().numpy()
+
+    def recall(adj, entry, R):
+        gpu = b.GpuIndex(b.IndexData(vectors=base, adj=adj.cpu().numpy(), entry_node=entry, similarity=0))
+        got = gpu.search_batch(q, 10, 100)
+        gpu.close()
+        return float(np.mean([len(set(got.nodes[i]) & set(truth[i])) / 10 for i in range(nq)]))
+
+    ref = recall(*gb.build_graph_gpu(torch, bt, 0, R=32, L=100, verbose=False, refine_passes=1), 32)
+    for L, passes in ((128, 1), (200, 0), (200, 1)):
+        adj, entry = gb.build_graph_gpu(torch, bt, 0, R=32, L=L, verbose=False, refine_passes=passes)
+        assert adj.shape == (n, 32) and int((adj >= n).sum()) == 0
+        assert recall(adj, entry, 32) >= ref - 0.02, (L, passes, ref)
+    # same n, different degree, back to back
+    a16, e16 = gb.build_graph_gpu(torch, bt, 0, R=16, L=100, verbose=False)
+    a48, e48 = gb.build_graph_gpu(torch, bt, 0, R=48, L=100, verbose=False)
+    a16b, e16b = gb.build_graph_gpu(torch, bt, 0, R=16, L=100, verbose=False)
+    assert e16 == e16b and torch.equal(a16, a16b)
+    assert a48.shape == (n, 48) and recall(a48, e48, 48) >= recall(a16, e16, 16) - 0.01
+    with pytest.raises(ValueError):
+        gb.build_graph_gpu(torch, bt, 0, R=200, L=100, verbose=False)
+
+
 def test_leading_segment_merge_on_the_gpu(pkg):
     """Incremental merge (J/JVectorWriter.java:1166-1341): a 2 000-vector leading segment's graph + 1 000 vectors of other
     segments, 300 of the leading segment's docs deleted.  The merged graph has compact ordinals in order, no edge into a
