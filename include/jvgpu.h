@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define JVGPU_ABI_VERSION 3
+#define JVGPU_ABI_VERSION 4
 
 /* ---- status codes (the Java shim maps them to the reference's exception types,
  *      SURVEY §8(b) "Errors": EINVAL -> IllegalArgumentException, EUNSUPPORTED ->
@@ -218,6 +218,49 @@ int jv_search_batch_device(jv_index* index, const float* d_queries, int32_t nq, 
  * Scores carry score_scale exactly like the search path. Host pointers. */
 int jv_score_ordinals(jv_index* index, const float* query, const int32_t* ordinals, int32_t count,
                       float* out_scores);
+
+/* ---- the exact scorer for a BATCH of queries that share one candidate set (ABI v4) ----
+ * Replaces: Lucene's exact fallback as the reference wires it — AbstractKnnVectorQuery.exactSearch iterating the accepted
+ * docs through JVectorFloatVectorValues.scorer(target) (J/JVectorFloatVectorValues.java:189-191) and
+ * JVectorVectorScorer.score (J/JVectorVectorScorer.java:36-53) into a HitQueue of k — for nq queries that run under the SAME
+ * acceptDocs (one tenant / ACL / facet filter, the case a filtered k-NN query takes whenever its filter is selective:
+ * J/JVectorReader.java:202-207 reports visited + expanded and Lucene discards a graph search that reached the filter's
+ * cardinality).  The candidate set is, in this order of precedence:
+ *   accept_doc_words  a doc-space bitset (bit = Lucene doc id): every ordinal with ord2doc[ord] >= 0 and its bit set;
+ *   ordinals / count  an explicit ordinal list (entries < 0 or >= n, and ordinals whose doc is deleted, are skipped);
+ *   neither           every live ordinal of the index (brute force).
+ * Per query the call returns the topK best candidates by (score desc, doc asc) — Lucene's HitQueue order — with EXACTLY
+ * the scores jv_score_ordinals returns (canonical fp32 accumulation, score_scale applied): out_nodes / out_docs / out_scores
+ * [nq][topK], unused tail = -1 / -1 / 0, out_count [nq].  On the way a bf16 matrix-core pass over a bf16 mirror of the
+ * vectors (built by the first call, n * (2 * roundup(d, 64) + 4) bytes of HBM; when that does not fit, or the field is
+ * NVQ-only, the call scans the list in fp32 instead) only DISCARDS candidates that provably cannot reach the top k; the
+ * survivors are re-scored in fp32.  Results never depend on that pass (flag JV_XB_NO_PREFILTER runs without it).
+ * out_info (optional, host, JV_XB_INFO_WORDS words): [0] candidates, [1] sample rows of the bound pass (0 = no pre-filter
+ * ran), [2] rows re-scored in fp32 summed over the queries, [3] queries whose survivor list overflowed (they scanned the
+ * whole list).  topK <= JV_XB_TOPK_MAX (JV_EUNSUPPORTED beyond: score the ordinals with jv_score_ordinals). */
+#define JV_XB_NO_PREFILTER 0x1u
+#define JV_XB_TOPK_MAX 1024
+#define JV_XB_INFO_WORDS 4
+typedef struct jv_exact_batch_params {
+    uint32_t struct_size;              /* sizeof(jv_exact_batch_params) */
+    int32_t topK;
+    const uint64_t* accept_doc_words;  /* shared doc filter or NULL */
+    int64_t accept_num_docs;
+    const int32_t* ordinals;           /* shared ordinal list (used when accept_doc_words is NULL) or NULL */
+    int32_t count;
+    uint32_t flags;                    /* JV_XB_* */
+    uint64_t accept_key;               /* filter-cache key of accept_doc_words, 0 = hash (see jv_search_params) */
+} jv_exact_batch_params;
+/* Host pointers (queries, the params' arrays, outputs); synchronous. */
+int jv_score_ordinals_batch(jv_index* index, const float* queries, int32_t nq, const jv_exact_batch_params* params,
+                            int32_t* out_nodes, int32_t* out_docs, float* out_scores, int32_t* out_count, int64_t* out_info);
+/* DEVICE pointers on the index's device (queries, the params' arrays, outputs; out_info stays a host pointer).  The work is
+ * ordered behind what `hip_stream` has enqueued at call time and that stream continues behind it; the call itself returns
+ * after enqueueing unless a doc filter (its cardinality sizes the launch) or out_info asks for a host round trip.  NULL
+ * stream = synchronous. */
+int jv_score_ordinals_batch_device(jv_index* index, const float* d_queries, int32_t nq, const jv_exact_batch_params* params,
+                                   int32_t* d_out_nodes, int32_t* d_out_docs, float* d_out_scores, int32_t* d_out_count,
+                                   int64_t* out_info, void* hip_stream);
 
 /* Merge per-shard top-k lists (the step Lucene's TopDocs.merge performs over leaves, and the
  * exchange step of the doc-range sharded multi-GPU layout): `lists` rows of `k` (doc, score)

@@ -26,7 +26,9 @@ ABI_SYMBOLS = [
     "jv_score_ordinals", "jv_merge_topk_device", "jv_index_get_info", "jv_set_option", "jv_last_error",
     "jv_abi_version", "jv_search_ex", "jv_search_batch_ex", "jv_index_set_option", "jv_index_get_counter", "jv_shard_group_create",
     "jv_shard_group_destroy", "jv_search_sharded_batch", "jv_search_sharded_batch_ex", "jv_shard_group_set_option",
+    "jv_score_ordinals_batch", "jv_score_ordinals_batch_device",
 ]
+XB_NO_PREFILTER, XB_TOPK_MAX, XB_INFO_WORDS = 0x1, 1024, 4
 QFLAG_RETRIED_BIG, QFLAG_EARLY_TERMINATED = 0x1, 0x2
 
 
@@ -54,6 +56,11 @@ class JvIndexDesc(C.Structure):
         ("nvq_M", C.c_int32), ("reserved2", C.c_int32), ("nvq_sub_sizes", C.c_void_p), ("nvq_params", C.c_void_p),
         ("nvq_bytes", C.c_void_p), ("nvq_global_mean", C.c_void_p),
     ]
+
+
+class JvExactBatchParams(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("topK", C.c_int32), ("accept_doc_words", C.c_void_p), ("accept_num_docs", C.c_int64),
+                ("ordinals", C.c_void_p), ("count", C.c_int32), ("flags", C.c_uint32), ("accept_key", C.c_uint64)]
 
 
 class JvIndexInfo(C.Structure):
@@ -233,6 +240,10 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.jv_search_batch_device.restype = C.c_int
     lib.jv_score_ordinals.argtypes = [vp, vp, vp, i32, vp]
     lib.jv_score_ordinals.restype = C.c_int
+    lib.jv_score_ordinals_batch.argtypes = [vp, vp, i32, C.POINTER(JvExactBatchParams), vp, vp, vp, vp, vp]
+    lib.jv_score_ordinals_batch.restype = C.c_int
+    lib.jv_score_ordinals_batch_device.argtypes = [vp, vp, i32, C.POINTER(JvExactBatchParams), vp, vp, vp, vp, vp, vp]
+    lib.jv_score_ordinals_batch_device.restype = C.c_int
     lib.jv_merge_topk_device.argtypes = [i32, vp, vp, i32, i32, i32, vp, vp, vp]
     lib.jv_merge_topk_device.restype = C.c_int
     lib.jv_index_get_info.argtypes = [vp, C.POINTER(JvIndexInfo)]
@@ -420,6 +431,51 @@ class GpuIndex:
         out = np.zeros(o.shape[0], dtype=np.float32)
         _check(self.lib, self.lib.jv_score_ordinals(self.handle, q.ctypes.data, o.ctypes.data, o.shape[0], out.ctypes.data))
         return out
+
+
+    def score_ordinals_batch(self, queries: np.ndarray, topK: int, accept: Optional[np.ndarray] = None, accept_num_docs: int = 0,
+                             ordinals: Optional[np.ndarray] = None, flags: int = 0, accept_key: int = 0):
+        """jv_score_ordinals_batch: the exact top-k of every query over ONE shared candidate set (doc filter, ordinal list, or
+        every live ordinal).  Returns (nodes [nq][topK], docs, scores, count [nq], info [4])."""
+        q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, self.d)
+        nq = q.shape[0]
+        nodes = np.full((nq, topK), -1, dtype=np.int32)
+        docs = np.full((nq, topK), -1, dtype=np.int32)
+        scores = np.zeros((nq, topK), dtype=np.float32)
+        count = np.zeros(nq, dtype=np.int32)
+        info = np.zeros(XB_INFO_WORDS, dtype=np.int64)
+        acc = None if accept is None else np.ascontiguousarray(accept, dtype=np.uint64)
+        o = None if ordinals is None else np.ascontiguousarray(ordinals, dtype=np.int32)
+        p = JvExactBatchParams()
+        p.struct_size = C.sizeof(JvExactBatchParams)
+        p.topK = topK
+        p.accept_doc_words = _ptr(acc)
+        p.accept_num_docs = accept_num_docs
+        p.ordinals = _ptr(o)
+        p.count = 0 if o is None else int(o.shape[0])
+        p.flags = flags
+        p.accept_key = accept_key
+        _check(self.lib, self.lib.jv_score_ordinals_batch(self.handle, q.ctypes.data, nq, C.byref(p), nodes.ctypes.data, docs.ctypes.data,
+                                                          scores.ctypes.data, count.ctypes.data, info.ctypes.data))
+        return nodes, docs, scores, count, info
+
+    def score_ordinals_batch_device(self, d_queries: int, nq: int, topK: int, d_nodes: int, d_docs: int, d_scores: int, d_count: int,
+                                    d_accept: int = 0, accept_num_docs: int = 0, d_ordinals: int = 0, count: int = 0, flags: int = 0,
+                                    stream: int = 0, want_info: bool = False):
+        """Raw device pointers (ints); enqueued behind `stream`.  Returns info [4] when want_info (that synchronises)."""
+        p = JvExactBatchParams()
+        p.struct_size = C.sizeof(JvExactBatchParams)
+        p.topK = topK
+        p.accept_doc_words = d_accept or None
+        p.accept_num_docs = accept_num_docs
+        p.ordinals = d_ordinals or None
+        p.count = count
+        p.flags = flags
+        p.accept_key = 0
+        info = np.zeros(XB_INFO_WORDS, dtype=np.int64) if want_info else None
+        _check(self.lib, self.lib.jv_score_ordinals_batch_device(self.handle, d_queries, nq, C.byref(p), d_nodes or None, d_docs or None,
+                                                                 d_scores or None, d_count or None, _ptr(info), stream or None))
+        return info
 
 
 class ShardGroup:

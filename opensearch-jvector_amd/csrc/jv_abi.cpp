@@ -26,8 +26,16 @@
 
 #include "../../include/jvgpu.h"
 #include "jv_device.h"
+#include "jv_xb.h"
 
 extern "C" {
+// batched exact scorer (jv_kernels_xb.hip)
+hipError_t jvk_xb_mirror(const float* src, long long rows, int d, long long src_stride, int kp, uint16_t* dst, float* norm2, int scalar, hipStream_t s);
+hipError_t jvk_xb_build_list(const JvIndexDev* ix, const uint64_t* d_accept, long long accept_docs, int32_t* d_counts, int32_t* d_list, hipStream_t s);
+int jvk_xb_list_blocks(int n);
+hipError_t jvk_xb_tile(const JvXbTileArgs* a, int mode, hipStream_t s);
+hipError_t jvk_xb_kth(const float* sample, int ld, int S, int k, float* thr, int B, hipStream_t s);
+hipError_t jvk_xb_rescore(const JvIndexDev* ix, const JvXbRescoreArgs* a, int nq, hipStream_t s);
 hipError_t jvk_set_max_lds(int bytes);
 hipError_t jvk_build_fused(const uint8_t* codes, const int32_t* adj, uint8_t* fused, long long n, int R, int cs, hipStream_t s);
 hipError_t jvk_launch_search_lds(const JvIndexDev* ix, const JvSearchArgs* a, int pq, int pool, int tag, int lds_bytes, hipStream_t s);
@@ -283,8 +291,32 @@ struct FilterEntry {
 
 }  // namespace
 
+// Batched exact scorer (jv_score_ordinals_batch): the bf16 mirror of the vectors (built by the first call that can use it)
+// and the call's scratch.  One call at a time per index (`mu`); the kernels of a call fill the GPU by themselves.
+struct XbState {
+    std::mutex mu;
+    hipStream_t stream = nullptr;
+    int mirror_state = 0;           // 0 = not tried, 1 = ready, -1 = unavailable (NVQ-only field, or no HBM left for it)
+    uint16_t* vb = nullptr;         // [n][kp] bf16
+    float* vnorm2 = nullptr;        // [n]
+    int kp = 0;
+    int32_t* d_list = nullptr; size_t list_cap = 0;       // candidate ordinals
+    int32_t* d_counts = nullptr; size_t counts_cap = 0;   // list construction: per-block counts / offsets
+    float* d_queries = nullptr; size_t queries_cap = 0;   // fp32 queries (host-pointer API)
+    uint16_t* d_qb = nullptr; size_t qb_cap = 0;          // bf16 queries of one round
+    float* d_qn2 = nullptr; float* d_thr = nullptr; int32_t* d_surv_cnt = nullptr; size_t round_cap = 0;
+    float* d_sample = nullptr; size_t sample_cap = 0;
+    int32_t* d_surv = nullptr; size_t surv_cap = 0;
+    uint8_t* d_out = nullptr; uint8_t* h_out = nullptr; size_t out_cap = 0;
+    int64_t* d_info = nullptr;
+    int64_t* h_info = nullptr;      // pinned: [0..1] kernel counters, [2] list length
+    uint64_t* d_accept = nullptr; size_t accept_cap = 0;  // filter words when the cache has no slot
+    int64_t bytes = 0;
+};
+
 struct JvQueryServer;
 struct jv_index {
+    XbState xb;
     Opts opts;
     Combiner combiner;
     int device = 0;
@@ -1496,6 +1528,14 @@ void jv_index_destroy(jv_index* ix) {
         if (f.ready) hipEventDestroy(f.ready);
     }
     for (void* p : ix->owned) jv_free(p);
+    {
+        XbState& x = ix->xb;
+        jv_free(x.vb); jv_free(x.vnorm2); jv_free(x.d_list); jv_free(x.d_counts); jv_free(x.d_queries); jv_free(x.d_qb);
+        jv_free(x.d_qn2); jv_free(x.d_thr); jv_free(x.d_surv_cnt); jv_free(x.d_sample); jv_free(x.d_surv); jv_free(x.d_out);
+        jv_free(x.d_info); jv_free(x.d_accept);
+        jv_host_free(x.h_out); jv_host_free(x.h_info);
+        if (x.stream) hipStreamDestroy(x.stream);
+    }
     delete ix;
 }
 
@@ -2653,6 +2693,404 @@ int jv_score_ordinals(jv_index* index, const float* query, const int32_t* ordina
     if (e == hipSuccess) e = hipMemcpyAsync(out_scores, dout, (size_t)count * 4, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) return fail(JV_EDEVICE, "jv_score_ordinals: %s", hipGetErrorString(e));
+    return JV_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Batched exact scorer: nq queries against ONE shared candidate set (csrc/jv_kernels_xb.hip has the method and the bound).
+// ---------------------------------------------------------------------------------------------
+static bool xb_trace() {
+    static const bool on = getenv("JV_XB_TRACE") != nullptr;
+    return on;
+}
+// diagnostics (JV_XB_TRACE=1): drain the stream after every step and say which one failed
+#define XB_STEP(what)                                                                                        \
+    do {                                                                                                     \
+        if (xb_trace()) {                                                                                    \
+            hipError_t e_ = hipStreamSynchronize(ix->xb.stream);                                             \
+            fprintf(stderr, "[jvgpu xb] %s: %s\n", what, hipGetErrorString(e_));                             \
+            if (e_ != hipSuccess) return fail(JV_EDEVICE, "%s: %s", what, hipGetErrorString(e_));            \
+        }                                                                                                    \
+    } while (0)
+#define XB_ROUND_QUERIES 1024   /* queries per round (8 panels of 128): the candidates are read once per round */
+#define XB_SURV_CAP 4096        /* survivor slots per query; a query that overflows scans the whole list */
+
+extern "C++" {
+template <typename T>
+static int xb_grow(XbState& x, T** p, size_t* cap, size_t need) {
+    if (need <= *cap && *p) return JV_OK;
+    if (*p) {
+        jv_free(*p);
+        x.bytes -= (int64_t)(*cap * sizeof(T));
+    }
+    *p = nullptr;
+    *cap = 0;
+    const size_t ncap = need < 256 ? 256 : need + need / 4;
+    HIPCHK(hipMalloc((void**)p, ncap * sizeof(T)));
+    *cap = ncap;
+    x.bytes += (int64_t)(ncap * sizeof(T));
+    return JV_OK;
+}
+}  // extern "C++"
+
+// the bf16 mirror: [n][kp] + |v|^2, built once (n * (2 kp + 4) bytes: 15.4 GB for 10M x 768)
+static int xb_ensure_mirror(jv_index* ix) {
+    XbState& x = ix->xb;
+    if (x.mirror_state != 0) return JV_OK;
+    const JvIndexDev& dv = ix->dev;
+    x.mirror_state = -1;
+    if (!dv.vectors || dv.n <= 0) return JV_OK;  // NVQ-only field: every batch takes the canonical scan
+    const int kp = (dv.d + 63) / 64 * 64;
+    uint16_t* vb = nullptr;
+    float* vn = nullptr;
+    if (hipMalloc((void**)&vb, (size_t)dv.n * (size_t)kp * 2) != hipSuccess || hipMalloc((void**)&vn, (size_t)dv.n * 4) != hipSuccess) {
+        (void)hipGetLastError();
+        if (vb) jv_free(vb);
+        return JV_OK;  // no room: not an error, the canonical scan answers
+    }
+    hipError_t e = jvk_xb_mirror(dv.vectors, dv.n, dv.d, dv.stride, kp, vb, vn, 0, x.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(x.stream);
+    if (e != hipSuccess) {
+        jv_free(vb);
+        jv_free(vn);
+        return fail(JV_EDEVICE, "bf16 mirror: %s", hipGetErrorString(e));
+    }
+    x.vb = vb;
+    x.vnorm2 = vn;
+    x.kp = kp;
+    x.bytes += (int64_t)dv.n * ((int64_t)kp * 2 + 4);
+    x.mirror_state = 1;
+    return JV_OK;
+}
+
+// d_* = device pointers on the index's device; d_ords = nullptr: every ordinal is a candidate (C = n).  Enqueues on x.stream.
+static int xb_run(jv_index* ix, const float* d_queries, int nq, int topK, const int32_t* d_ords, int C, uint32_t flags,
+                  int32_t* d_nodes, int32_t* d_docs, float* d_scores, int32_t* d_count, int64_t* info) {
+    XbState& x = ix->xb;
+    const JvIndexDev& dv = ix->dev;
+    hipStream_t st = x.stream;
+    if (!x.d_info) {
+        HIPCHK(hipMalloc((void**)&x.d_info, 4 * sizeof(int64_t)));
+        HIPCHK(hipHostMalloc((void**)&x.h_info, 4 * sizeof(int64_t), hipHostMallocDefault));
+    }
+    HIPCHK(hipMemsetAsync(x.d_info, 0, 4 * sizeof(int64_t), st));
+    int S = 0;
+    bool pre = !(flags & JV_XB_NO_PREFILTER) && C >= 2048;
+    if (pre) {
+        int rc = xb_ensure_mirror(ix);
+        if (rc != JV_OK) return rc;
+        pre = x.mirror_state == 1;
+    }
+    if (pre) {
+        S = std::min(C, std::max(4096, std::min(32768, C / 8)));
+        if ((int64_t)topK * 4 > S) pre = false;
+    }
+    const int kp = x.kp;
+    // kappa: (2u + u^2) with u = 2^-8 (bf16 round to nearest even, both operands) + fp32 accumulation of kp products in
+    // the matrix pipe, whatever its order and rounding (4 kp 2^-24 of sum |q c|: four times the round-to-nearest chain) + the
+    // fp32 norms' own error
+    const float kappa = (float)((2.0 / 256.0 + 1.0 / 65536.0) * 1.001 + 4.0 * (double)kp / 16777216.0 + 1e-5);
+    for (int q0 = 0; q0 < nq; q0 += XB_ROUND_QUERIES) {
+        const int B = std::min(XB_ROUND_QUERIES, nq - q0);
+        const float* dq = d_queries + (size_t)q0 * dv.d;
+        JvXbRescoreArgs ra;
+        memset(&ra, 0, sizeof(ra));
+        ra.queries = dq;
+        ra.ords = d_ords;
+        ra.C = C;
+        ra.topK = topK;
+        ra.out_nodes = d_nodes ? d_nodes + (size_t)q0 * topK : nullptr;
+        ra.out_docs = d_docs ? d_docs + (size_t)q0 * topK : nullptr;
+        ra.out_scores = d_scores ? d_scores + (size_t)q0 * topK : nullptr;
+        ra.out_count = d_count ? d_count + q0 : nullptr;
+        ra.out_info = x.d_info;
+        if (pre) {
+            const int panels = (B + 127) / 128;
+            int rc;
+            if ((rc = xb_grow(x, &x.d_qb, &x.qb_cap, (size_t)panels * 128 * kp)) != JV_OK) return rc;
+            if (x.round_cap < (size_t)panels * 128) {
+                size_t c1 = x.round_cap, c2 = x.round_cap, c3 = x.round_cap;
+                if ((rc = xb_grow(x, &x.d_qn2, &c1, (size_t)panels * 128)) != JV_OK) return rc;
+                if ((rc = xb_grow(x, &x.d_thr, &c2, (size_t)panels * 128)) != JV_OK) return rc;
+                if ((rc = xb_grow(x, &x.d_surv_cnt, &c3, (size_t)panels * 128)) != JV_OK) return rc;
+                x.round_cap = std::min(c1, std::min(c2, c3));
+            }
+            if ((rc = xb_grow(x, &x.d_sample, &x.sample_cap, (size_t)B * S)) != JV_OK) return rc;
+            if ((rc = xb_grow(x, &x.d_surv, &x.surv_cap, (size_t)B * XB_SURV_CAP)) != JV_OK) return rc;
+            HIPCHK(hipMemsetAsync(x.d_qb, 0, (size_t)panels * 128 * kp * 2, st));
+            HIPCHK(jvk_xb_mirror(dq, B, dv.d, dv.d, kp, x.d_qb, x.d_qn2, 1, st));
+            HIPCHK(hipMemsetAsync(x.d_surv_cnt, 0, (size_t)B * 4, st));
+            XB_STEP("bf16 queries");
+            JvXbTileArgs ta;
+            memset(&ta, 0, sizeof(ta));
+            ta.vb = x.vb;
+            ta.vnorm2 = x.vnorm2;
+            ta.kp = kp;
+            ta.n = dv.n;
+            ta.ords = d_ords;
+            ta.C = C;
+            ta.qb = x.d_qb;
+            ta.qnorm2 = x.d_qn2;
+            ta.B = B;
+            ta.panels = panels;
+            ta.sim = dv.sim;
+            ta.kappa = kappa;
+            // pass A: the strided sample -> per-query bar
+            ta.cstride = C / S;
+            ta.rows = S;
+            ta.sample = x.d_sample;
+            ta.sample_ld = S;
+            HIPCHK(jvk_xb_tile(&ta, 0, st));
+            XB_STEP("sample pass");
+            HIPCHK(jvk_xb_kth(x.d_sample, S, S, topK, x.d_thr, B, st));
+            XB_STEP("k-th select");
+            // pass B: every candidate against the bar
+            ta.cstride = 1;
+            ta.rows = C;
+            ta.thr = x.d_thr;
+            ta.surv_cnt = x.d_surv_cnt;
+            ta.surv = x.d_surv;
+            ta.surv_cap = XB_SURV_CAP;
+            HIPCHK(jvk_xb_tile(&ta, 1, st));
+            XB_STEP("filter pass");
+            ra.surv_cnt = x.d_surv_cnt;
+            ra.surv = x.d_surv;
+            ra.surv_cap = XB_SURV_CAP;
+        } else {
+            ra.force_all = 1;
+        }
+        HIPCHK(jvk_xb_rescore(&dv, &ra, B, st));
+        XB_STEP("re-score");
+    }
+    if (info) {
+        HIPCHK(hipMemcpyAsync(x.h_info, x.d_info, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        info[0] = C;
+        info[1] = pre ? S : 0;
+        info[2] = x.h_info[0];
+        info[3] = x.h_info[1];
+    }
+    return JV_OK;
+}
+
+static int xb_check(jv_index* index, const void* queries, int32_t nq, const jv_exact_batch_params* p) {
+    if (!index || !p) return fail(JV_EINVAL, "NULL argument");
+    if (p->struct_size != sizeof(jv_exact_batch_params)) return fail(JV_EINVAL, "jv_exact_batch_params has the wrong struct_size");
+    if (nq < 0 || (nq > 0 && !queries)) return fail(JV_EINVAL, "bad query batch");
+    if (p->topK < 1 || p->topK > JV_XB_TOPK_MAX) return fail(p->topK < 1 ? JV_EINVAL : JV_EUNSUPPORTED, "topK must be 1..%d", JV_XB_TOPK_MAX);
+    if (p->accept_doc_words && p->accept_num_docs <= 0) return fail(JV_EINVAL, "accept_num_docs <= 0");
+    if (!p->accept_doc_words && p->count < 0) return fail(JV_EINVAL, "count < 0");
+    if (!p->accept_doc_words && p->count > 0 && !p->ordinals) return fail(JV_EINVAL, "ordinals is NULL");
+    return JV_OK;
+}
+
+// candidate list of a call: device list pointer (nullptr = identity) and its length
+static int xb_candidates(jv_index* ix, const jv_exact_batch_params* p, bool device_ptrs, const int32_t** d_ords, int* C, int* filter_slot) {
+    XbState& x = ix->xb;
+    const JvIndexDev& dv = ix->dev;
+    *filter_slot = -1;
+    *d_ords = nullptr;
+    int rc;
+    if (p->accept_doc_words) {
+        const size_t nwords = (size_t)((p->accept_num_docs + 63) / 64);
+        const uint64_t* d_acc = nullptr;
+        if (device_ptrs) {
+            d_acc = p->accept_doc_words;
+        } else {
+            if ((rc = filter_acquire(ix, p->accept_doc_words, nwords, p->accept_key, x.stream, &d_acc, filter_slot)) != JV_OK) return rc;
+            if (*filter_slot < 0) {
+                if ((rc = xb_grow(x, &x.d_accept, &x.accept_cap, nwords)) != JV_OK) return rc;
+                HIPCHK(hipMemcpyAsync(x.d_accept, p->accept_doc_words, nwords * 8, hipMemcpyHostToDevice, x.stream));
+                d_acc = x.d_accept;
+            }
+        }
+        const int nb = jvk_xb_list_blocks(dv.n);
+        if ((rc = xb_grow(x, &x.d_counts, &x.counts_cap, (size_t)nb + 1)) != JV_OK) return rc;
+        if ((rc = xb_grow(x, &x.d_list, &x.list_cap, (size_t)std::max(dv.n, 1))) != JV_OK) return rc;
+        if (!x.h_info) {
+            HIPCHK(hipMalloc((void**)&x.d_info, 4 * sizeof(int64_t)));
+            HIPCHK(hipHostMalloc((void**)&x.h_info, 4 * sizeof(int64_t), hipHostMallocDefault));
+        }
+        HIPCHK(jvk_xb_build_list(&dv, d_acc, p->accept_num_docs, x.d_counts, x.d_list, x.stream));
+        HIPCHK(hipMemcpyAsync(x.h_info + 2, x.d_counts + nb, 4, hipMemcpyDeviceToHost, x.stream));
+        HIPCHK(hipStreamSynchronize(x.stream));  // the grid of the tile kernel is sized by the filter's cardinality
+        *C = (int)(*(int32_t*)(x.h_info + 2));
+        *d_ords = x.d_list;
+    } else if (p->ordinals) {
+        *C = p->count;
+        if (device_ptrs) {
+            *d_ords = p->ordinals;
+        } else {
+            if ((rc = xb_grow(x, &x.d_list, &x.list_cap, (size_t)std::max(p->count, 1))) != JV_OK) return rc;
+            HIPCHK(hipMemcpyAsync(x.d_list, p->ordinals, (size_t)p->count * 4, hipMemcpyHostToDevice, x.stream));
+            *d_ords = x.d_list;
+        }
+    } else {
+        *C = dv.n;  // no filter, no list: every ordinal (brute force)
+    }
+    return JV_OK;
+}
+
+static int xb_prepare(jv_index* ix) {
+    XbState& x = ix->xb;
+    HIPCHK(hipSetDevice(ix->device));
+    if (!x.stream) HIPCHK(hipStreamCreateWithFlags(&x.stream, hipStreamNonBlocking));
+    return JV_OK;
+}
+
+int jv_score_ordinals_batch(jv_index* index, const float* queries, int32_t nq, const jv_exact_batch_params* p, int32_t* out_nodes,
+                            int32_t* out_docs, float* out_scores, int32_t* out_count, int64_t* out_info) {
+    int rc = xb_check(index, queries, nq, p);
+    if (rc != JV_OK) return rc;
+    if (out_info) memset(out_info, 0, JV_XB_INFO_WORDS * sizeof(int64_t));
+    if (nq == 0) return JV_OK;
+    XbState& x = index->xb;
+    std::lock_guard<std::mutex> lk(x.mu);
+    if ((rc = xb_prepare(index)) != JV_OK) return rc;
+    const int topK = p->topK, d = index->dev.d;
+    if (index->dev.n == 0) {
+        if (out_count) memset(out_count, 0, (size_t)nq * 4);
+        for (size_t i = 0; i < (size_t)nq * topK; i++) {
+            if (out_nodes) out_nodes[i] = -1;
+            if (out_docs) out_docs[i] = -1;
+            if (out_scores) out_scores[i] = 0.0f;
+        }
+        return JV_OK;
+    }
+    const int32_t* d_ords = nullptr;
+    int C = 0, slot = -1;
+    rc = xb_candidates(index, p, false, &d_ords, &C, &slot);
+    struct Rel {
+        jv_index* ix;
+        int* slot;
+        ~Rel() { filter_release(ix, *slot); }
+    } rel{index, &slot};
+    if (rc != JV_OK) return rc;
+    if ((rc = xb_grow(x, &x.d_queries, &x.queries_cap, (size_t)nq * d)) != JV_OK) return rc;
+    const size_t rows = (size_t)nq * topK;
+    const size_t need = rows * 12 + (size_t)nq * 4;
+    if (need > x.out_cap || !x.d_out) {
+        jv_free(x.d_out);
+        jv_host_free(x.h_out);
+        x.d_out = nullptr;
+        x.h_out = nullptr;
+        x.out_cap = 0;
+        const size_t cap = need + need / 4;
+        HIPCHK(hipMalloc((void**)&x.d_out, cap));
+        HIPCHK(hipHostMalloc((void**)&x.h_out, cap, hipHostMallocDefault));
+        x.out_cap = cap;
+    }
+    int32_t* dn = (int32_t*)x.d_out;
+    int32_t* dd = dn + rows;
+    float* ds = (float*)(dd + rows);
+    int32_t* dc = (int32_t*)(ds + rows);
+    HIPCHK(hipMemcpyAsync(x.d_queries, queries, (size_t)nq * d * 4, hipMemcpyHostToDevice, x.stream));
+    int64_t info[4] = {0, 0, 0, 0};
+    if ((rc = xb_run(index, x.d_queries, nq, topK, d_ords, C, p->flags, dn, dd, ds, dc, out_info ? info : nullptr)) != JV_OK) {
+        hipStreamSynchronize(x.stream);
+        return rc;
+    }
+    HIPCHK(hipMemcpyAsync(x.h_out, x.d_out, need, hipMemcpyDeviceToHost, x.stream));
+    HIPCHK(hipStreamSynchronize(x.stream));
+    if (out_nodes) memcpy(out_nodes, x.h_out, rows * 4);
+    if (out_docs) memcpy(out_docs, x.h_out + rows * 4, rows * 4);
+    if (out_scores) memcpy(out_scores, x.h_out + rows * 8, rows * 4);
+    if (out_count) memcpy(out_count, x.h_out + rows * 12, (size_t)nq * 4);
+    if (out_info) memcpy(out_info, info, sizeof(info));
+    return JV_OK;
+}
+
+int jv_score_ordinals_batch_device(jv_index* index, const float* d_queries, int32_t nq, const jv_exact_batch_params* p,
+                                   int32_t* d_out_nodes, int32_t* d_out_docs, float* d_out_scores, int32_t* d_out_count,
+                                   int64_t* out_info, void* hip_stream) {
+    int rc = xb_check(index, d_queries, nq, p);
+    if (rc != JV_OK) return rc;
+    if (out_info) memset(out_info, 0, JV_XB_INFO_WORDS * sizeof(int64_t));
+    if (nq == 0) return JV_OK;
+    if (index->dev.n == 0) return fail(JV_EINVAL, "empty index: nothing to score on the device path");
+    XbState& x = index->xb;
+    std::lock_guard<std::mutex> lk(x.mu);
+    if ((rc = xb_prepare(index)) != JV_OK) return rc;
+    hipStream_t caller = (hipStream_t)hip_stream;
+    // the library's stream starts behind what the caller's stream has enqueued (the queries), and the caller's stream
+    // continues behind the library's work
+    hipEvent_t ev = nullptr;
+    HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    struct EvGuard {
+        hipEvent_t e;
+        ~EvGuard() { hipEventDestroy(e); }
+    } evg{ev};
+    HIPCHK(hipEventRecord(ev, caller));
+    HIPCHK(hipStreamWaitEvent(x.stream, ev, 0));
+    const int32_t* d_ords = nullptr;
+    int C = 0, slot = -1;
+    if ((rc = xb_candidates(index, p, true, &d_ords, &C, &slot)) != JV_OK) return rc;
+    if ((rc = xb_run(index, d_queries, nq, p->topK, d_ords, C, p->flags, d_out_nodes, d_out_docs, d_out_scores, d_out_count, out_info)) != JV_OK) {
+        hipStreamSynchronize(x.stream);
+        return rc;
+    }
+    HIPCHK(hipEventRecord(ev, x.stream));
+    HIPCHK(hipStreamWaitEvent(caller, ev, 0));
+    if (!hip_stream) HIPCHK(hipStreamSynchronize(x.stream));
+    return JV_OK;
+}
+
+// Diagnostics (tests/test_gpu_xb.py; not part of include/jvgpu.h): the interval [lower, upper] the matrix-core pass
+// computes for every (query, list entry) pair — the canonical fp32 raw value (dot, -squared distance, cosine) must lie
+// inside it, or the pre-filter could discard a true neighbour.  Host pointers, nq <= 1024, out_* [nq][count].
+int jv_xb_debug_bounds(jv_index* index, const float* queries, int32_t nq, const int32_t* ordinals, int32_t count, float* out_lower,
+                       float* out_upper, float* out_kappa) {
+    if (!index || !queries || !ordinals || nq < 1 || nq > XB_ROUND_QUERIES || count < 1) return fail(JV_EINVAL, "bad argument");
+    XbState& x = index->xb;
+    std::lock_guard<std::mutex> lk(x.mu);
+    int rc;
+    if ((rc = xb_prepare(index)) != JV_OK) return rc;
+    if ((rc = xb_ensure_mirror(index)) != JV_OK) return rc;
+    if (x.mirror_state != 1) return fail(JV_EUNSUPPORTED, "no bf16 mirror for this index");
+    const JvIndexDev& dv = index->dev;
+    const int kp = x.kp, panels = (nq + 127) / 128;
+    hipStream_t st = x.stream;
+    if ((rc = xb_grow(x, &x.d_queries, &x.queries_cap, (size_t)nq * dv.d)) != JV_OK) return rc;
+    if ((rc = xb_grow(x, &x.d_list, &x.list_cap, (size_t)count)) != JV_OK) return rc;
+    if ((rc = xb_grow(x, &x.d_qb, &x.qb_cap, (size_t)panels * 128 * kp)) != JV_OK) return rc;
+    if (x.round_cap < (size_t)panels * 128) {
+        size_t c1 = x.round_cap, c2 = x.round_cap, c3 = x.round_cap;
+        if ((rc = xb_grow(x, &x.d_qn2, &c1, (size_t)panels * 128)) != JV_OK) return rc;
+        if ((rc = xb_grow(x, &x.d_thr, &c2, (size_t)panels * 128)) != JV_OK) return rc;
+        if ((rc = xb_grow(x, &x.d_surv_cnt, &c3, (size_t)panels * 128)) != JV_OK) return rc;
+        x.round_cap = std::min(c1, std::min(c2, c3));
+    }
+    if ((rc = xb_grow(x, &x.d_sample, &x.sample_cap, (size_t)nq * count)) != JV_OK) return rc;
+    HIPCHK(hipMemcpyAsync(x.d_queries, queries, (size_t)nq * dv.d * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(x.d_list, ordinals, (size_t)count * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(x.d_qb, 0, (size_t)panels * 128 * kp * 2, st));
+    HIPCHK(jvk_xb_mirror(x.d_queries, nq, dv.d, dv.d, kp, x.d_qb, x.d_qn2, 1, st));
+    JvXbTileArgs ta;
+    memset(&ta, 0, sizeof(ta));
+    ta.vb = x.vb;
+    ta.vnorm2 = x.vnorm2;
+    ta.kp = kp;
+    ta.n = dv.n;
+    ta.ords = x.d_list;
+    ta.C = count;
+    ta.cstride = 1;
+    ta.rows = count;
+    ta.qb = x.d_qb;
+    ta.qnorm2 = x.d_qn2;
+    ta.B = nq;
+    ta.panels = panels;
+    ta.sim = dv.sim;
+    ta.kappa = (float)((2.0 / 256.0 + 1.0 / 65536.0) * 1.001 + 4.0 * (double)kp / 16777216.0 + 1e-5);
+    ta.sample = x.d_sample;
+    ta.sample_ld = count;
+    if (out_kappa) *out_kappa = ta.kappa;
+    for (int mode = 0; mode <= 2; mode += 2) {
+        float* dst = mode == 0 ? out_lower : out_upper;
+        if (!dst) continue;
+        HIPCHK(jvk_xb_tile(&ta, mode, st));
+        HIPCHK(hipMemcpyAsync(dst, x.d_sample, (size_t)nq * count * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
     return JV_OK;
 }
 

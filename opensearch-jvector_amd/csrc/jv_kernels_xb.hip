@@ -1,0 +1,556 @@
+// jv_kernels_xb.hip — the BATCHED exact scorer: B queries against ONE shared candidate list (gfx950 / CDNA4).
+//
+// What it replaces.  Lucene's exact fallback — AbstractKnnVectorQuery.exactSearch driving
+// JVectorFloatVectorValues.scorer(q) / JVectorVectorScorer.score (J/JVectorFloatVectorValues.java:189-191,
+// J/JVectorVectorScorer.java:36-53) — scores ONE query against the docs of ONE filter.  It is the path the reference takes
+// at exactly the selectivities where a graph search stops paying (JVectorReader.search reports visited + expanded,
+// J/JVectorReader.java:202-207, and AbstractKnnVectorQuery discards the approximate result once that reaches the filter's
+// cardinality).  B concurrent queries under the SAME filter (a tenant, an ACL, a facet) are  Q[B x d] . C^T[d x |filter|]
+// — the one dense contraction with a shared operand on this path (BASELINE.json configs[4]).
+//
+// How.  The answer must equal the oracle's exact scan: ids, order (score desc, doc asc) and score BITS of the canonical
+// fp32 accumulation (jv_dev_common.h score_rows).  So the matrix cores only PRE-FILTER:
+//   1. a bf16 mirror of the vectors ([n][kp] bf16 + |v|^2 per row, built once per index, 288 GB of HBM make it affordable)
+//      and the bf16 queries feed v_mfma_f32_32x32x16_bf16: a[q][c] ~ q.c with a PROVEN bound
+//          |a - q.c| <= kappa |q| |c|,   kappa = (2u + u^2) + accumulation slack,  u = 2^-8 (bf16 round-to-nearest-even)
+//      (Cauchy-Schwarz over the per-element relative errors; DESIGN.md "Batched exact scorer" has the derivation and
+//      tests/test_gpu_xb.py checks  lower <= canonical value <= upper  against float64 for every pair it computes);
+//   2. pass A runs the tile kernel over a strided SAMPLE of the candidates and a radix select takes, per query, the k-th
+//      largest LOWER bound: at least k candidates are certainly that good;
+//   3. pass B runs the tile kernel over ALL candidates and keeps those whose UPPER bound reaches that value — a superset of
+//      the true top k, ties and fp32 rounding plateaus included (the slack terms);
+//   4. the survivors (typically a few hundred per query) are re-scored in the canonical fp32 order and the top k taken by
+//      (score desc, doc asc) — bit-equal to jvo_score_ordinals + a sort.  A query whose survivor list overflows is
+//      re-scored against the whole list (exactness never depends on the bound being tight).
+//
+// Tile kernel: 128 candidates x 128 queries per 256-thread workgroup, K step 64, both operands staged with
+// global_load_lds (16 B per lane, candidate rows GATHERED by ordinal through the per-lane source address), double-buffered
+// LDS with an XOR-swizzled image (conflict-free ds_read_b128 fragment reads), 4 waves x (2 x 2) 32x32 accumulators.
+// Bound: HBM (1.5 KB of bf16 per candidate, read once) against 256 FLOP per byte at B = 256 — both roofs in reach; bench.py
+// reports flops vs the dense bf16 peak and bytes vs 8 TB/s.
+//
+// Compile with -ffp-contract=off (the canonical re-score); the pre-filter's arithmetic is covered by its slack terms.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "jv_device.h"
+
+#include "jv_dev_common.h"
+#include "jv_xb.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define XB_TM 128          // candidates per tile
+#define XB_TN 128          // queries per tile (panel)
+#define XB_BK 64           // k per step (128 B of bf16 per row)
+#define XB_GROUP 1152      // LDS bytes per 8-row group: 8 x 128 B + 128 B so that groups alternate between the two halves of the 256-B bank row
+#define XB_OPER (16 * XB_GROUP)  // one operand tile (128 rows)
+#define XB_BUF (2 * XB_OPER)     // candidates + queries of one k step
+#define XB_AUX (2 * XB_BUF)      // byte offset of the per-row constants behind the two buffers
+#define XB_LDS (XB_AUX + 3 * XB_TN * 4)
+
+// ---------------------------------------------------------------------------------------------
+// fp32 rows -> bf16 mirror (+ squared norms).  One wave per row, 8-B stores; used for the index's vectors (once per index)
+// and for every batch's queries.  `scalar` = rows not 16-B aligned (the caller's query matrix with d % 4 != 0).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void jvx_mirror_kernel(const float* __restrict__ src, long long rows, int d, long long src_stride,
+                                                         int kp, uint16_t* __restrict__ dst, float* __restrict__ norm2, int scalar) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long nw = (long long)gridDim.x * 4;
+    for (long long r = wave; r < rows; r += nw) {
+        const float* row = src + r * src_stride;
+        float acc = 0.0f;
+        for (int p = lane; p * 4 < kp; p += 64) {
+            float x[4];
+            if (!scalar && p * 4 + 3 < d) {
+                const f32x4 v = *(const f32x4*)(row + p * 4);
+                x[0] = v[0], x[1] = v[1], x[2] = v[2], x[3] = v[3];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; e++) x[e] = (p * 4 + e) < d ? row[p * 4 + e] : 0.0f;
+            }
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                o[e] = (__bf16)x[e];
+                acc = fmaf(x[e], x[e], acc);
+            }
+            *(bf16x4*)(dst + r * (long long)kp + p * 4) = o;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (lane == 0) norm2[r] = acc;
+    }
+}
+
+extern "C" hipError_t jvk_xb_mirror(const float* src, long long rows, int d, long long src_stride, int kp, uint16_t* dst, float* norm2,
+                                    int scalar, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    const long long want = (rows + 3) / 4;
+    const int blocks = (int)(want < 65536 ? want : 65536);
+    jvx_mirror_kernel<<<blocks, 256, 0, s>>>(src, rows, d, src_stride, kp, dst, norm2, scalar);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// doc filter -> ascending ordinal list (the reference's acceptOrds lambda, J/JVectorReader.java:157-163, evaluated once for
+// the whole batch): per-block counts, one-workgroup scan, scatter.
+// ---------------------------------------------------------------------------------------------
+#define XB_LIST_PER_BLOCK 2048
+__device__ __forceinline__ bool xb_accepts(const int32_t* ord2doc, int n, const uint64_t* accept, long long accept_docs, int i) {
+    if (i >= n) return false;
+    const int doc = ord2doc ? ord2doc[i] : i;
+    return doc >= 0 && (long long)doc < accept_docs && ((accept[doc >> 6] >> (doc & 63)) & 1ull);
+}
+__global__ __launch_bounds__(256) void jvx_list_count_kernel(const int32_t* __restrict__ ord2doc, int n, const uint64_t* __restrict__ accept,
+                                                             long long accept_docs, int32_t* __restrict__ counts) {
+    __shared__ int s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    int c = 0;
+    const int base = blockIdx.x * XB_LIST_PER_BLOCK;
+    for (int j = 0; j < XB_LIST_PER_BLOCK / 256; j++) c += xb_accepts(ord2doc, n, accept, accept_docs, base + j * 256 + threadIdx.x) ? 1 : 0;
+    c = jv_wave_sum_int(c);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&s_cnt, c);
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = s_cnt;
+}
+// counts[nb] -> exclusive offsets in place, total in counts[nb]
+__global__ __launch_bounds__(1024) void jvx_list_scan_kernel(int32_t* __restrict__ counts, int nb) {
+    __shared__ int s_part[1024];
+    __shared__ int s_carry;
+    const int t = threadIdx.x;
+    if (t == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nb; base += 1024) {
+        const int i = base + t;
+        const int v = i < nb ? counts[i] : 0;
+        s_part[t] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const int add = t >= off ? s_part[t - off] : 0;
+            __syncthreads();
+            s_part[t] += add;
+            __syncthreads();
+        }
+        const int incl = s_part[t];
+        const int carry = s_carry;
+        if (i < nb) counts[i] = carry + incl - v;
+        __syncthreads();
+        if (t == 1023) s_carry = carry + incl;
+        __syncthreads();
+    }
+    if (t == 0) counts[nb] = s_carry;
+}
+__global__ __launch_bounds__(256) void jvx_list_scatter_kernel(const int32_t* __restrict__ ord2doc, int n, const uint64_t* __restrict__ accept,
+                                                               long long accept_docs, const int32_t* __restrict__ offsets,
+                                                               int32_t* __restrict__ out) {
+    __shared__ int s_wave[4];
+    const int base = blockIdx.x * XB_LIST_PER_BLOCK;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int pos = offsets[blockIdx.x];
+    for (int j = 0; j < XB_LIST_PER_BLOCK / 256; j++) {
+        const int i = base + j * 256 + threadIdx.x;
+        const bool acc = xb_accepts(ord2doc, n, accept, accept_docs, i);
+        const unsigned long long m = __ballot(acc);
+        if (lane == 0) s_wave[w] = __popcll(m);
+        __syncthreads();
+        int before = 0, all = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int c = s_wave[k];
+            before += k < w ? c : 0;
+            all += c;
+        }
+        if (acc) out[pos + before + __popcll(m & ((1ull << lane) - 1ull))] = i;
+        pos += all;
+        __syncthreads();
+    }
+}
+extern "C" hipError_t jvk_xb_build_list(const JvIndexDev* ix, const uint64_t* d_accept, long long accept_docs, int32_t* d_counts,
+                                        int32_t* d_list, hipStream_t s) {
+    if (ix->n <= 0) return hipSuccess;
+    const int nb = (ix->n + XB_LIST_PER_BLOCK - 1) / XB_LIST_PER_BLOCK;
+    jvx_list_count_kernel<<<nb, 256, 0, s>>>(ix->ord2doc, ix->n, d_accept, accept_docs, d_counts);
+    jvx_list_scan_kernel<<<1, 1024, 0, s>>>(d_counts, nb);
+    jvx_list_scatter_kernel<<<nb, 256, 0, s>>>(ix->ord2doc, ix->n, d_accept, accept_docs, d_counts, d_list);
+    return hipGetLastError();
+}
+extern "C" int jvk_xb_list_blocks(int n) { return (n + XB_LIST_PER_BLOCK - 1) / XB_LIST_PER_BLOCK; }
+
+// ---------------------------------------------------------------------------------------------
+// The tile kernel.  D[query][candidate] = sum_k Qb[query][k] Vb[ord(candidate)][k] on v_mfma_f32_32x32x16_bf16:
+// A operand = queries (accumulator rows), B operand = candidates (accumulator column = lane & 31), so that a lane owns ONE
+// candidate and 16 queries per accumulator: sample rows are written coalesced over candidates, and a candidate's norm is
+// one register.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void xb_glds16(const char* g, unsigned char* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+// quality value v (higher = better, the order of the final score) and half-width e of the interval that contains the
+// CANONICAL fp32 raw value (oracle/jv_oracle.c jvo_raw_dot / jvo_raw_l2 / the cosine quotient): see the header.
+__device__ __forceinline__ void xb_bounds(int sim, float a, float qn, float qn2, float cn, float cn2, float kappa, float& v, float& e) {
+    const float nn = qn * cn;
+    if (sim == 0) {
+        const float ss = qn2 + cn2;
+        v = -(ss - 2.0f * a);
+        e = 2.0f * kappa * nn + 1.2e-5f * ss + 1e-6f;
+    } else if (sim == 1) {
+        v = a;
+        e = kappa * nn + 1e-6f;
+    } else {
+        v = a / nn;               // nn == 0: NaN / inf — such a candidate always survives (the tests below are written for that)
+        e = kappa + 2e-5f;
+    }
+    e = e * 1.000001f + 4e-7f * fabsf(v);
+}
+
+template <int MODE>  // 0: sample pass (write lower bounds), 1: filter pass (append survivors), 2: diagnostics (write UPPER bounds)
+__global__ __launch_bounds__(256, 2) void jvx_tile_kernel(const JvXbTileArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // XCD-aware order: the blocks of one XCD (blockIdx % 8) take a contiguous run of (tile, panel) pairs, so the panels of a
+    // candidate tile meet in one L2 (bijective for any grid size)
+    const int nb = gridDim.x;
+    int L;
+    {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, q = nb >> 3, r = nb & 7;
+        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int tile = L / a.panels, panel = L - tile * a.panels;
+    const int kp = a.kp, nk = kp / XB_BK;
+
+    // ---- staging addresses: lane l of an instruction writes LDS piece l of an 8-row group (row l >> 3, physical 16-B piece
+    //      l & 7) and fetches the LOGICAL piece (l & 7) ^ (l >> 3) of that row — swizzle on the source, linear destination ----
+    const int lr = lane >> 3, lp = (lane & 7) ^ lr;
+    const char* cptr[4];
+    const char* qptr[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int row = 8 * (4 * w + i) + lr;
+        long long ci = (long long)tile * XB_TM + row;
+        if (ci >= a.rows) ci = a.rows - 1;
+        long long idx = ci * a.cstride;
+        if (idx >= a.C) idx = a.C - 1;
+        int ord = a.ords ? a.ords[idx] : (int)idx;
+        if (ord < 0 || ord >= a.n) ord = 0;  // (an invalid list entry: row 0 is staged in its place, the epilogue drops the column)
+        cptr[i] = (const char*)a.vb + (size_t)ord * (size_t)kp * 2 + lp * 16;
+        qptr[i] = (const char*)a.qb + (size_t)(panel * XB_TN + row) * (size_t)kp * 2 + lp * 16;
+    }
+    // ---- per-row constants of the epilogue: |q|, |q|^2, threshold ----
+    float* s_qn = (float*)(smem + XB_AUX);
+    float* s_qn2 = s_qn + XB_TN;
+    float* s_thr = s_qn2 + XB_TN;
+    if (tid < XB_TN) {
+        const int q = panel * XB_TN + tid;
+        const float n2 = q < a.B ? a.qnorm2[q] : 0.0f;
+        s_qn2[tid] = n2;
+        s_qn[tid] = sqrtf(n2);
+        s_thr[tid] = (MODE == 1 && q < a.B) ? a.thr[q] : 0.0f;
+    }
+    // ---- fragment read offsets ----
+    const int wn = w & 1, wm = w >> 1, h = lane >> 5, r31 = lane & 31;
+    int qoff[2], coff[2], qx[2], cx[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int rq = wn * 64 + t * 32 + r31, rc = wm * 64 + t * 32 + r31;
+        qoff[t] = XB_OPER + (rq >> 3) * XB_GROUP + (rq & 7) * 128;
+        coff[t] = (rc >> 3) * XB_GROUP + (rc & 7) * 128;
+        qx[t] = rq & 7;
+        cx[t] = rc & 7;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int n = 0; n < 2; n++)
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[n][m][e] = 0.0f;
+
+    auto stage = [&](int s, int b) {
+        unsigned char* base = smem + b * XB_BUF;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            xb_glds16(cptr[i] + (size_t)s * 128, base + (4 * w + i) * XB_GROUP);
+            xb_glds16(qptr[i] + (size_t)s * 128, base + XB_OPER + (4 * w + i) * XB_GROUP);
+        }
+    };
+    stage(0, 0);
+    for (int s = 0; s < nk; s++) {
+        const int b = s & 1;
+        if (s + 1 < nk) {
+            stage(s + 1, b ^ 1);
+            asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        const unsigned char* base = smem + b * XB_BUF;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            bf16x8 fq[2], fc[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                fq[t] = *(const bf16x8*)(base + qoff[t] + (((2 * kk + h) ^ qx[t]) << 4));
+                fc[t] = *(const bf16x8*)(base + coff[t] + (((2 * kk + h) ^ cx[t]) << 4));
+            }
+#pragma unroll
+            for (int n = 0; n < 2; n++)
+#pragma unroll
+                for (int m = 0; m < 2; m++) acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[n], fc[m], acc[n][m], 0, 0, 0);
+        }
+        // every fragment read of this buffer has RETURNED before any wave may restage it (the compiler places its own
+        // lgkmcnt wait at the first use, which it is free to sink below a barrier it does not understand)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+
+    // ---- epilogue ----
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+        const int col = wm * 64 + m * 32 + r31;
+        const long long ci = (long long)tile * XB_TM + col;
+        const bool cin = ci < a.rows;
+        long long idx = (cin ? ci : a.rows - 1) * a.cstride;
+        if (idx >= a.C) idx = a.C - 1;
+        int ord = a.ords ? a.ords[idx] : (int)idx;
+        const bool cval = cin && ord >= 0 && ord < a.n;
+        if (!cval) ord = 0;
+        const float cn2 = a.vnorm2[ord], cn = sqrtf(cn2);
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) {
+                const int row = wn * 64 + n * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                const int q = panel * XB_TN + row;
+                float v, e;
+                xb_bounds(a.sim, acc[n][m][reg], s_qn[row], s_qn2[row], cn, cn2, a.kappa, v, e);
+                if (MODE == 0 || MODE == 2) {
+                    if (cin && q < a.B) a.sample[(size_t)q * a.sample_ld + ci] = !cval ? -__builtin_inff() : (MODE == 0 ? v - e : v + e);
+                } else {
+                    // NaN-proof: "certainly worse" must be TRUE to drop a candidate
+                    if (cval && q < a.B && !(v + e < s_thr[row])) {
+                        const int pos = atomicAdd(a.surv_cnt + q, 1);
+                        if (pos < a.surv_cap) a.surv[(size_t)q * a.surv_cap + pos] = (int32_t)idx;
+                    }
+                }
+            }
+        }
+    }
+}
+
+extern "C" hipError_t jvk_xb_tile(const JvXbTileArgs* a, int mode, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)jvx_tile_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, XB_LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)jvx_tile_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, XB_LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)jvx_tile_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, XB_LDS);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    if (a->rows <= 0 || a->B <= 0) return hipSuccess;
+    const long long tiles = ((long long)a->rows + XB_TM - 1) / XB_TM;
+    const long long nb = tiles * a->panels;
+    if (nb > 0x7fffffffll) return hipErrorInvalidValue;
+    if (mode == 0) jvx_tile_kernel<0><<<(int)nb, 256, XB_LDS, s>>>(*a);
+    else if (mode == 1) jvx_tile_kernel<1><<<(int)nb, 256, XB_LDS, s>>>(*a);
+    else jvx_tile_kernel<2><<<(int)nb, 256, XB_LDS, s>>>(*a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// k-th largest of a query's sample row: 4-pass radix select on the order-preserving integer image of the floats
+// (NaNs sort above everything: a NaN threshold makes every candidate survive — correct, merely slow).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t xb_ukey(float f) {
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__global__ __launch_bounds__(256) void jvx_kth_kernel(const float* __restrict__ sample, int ld, int S, int k, float* __restrict__ thr) {
+    __shared__ int s_hist[256];
+    __shared__ uint32_t s_prefix;
+    __shared__ int s_k;
+    const int q = blockIdx.x, t = threadIdx.x;
+    if (S < k) {
+        if (t == 0) thr[q] = -__builtin_inff();
+        return;
+    }
+    const float* row = sample + (size_t)q * ld;
+    if (t == 0) s_prefix = 0u, s_k = k;
+    uint32_t mask = 0u;
+    for (int pass = 0; pass < 4; pass++) {
+        const int shift = 24 - 8 * pass;
+        s_hist[t] = 0;
+        __syncthreads();
+        const uint32_t prefix = s_prefix;
+        for (int i = t; i < S; i += 256) {
+            const uint32_t u = xb_ukey(row[i]);
+            if ((u & mask) == prefix) atomicAdd(&s_hist[(u >> shift) & 255], 1);
+        }
+        __syncthreads();
+        if (t == 0) {
+            int kk = s_k, cum = 0, b = 255;
+            for (; b > 0; b--) {
+                if (cum + s_hist[b] >= kk) break;
+                cum += s_hist[b];
+            }
+            s_k = kk - cum;
+            s_prefix = prefix | ((uint32_t)b << shift);
+        }
+        mask |= 255u << shift;
+        __syncthreads();
+    }
+    if (t == 0) {
+        const uint32_t u = s_prefix;
+        thr[q] = __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+    }
+}
+extern "C" hipError_t jvk_xb_kth(const float* sample, int ld, int S, int k, float* thr, int B, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    jvx_kth_kernel<<<B, 256, 0, s>>>(sample, ld, S, k, thr);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Canonical re-score of a query's survivors (or of the whole list) + top k by (score desc, doc asc): one 256-thread
+// workgroup per query; a wave scores 64 rows per round with score_rows (the arithmetic of every exact score in this engine),
+// keys that beat the running k-th best collect in an LDS buffer that is bitonic-sorted and cut back to k when it fills.
+// ---------------------------------------------------------------------------------------------
+#define XB_KCAP 4096
+__device__ __forceinline__ void xb_sort_desc(int64_t* keys, int32_t* pay, int n_pow2, int tid) {
+    for (int size = 2; size <= n_pow2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = tid; i < (n_pow2 >> 1); i += 256) {
+                const int lo = (i / stride) * (stride << 1) + (i % stride);
+                const int hi = lo + stride;
+                const bool desc = ((lo & size) == 0);
+                const int64_t x = keys[lo], y = keys[hi];
+                if ((x < y) == desc) {
+                    keys[lo] = y;
+                    keys[hi] = x;
+                    const int32_t p = pay[lo];
+                    pay[lo] = pay[hi];
+                    pay[hi] = p;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int NCHT>
+__global__ __launch_bounds__(256) void jvx_rescore_kernel(const JvIndexDev ix, const JvXbRescoreArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int q = blockIdx.x;
+    float* q_lds = (float*)smem;
+    size_t off = (size_t)ix.nch * 64 * sizeof(float);
+    int64_t* keys = (int64_t*)(smem + off);
+    off += (size_t)XB_KCAP * 8;
+    int32_t* pay = (int32_t*)(smem + off);
+    off += (size_t)XB_KCAP * 4;
+    float* todo_score = (float*)(smem + off) + w * 64;
+    off += 4 * 64 * 4;
+    int32_t* todo = (int32_t*)(smem + off) + w * 64;
+    off += 4 * 64 * 4;
+    int* s_cnt = (int*)(smem + off);
+
+    const float* query = a.queries + (size_t)q * ix.d;
+    for (int i = tid; i < ix.nch * 64; i += 256) q_lds[i] = i < ix.d ? query[i] : 0.0f;
+    if (tid == 0) *s_cnt = 0;
+    __syncthreads();
+    float qnorm2 = 0.0f;
+    if (ix.sim == 2) qnorm2 = query_norm2(ix, q_lds, lane), qnorm2 = __shfl(qnorm2, 0, 64);
+
+    const int nsurv = a.surv_cnt ? a.surv_cnt[q] : 0;
+    const bool all = a.force_all || !a.surv_cnt || nsurv > a.surv_cap;
+    const int total = all ? a.C : nsurv;
+    const int k = a.topK;
+    int64_t thr_key = KEY_MIN;
+    if (tid == 0 && a.out_info) {
+        atomicAdd((unsigned long long*)a.out_info + 0, (unsigned long long)total);
+        if (all && a.surv_cnt && !a.force_all) atomicAdd((unsigned long long*)a.out_info + 1, 1ull);
+    }
+    for (int base = 0; base < total; base += 256) {
+        const int idx = base + tid;
+        int ord = -1, doc = -1;
+        if (idx < total) {
+            const int ci = all ? idx : a.surv[(size_t)q * a.surv_cap + idx];
+            ord = a.ords ? a.ords[ci] : ci;
+            if (ord >= 0 && ord < ix.n) doc = ix.ord2doc ? ix.ord2doc[ord] : ord;
+        }
+        const bool ok = doc >= 0;
+        const unsigned long long mk = __ballot(ok);
+        const int m = __popcll(mk);
+        const int pos = __popcll(mk & ((1ull << lane) - 1ull));
+        if (ok) todo[pos] = ord;
+        __syncthreads();
+        if (m > 0) score_rows<NCHT>(ix, q_lds, todo, m, todo_score, qnorm2, ix.score_scale, lane);
+        __syncthreads();
+        int64_t key = KEY_MIN;
+        if (ok) key = make_key(todo_score[pos], doc);
+        const bool take = ok && key > thr_key;
+        const unsigned long long tk = __ballot(take);
+        int wbase = 0;
+        if (lane == 0 && tk) wbase = atomicAdd(s_cnt, __popcll(tk));
+        wbase = __shfl(wbase, 0, 64);
+        if (take) {
+            const int p = wbase + __popcll(tk & ((1ull << lane) - 1ull));
+            keys[p] = key;
+            pay[p] = ord;
+        }
+        __syncthreads();
+        const int cnt = *s_cnt;
+        if (cnt + 256 > XB_KCAP) {  // (workgroup-uniform) sort, keep the best k, raise the bar
+            int np = 1;
+            while (np < cnt) np <<= 1;
+            for (int i = cnt + tid; i < np; i += 256) keys[i] = KEY_MIN, pay[i] = -1;
+            __syncthreads();
+            xb_sort_desc(keys, pay, np, tid);
+            const int keep = cnt < k ? cnt : k;
+            if (keep >= k) thr_key = keys[k - 1];
+            __syncthreads();
+            if (tid == 0) *s_cnt = keep;
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    const int cnt = *s_cnt;
+    int np = 1;
+    while (np < cnt) np <<= 1;
+    for (int i = cnt + tid; i < np; i += 256) keys[i] = KEY_MIN, pay[i] = -1;
+    __syncthreads();
+    if (cnt > 1) xb_sort_desc(keys, pay, np, tid);
+    const int outn = cnt < k ? cnt : k;
+    for (int i = tid; i < k; i += 256) {
+        const bool v = i < outn;
+        const int64_t key = v ? keys[i] : 0;
+        if (a.out_nodes) a.out_nodes[(size_t)q * k + i] = v ? pay[i] : -1;
+        if (a.out_docs) a.out_docs[(size_t)q * k + i] = v ? key_node(key) : -1;
+        if (a.out_scores) a.out_scores[(size_t)q * k + i] = v ? key_score(key) : 0.0f;
+    }
+    if (tid == 0 && a.out_count) a.out_count[q] = outn;
+}
+
+extern "C" int jvk_xb_rescore_lds(const JvIndexDev* ix) { return ix->nch * 64 * 4 + XB_KCAP * 12 + 2 * 4 * 64 * 4 + 16; }
+extern "C" hipError_t jvk_xb_rescore(const JvIndexDev* ix, const JvXbRescoreArgs* a, int nq, hipStream_t s) {
+    if (nq <= 0) return hipSuccess;
+    const int lds = jvk_xb_rescore_lds(ix);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)jvx_rescore_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)jvx_rescore_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)jvx_rescore_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)jvx_rescore_kernel<24>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const bool fixed = ix->nvq_M == 0 && ix->vectors && ix->stride == ix->nch * 64;
+    if (fixed && ix->nch == 2) jvx_rescore_kernel<2><<<nq, 256, lds, s>>>(*ix, *a);
+    else if (fixed && ix->nch == 12) jvx_rescore_kernel<12><<<nq, 256, lds, s>>>(*ix, *a);
+    else if (fixed && ix->nch == 24) jvx_rescore_kernel<24><<<nq, 256, lds, s>>>(*ix, *a);
+    else jvx_rescore_kernel<0><<<nq, 256, lds, s>>>(*ix, *a);
+    return hipGetLastError();
+}

@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol(pkg):
     assert sorted(pkg.binding.ABI_SYMBOLS) == declared, "binding.ABI_SYMBOLS must list exactly the header's functions"
     for sym in declared:
         assert hasattr(lib, sym), f"{sym} is declared in include/jvgpu.h but not exported"
-    assert lib.jv_abi_version() == 3
+    assert lib.jv_abi_version() == 4
 
 
 def test_desc_struct_layout_matches_header(pkg):

@@ -1,0 +1,268 @@
+"""The batched exact scorer (jv_score_ordinals_batch, ABI v4): B queries against ONE shared candidate set.
+
+Replaces the batched form of Lucene's exact fallback (AbstractKnnVectorQuery.exactSearch over JVectorVectorScorer.score,
+J/JVectorVectorScorer.java:36-53, reached through J/JVectorReader.java:202-207).  Bar: ids, order (score desc, doc asc —
+Lucene's HitQueue) and score BITS equal the oracle's jvo_score_ordinals + a sort, whatever the bf16 matrix-core pass
+discarded on the way; and the interval that pass computes must contain the exact value for every pair."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _index(b, base, sim, scale=1.0, ord2doc=None, max_doc=0):
+    n = base.shape[0]
+    ix = b.IndexData(vectors=base, adj=np.full((n, 4), -1, dtype=np.int32), entry_node=0, similarity=sim, score_scale=scale)
+    if ord2doc is not None:
+        ix.ord2doc = ord2doc.astype(np.int32)
+        ix.max_doc = int(max_doc)
+    return ix
+
+
+def _want(orc, q, ords, docs_of, k):
+    """the oracle's exact scan: jvo_score_ordinals + (score desc, doc asc)"""
+    sc = orc.score_ordinals(q, ords)
+    docs = docs_of[ords]
+    order = np.lexsort((docs, -sc.astype(np.float64)))[:k]
+    # -score as float64 is exact for float32 inputs; equal float32 scores stay equal
+    return ords[order], docs[order], sc[order]
+
+
+def _check(got, orc, queries, ords, docs_of, k, what):
+    nodes, docs, scores, count, info = got
+    for i in range(queries.shape[0]):
+        wn, wd, ws = _want(orc, queries[i], ords, docs_of, k)
+        m = len(wn)
+        assert count[i] == m, (what, i, count[i], m)
+        assert np.array_equal(docs[i, :m], wd), f"{what}: docs of query {i} differ from the oracle's exact scan"
+        assert np.array_equal(nodes[i, :m], wn), f"{what}: ordinals of query {i} differ"
+        assert np.array_equal(scores[i, :m].view(np.uint32), ws.view(np.uint32)), f"{what}: score bits of query {i} differ"
+        assert (nodes[i, m:] == -1).all() and (docs[i, m:] == -1).all() and (scores[i, m:] == 0).all()
+
+
+@pytest.mark.parametrize("d,sim,scale", [(64, 0, 1.0), (128, 1, 1.0), (128, 1, 2.0), (100, 2, 1.0), (768, 0, 1.0), (70, 1, 1.0)])
+def test_batched_exact_scorer_equals_the_oracle_scan(pkg, pyoracle, d, sim, scale):
+    """doc filters of several selectivities over a permuted, sparse doc-id space with deleted ordinals; explicit ordinal lists
+    (with invalid entries); no filter at all; 1 ... 300 queries; topK 1 ... 100; with and without the matrix-core pass."""
+    b = pkg.binding
+    rng = np.random.default_rng(d * 10 + sim)
+    n = 30000
+    base = pkg.datagen.splitmix_uniform(100 + d, n, d)
+    if sim != 0:
+        base = base - np.float32(0.5)
+    max_doc = n + n // 2
+    perm = rng.permutation(max_doc)[:n].astype(np.int32)
+    dead = rng.random(n) < 0.03
+    ord2doc = np.where(dead, -1, perm).astype(np.int32)
+    ix = _index(b, base, sim, scale, ord2doc, max_doc)
+    gpu = b.GpuIndex(ix)
+    orc = pyoracle.Oracle(b, ix)
+    docs_of = ord2doc
+    queries = pkg.datagen.splitmix_uniform(7, 300, d)
+    if sim != 0:
+        queries = queries - np.float32(0.5)
+    for sel, nq, k in [(0.5, 37, 10), (0.1, 300, 10), (0.1, 5, 100), (0.01, 130, 1), (0.003, 64, 100)]:
+        acc_docs = np.nonzero(rng.random(max_doc) < sel)[0]
+        words = b.accept_words(acc_docs, max_doc)
+        accepted = np.zeros(max_doc, dtype=bool)
+        accepted[acc_docs] = True
+        ords = np.nonzero((ord2doc >= 0) & accepted[np.maximum(ord2doc, 0)])[0].astype(np.int32)
+        got = gpu.score_ordinals_batch(queries[:nq], k, accept=words, accept_num_docs=max_doc)
+        assert got[4][0] == len(ords), "candidate count = accepted live ordinals"
+        if len(ords) >= 2048:
+            assert got[4][1] > 0, "the matrix-core pass must have run"
+        _check(got, orc, queries[:nq], ords, docs_of, k, f"filter {sel}")
+        plain = gpu.score_ordinals_batch(queries[:nq], k, accept=words, accept_num_docs=max_doc, flags=b.XB_NO_PREFILTER)
+        assert plain[4][1] == 0
+        for a, c in zip(got[:4], plain[:4]):
+            assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, c.view(np.uint32) if c.dtype == np.float32 else c)
+    # explicit list with invalid entries and a deleted ordinal
+    lst = np.concatenate([rng.choice(n, 5000, replace=False), [-1, n + 5, int(np.nonzero(dead)[0][0])]]).astype(np.int32)
+    valid = lst[(lst >= 0) & (lst < n)]
+    valid = valid[ord2doc[valid] >= 0]
+    got = gpu.score_ordinals_batch(queries[:20], 10, ordinals=lst)
+    _check(got, orc, queries[:20], valid, docs_of, 10, "explicit list")
+    # neither: every live ordinal
+    live = np.nonzero(ord2doc >= 0)[0].astype(np.int32)
+    got = gpu.score_ordinals_batch(queries[:9], 10)
+    _check(got, orc, queries[:9], live, docs_of, 10, "all ordinals")
+    gpu.close()
+
+
+def test_the_bound_contains_the_exact_value(pkg):
+    """[lower, upper] of the bf16 pass against float64 for every pair: uniform, centred, badly scaled and near-duplicate rows —
+    the property the pre-filter's correctness rests on — and not vacuously (width <= 2.2 kappa |q||c| (x2 for L2) + slack)."""
+    b = pkg.binding
+    lib = b.load_library()
+    lib.jv_xb_debug_bounds.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.jv_xb_debug_bounds.restype = C.c_int
+    rng = np.random.default_rng(5)
+    for d in (64, 200, 768, 1536):
+        n, nq = 4096, 130
+        base = rng.standard_normal((n, d)).astype(np.float32)
+        base[:512] = np.abs(base[:512]) * 3 + 1                      # far from the origin: worst case for the L2 cancellation
+        base[512:1024] *= np.float32(1e-3)
+        base[1024:1536] *= np.float32(1e3)
+        base[1536:1600] = base[1536] + rng.standard_normal((64, d)).astype(np.float32) * np.float32(1e-4)   # near-duplicates
+        q = rng.standard_normal((nq, d)).astype(np.float32)
+        q[:16] = base[1536:1552] + np.float32(1e-5)
+        q[16:32] = np.abs(q[16:32]) * 3 + 1
+        ords = rng.permutation(n)[:3000].astype(np.int32)
+        for sim in (0, 1, 2):
+            gpu = b.GpuIndex(_index(b, base, sim))
+            lo = np.zeros((nq, len(ords)), dtype=np.float32)
+            hi = np.zeros_like(lo)
+            kappa = C.c_float(0)
+            rc = lib.jv_xb_debug_bounds(gpu.handle, q.ctypes.data, nq, ords.ctypes.data, len(ords), lo.ctypes.data, hi.ctypes.data, C.byref(kappa))
+            assert rc == 0, lib.jv_last_error()
+            q64, c64 = q.astype(np.float64), base[ords].astype(np.float64)
+            dots = q64 @ c64.T
+            qn, cn = np.linalg.norm(q64, axis=1)[:, None], np.linalg.norm(c64, axis=1)[None, :]
+            if sim == 0:
+                true = -(qn ** 2 + cn ** 2 - 2 * dots)
+                width = 2 * 2.2 * kappa.value * qn * cn + 3e-5 * (qn ** 2 + cn ** 2) + 1e-5
+            elif sim == 1:
+                true = dots
+                width = 2.2 * kappa.value * qn * cn + 1e-5
+            else:
+                true = dots / (qn * cn)
+                width = 2.2 * kappa.value + 1e-4
+            assert (lo <= true).all(), (d, sim, float((lo - true).max()))
+            assert (hi >= true).all(), (d, sim, float((true - hi).max()))
+            assert ((hi.astype(np.float64) - lo) <= width * 1.05 + 1e-6 * np.abs(true)).all(), (d, sim)
+            # how much of the interval the bf16 error actually uses (printed with -s; the bound must hold, not be tight)
+            mid = (hi.astype(np.float64) + lo) / 2
+            half = (hi.astype(np.float64) - lo) / 2
+            used = float((np.abs(mid - true) / np.maximum(half, 1e-30)).max())
+            print(f"d={d} sim={sim}: worst |mid - true| / half-width = {used:.3f}")
+            assert used <= 1.0
+            gpu.close()
+
+
+def test_ties_and_duplicates_keep_lucenes_order(pkg, pyoracle):
+    """grid-valued vectors: hundreds of candidates share a score exactly; among equal scores the LOWER DOC wins (HitQueue),
+    not the lower ordinal — the doc ids are a permutation — and the k-th / (k+1)-th tie must survive the pre-filter."""
+    b = pkg.binding
+    rng = np.random.default_rng(3)
+    n, d = 20000, 32
+    base = rng.integers(0, 3, size=(n, d)).astype(np.float32)
+    base[5000:5200] = base[5000]                       # 200 exact duplicates
+    ord2doc = rng.permutation(n).astype(np.int32)
+    queries = np.concatenate([base[5000:5004], rng.integers(0, 3, size=(60, d)).astype(np.float32)])
+    for sim in (0, 1, 2):
+        ix = _index(b, base, sim, 1.0, ord2doc, n)
+        gpu = b.GpuIndex(ix)
+        orc = pyoracle.Oracle(b, ix)
+        words = b.accept_words(np.arange(0, n, 2), n)
+        ords = np.nonzero(ord2doc % 2 == 0)[0].astype(np.int32)
+        for k in (1, 10, 150):
+            got = gpu.score_ordinals_batch(queries, k, accept=words, accept_num_docs=n)
+            _check(got, orc, queries, ords, ord2doc, k, f"ties sim={sim} k={k}")
+        gpu.close()
+
+
+def test_a_survivor_overflow_falls_back_to_the_full_scan(pkg, pyoracle):
+    """every candidate at (almost) the same distance: the bound cannot separate them, every query's survivor list
+    overflows and the canonical scan of the whole list answers — identically."""
+    b = pkg.binding
+    rng = np.random.default_rng(9)
+    n, d = 24000, 64
+    base = np.ones((n, d), dtype=np.float32) + rng.standard_normal((n, d)).astype(np.float32) * np.float32(1e-4)
+    ix = _index(b, base, 0)
+    gpu = b.GpuIndex(ix)
+    orc = pyoracle.Oracle(b, ix)
+    queries = np.ones((6, d), dtype=np.float32) * np.float32(1.5)
+    ords = np.arange(n, dtype=np.int32)
+    got = gpu.score_ordinals_batch(queries, 10)
+    assert got[4][1] > 0 and got[4][3] == 6, got[4]
+    _check(got, orc, queries, ords, ords, 10, "overflow")
+    gpu.close()
+
+
+def test_device_pointer_form_and_argument_errors(pkg, pyoracle):
+    import torch
+    b = pkg.binding
+    dev = torch.device("cuda", 0)
+    n, d, nq, k = 50000, 128, 256, 10
+    base = pkg.datagen.splitmix_uniform(21, n, d)
+    ix = _index(b, base, 0)
+    gpu = b.GpuIndex(ix)
+    orc = pyoracle.Oracle(b, ix)
+    queries = pkg.datagen.splitmix_uniform(22, nq, d)
+    acc = np.arange(0, n, 7)
+    words = b.accept_words(acc, n)
+    tq = torch.from_numpy(queries).to(dev)
+    tw = torch.from_numpy(words.view(np.int64)).to(dev)
+    o_nodes = torch.empty((nq, k), dtype=torch.int32, device=dev)
+    o_docs = torch.empty((nq, k), dtype=torch.int32, device=dev)
+    o_scores = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    o_count = torch.empty((nq,), dtype=torch.int32, device=dev)
+    s = torch.cuda.Stream(dev)
+    with torch.cuda.stream(s):
+        tq2 = tq * 1.0   # work on the caller's stream the call must be ordered behind
+        info = gpu.score_ordinals_batch_device(tq2.data_ptr(), nq, k, o_nodes.data_ptr(), o_docs.data_ptr(), o_scores.data_ptr(),
+                                               o_count.data_ptr(), d_accept=tw.data_ptr(), accept_num_docs=n, stream=s.cuda_stream,
+                                               want_info=True)
+        nodes = o_nodes.cpu().numpy()   # (on the same stream: ordered behind the library's work)
+        docs, scores, count = o_docs.cpu().numpy(), o_scores.cpu().numpy(), o_count.cpu().numpy()
+    assert info[0] == len(acc) and info[1] > 0
+    _check((nodes, docs, scores, count, info), orc, queries[:40], acc.astype(np.int32), np.arange(n, dtype=np.int32), k, "device form")
+    host = gpu.score_ordinals_batch(queries, k, accept=words, accept_num_docs=n)
+    assert np.array_equal(host[0], nodes) and np.array_equal(host[2].view(np.uint32), scores.view(np.uint32))
+    # the explicit-list device form does not wait for the host
+    tl = torch.from_numpy(acc.astype(np.int32)).to(dev)
+    gpu.score_ordinals_batch_device(tq.data_ptr(), nq, k, o_nodes.data_ptr(), o_docs.data_ptr(), o_scores.data_ptr(), o_count.data_ptr(),
+                                    d_ordinals=tl.data_ptr(), count=len(acc), stream=torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(o_nodes.cpu().numpy(), nodes)
+    for kk, code in ((0, b.JV_EINVAL), (b.XB_TOPK_MAX + 1, b.JV_EUNSUPPORTED)):
+        with pytest.raises(b.JvError) as e:
+            gpu.score_ordinals_batch(queries[:2], kk)
+        assert e.value.code == code
+    # fewer candidates than topK: short rows
+    got = gpu.score_ordinals_batch(queries[:3], 50, ordinals=np.arange(20, dtype=np.int32))
+    assert (got[3] == 20).all() and (got[0][:, 20:] == -1).all()
+    got = gpu.score_ordinals_batch(queries[:3], 5, ordinals=np.zeros(0, dtype=np.int32))
+    assert (got[3] == 0).all()
+    gpu.close()
+
+
+def test_two_million_docs_three_selectivities(pkg, pyoracle):
+    """>= 2M docs, selectivity 0.001 / 0.01 / 0.1, L2 / dot / cosine incl. score_scale 2 (Lucene MIP), 256
+    queries under one filter.  The oracle's scan checks a sample of the queries at every point; all 256 are checked against
+    the engine's own fp32 scan of the whole list (the arithmetic the oracle sample pins)."""
+    import torch
+    b = pkg.binding
+    dev = torch.device("cuda", 0)
+    n, d, nq, k = 2_000_000, 768, 256, 10
+    g = torch.Generator(device=dev)
+    g.manual_seed(42)
+    cen = torch.randn((2048, d), generator=g, device=dev)
+    base_t = cen[torch.randint(0, 2048, (n,), generator=g, device=dev)] + 0.35 * torch.randn((n, d), generator=g, device=dev)
+    q_t = cen[torch.randint(0, 2048, (nq,), generator=g, device=dev)] + 0.35 * torch.randn((nq, d), generator=g, device=dev)
+    base = base_t.cpu().numpy()
+    queries = q_t.cpu().numpy()
+    del base_t, q_t, cen
+    torch.cuda.empty_cache()
+    rng = np.random.default_rng(1)
+    ident = np.arange(n, dtype=np.int32)
+    for sim, scale in ((0, 1.0), (1, 1.0), (1, 2.0), (2, 1.0)):
+        ix = _index(b, base, sim, scale)
+        gpu = b.GpuIndex(ix)
+        orc = pyoracle.Oracle(b, ix)
+        for sel, sample in ((0.001, 24), (0.01, 12), (0.1, 4)):
+            acc = np.nonzero(rng.random(n) < sel)[0].astype(np.int32)
+            words = b.accept_words(acc, n)
+            got = gpu.score_ordinals_batch(queries, k, accept=words, accept_num_docs=n)
+            assert got[4][0] == len(acc)
+            if len(acc) >= 2048:
+                assert got[4][1] > 0 and got[4][3] == 0, got[4]
+                assert got[4][2] < 0.05 * nq * len(acc), f"the pre-filter must discard most candidates: {got[4]}"
+            _check(tuple(x[:sample] if x.ndim else x for x in got[:4]) + (got[4],), orc, queries[:sample], acc, ident, k,
+                   f"2M sim={sim} scale={scale} sel={sel}")
+            plain = gpu.score_ordinals_batch(queries, k, accept=words, accept_num_docs=n, flags=b.XB_NO_PREFILTER)
+            assert np.array_equal(got[0], plain[0]) and np.array_equal(got[2].view(np.uint32), plain[2].view(np.uint32))
+            print(f"sim={sim} scale={scale} sel={sel}: candidates {got[4][0]}, sample {got[4][1]}, re-scored per query {got[4][2] / nq:.0f}")
+        gpu.close()
