@@ -38,6 +38,7 @@ def load_library(path: str = LIB_PATH):
         lib.jvh_reader_close.argtypes = [vp]
         lib.jvh_reader_close.restype = None
         lib.jvh_query_search_leaf.argtypes = [vp, vp, i32, i32, i32, f32, f32, vp, vp, i32, vp, vp, vp, vp, vp]
+        lib.jvh_query_search_leaf_batch.argtypes = [vp, vp, i32, i32, i32, i32, f32, f32, vp, vp, i32, i32, C.c_double, vp, vp, vp, vp]
         lib.jvh_reader_search_plain_collector.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, vp]
         lib.jvh_reader_search_bytes.argtypes = [vp]
         lib.jvh_counters.argtypes = [vp]
@@ -131,6 +132,30 @@ class JVectorReader:
             None if fw is None else fw.ctypes.data, None if lw is None else lw.ctypes.data, self.max_doc,
             docs.ctypes.data, scores.ctypes.data, C.addressof(count), C.addressof(total), C.addressof(exact)))
         return docs[:count.value].tolist(), scores[:count.value].tolist(), total.value, bool(exact.value)
+
+    def search_leaf_batch(self, targets, k, over_query_factor=5, threshold=0.0, rerank_floor=0.0, filter_docs=None,
+                          filter_words=None, deleted_docs=(), exact_when_cheaper=False, crossover_selectivity=0.25):
+        """JVectorKnnFloatVectorQuery::searchLeafBatch: the per-leaf logic for MANY queries under one filter — every query gets
+        what search_leaf gives it (the graph search with visitLimit = cost and the exact fallback are one engine call each).
+        Returns (docs [nq][k], scores [nq][k], count [nq], used_exact [nq])."""
+        t = np.ascontiguousarray(targets, dtype=np.float32).reshape(-1, self.d)
+        nq = t.shape[0]
+        fw = filter_words if filter_words is not None else (None if filter_docs is None else binding.accept_words(filter_docs, self.max_doc))
+        lw = None
+        if len(deleted_docs):
+            live = np.ones(self.max_doc, dtype=bool)
+            live[list(deleted_docs)] = False
+            lw = binding.accept_words(np.nonzero(live)[0], self.max_doc)
+        docs = np.full((nq, max(k, 1)), -1, dtype=np.int32)
+        scores = np.zeros((nq, max(k, 1)), dtype=np.float32)
+        count = np.zeros(nq, dtype=np.int32)
+        exact = np.zeros(nq, dtype=np.int32)
+        _check(self.lib, self.lib.jvh_query_search_leaf_batch(
+            self.handle, t.ctypes.data, nq, self.d, k, over_query_factor, threshold, rerank_floor,
+            None if fw is None else fw.ctypes.data, None if lw is None else lw.ctypes.data, self.max_doc,
+            1 if exact_when_cheaper else 0, float(crossover_selectivity), docs.ctypes.data, scores.ctypes.data, count.ctypes.data,
+            exact.ctypes.data))
+        return docs, scores, count, exact.astype(bool)
 
     def search_plain_collector(self, target, k, accept_docs=None):
         t = np.ascontiguousarray(target, dtype=np.float32)

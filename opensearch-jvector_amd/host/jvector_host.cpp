@@ -434,6 +434,94 @@ std::vector<float> JVectorReader::scoreDocs(const std::string& field, const floa
     return out;
 }
 
+void JVectorReader::searchBatch(const std::string& field, const float* targets, int nq,
+                                std::vector<JVectorKnnCollector*>& collectors, const AcceptDocs* acceptDocs) {
+    const FieldEntry* fieldEntry = this->fieldEntry(field);
+    if (!fieldEntry) throw IllegalArgumentException("field not found: " + field);
+    if (nq <= 0) return;
+    if ((int)collectors.size() != nq) throw IllegalArgumentException("one collector per target");
+    JVectorKnnCollector* first = collectors[0];
+    for (JVectorKnnCollector* c : collectors)
+        if (c->k() != first->k() || c->getOverQueryFactor() != first->getOverQueryFactor() || c->getThreshold() != first->getThreshold() ||
+            c->getRerankFloor() != first->getRerankFloor() || c->visitLimit() != first->visitLimit())
+            throw IllegalArgumentException("searchBatch: the collectors must share k, overQueryFactor, threshold, rerankFloor and visitLimit");
+    const auto graphSearchStart = std::chrono::steady_clock::now();
+    const FixedBitSet* b = acceptDocs ? acceptDocs->bits() : nullptr;
+    const int topK = first->k();
+    const int rerankK = topK * first->getOverQueryFactor();
+    const size_t rows = (size_t)nq * (size_t)std::max(topK, 1);
+    std::vector<int32_t> nodes(rows), docs(rows), count((size_t)nq), stats((size_t)nq * JV_NUM_STATS), status((size_t)nq), flags((size_t)nq);
+    std::vector<float> scores(rows);
+    jv_search_params sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.struct_size = sizeof(sp);
+    sp.topK = topK;
+    sp.rerankK = rerankK;
+    sp.threshold = first->getThreshold();
+    sp.rerankFloor = first->getRerankFloor();
+    sp.accept_doc_words = b ? b->getBits() : nullptr;
+    sp.accept_num_docs = b ? b->length() : 0;
+    const int64_t limit = first->visitLimit();
+    sp.visit_limit = (limit > 0 && limit < INT32_MAX) ? limit : 0;
+    throwForStatus(jv_search_batch_ex(fieldEntry->index, targets, nq, &sp, nodes.data(), docs.data(), scores.data(), count.data(),
+                                      stats.data(), status.data(), flags.data()));
+    const auto searchTime = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - graphSearchStart).count();
+    for (int i = 0; i < nq; i++) {
+        JVectorKnnCollector* c = collectors[(size_t)i];
+        const int32_t* st = stats.data() + (size_t)i * JV_NUM_STATS;
+        for (int j = 0; j < count[(size_t)i]; j++) c->collect(docs[(size_t)i * topK + j], scores[(size_t)i * topK + j]);  // :175-177
+        KNNCounter::KNN_QUERY_VISITED_NODES += st[JV_STAT_VISITED];                                                      // :183-193
+        KNNCounter::KNN_QUERY_RERANKED_COUNT += st[JV_STAT_RERANKED];
+        KNNCounter::KNN_QUERY_EXPANDED_NODES += st[JV_STAT_EXPANDED];
+        KNNCounter::KNN_QUERY_EXPANDED_BASE_LAYER_NODES += st[JV_STAT_EXPANDED_BASE];
+        int visitedCount = st[JV_STAT_VISITED] + st[JV_STAT_EXPANDED];                                                    // :202-207
+        // (a search the engine stopped AT the limit has nothing to collect and must read as early-terminated)
+        if ((flags[(size_t)i] & JV_QFLAG_EARLY_TERMINATED) && sp.visit_limit > 0 && visitedCount < sp.visit_limit) visitedCount = (int)sp.visit_limit;
+        if (visitedCount > 0) c->incVisitedCount(visitedCount);
+    }
+    KNNCounter::KNN_QUERY_GRAPH_SEARCH_TIME += searchTime;
+}
+
+std::vector<TopDocs> JVectorReader::exactSearchBatch(const std::string& field, const float* targets, int nq, int k,
+                                                     const FixedBitSet& accept) {
+    const FieldEntry* fe = fieldEntry(field);
+    if (!fe) throw IllegalArgumentException("field not found: " + field);
+    std::vector<TopDocs> out((size_t)std::max(nq, 0));
+    if (nq <= 0 || k <= 0) return out;
+    if (k > JV_XB_TOPK_MAX) {
+        // beyond the batch scorer's top-k: the per-query scorer + a host-side queue, as a single exactSearch does
+        std::vector<int> docs;
+        for (int doc = 0; doc < accept.length(); doc++)
+            if (accept.get(doc) && doc < fe->graphNodeIdToDocMap.maxDoc() &&
+                fe->graphNodeIdToDocMap.getJVectorNodeId(doc) != GraphNodeIdToDocMap::NO_VECTOR_OR_DELETED_DOC)
+                docs.push_back(doc);
+        for (int i = 0; i < nq; i++) {
+            std::vector<float> sc = scoreDocs(field, targets + (size_t)i * fe->dimension, docs);
+            TopKnnCollector top(k, INT64_MAX);
+            for (size_t j = 0; j < docs.size(); j++) top.collect(docs[j], sc[j]);
+            out[(size_t)i] = top.topDocs();
+            out[(size_t)i].totalHits = (int64_t)out[(size_t)i].scoreDocs.size();
+        }
+        return out;
+    }
+    const size_t rows = (size_t)nq * (size_t)k;
+    std::vector<int32_t> docs(rows), count((size_t)nq);
+    std::vector<float> scores(rows);
+    jv_exact_batch_params p;
+    memset(&p, 0, sizeof(p));
+    p.struct_size = sizeof(p);
+    p.topK = k;
+    p.accept_doc_words = accept.getBits();
+    p.accept_num_docs = accept.length();
+    throwForStatus(jv_score_ordinals_batch(fe->index, targets, nq, &p, nullptr, docs.data(), scores.data(), count.data(), nullptr));
+    for (int i = 0; i < nq; i++) {
+        TopDocs& t = out[(size_t)i];
+        for (int j = 0; j < count[(size_t)i]; j++) t.scoreDocs.push_back({docs[(size_t)i * k + j], scores[(size_t)i * k + j]});
+        t.totalHits = (int64_t)t.scoreDocs.size();
+    }
+    return out;
+}
+
 // ---- JVectorKnnFloatVectorQuery ----
 TopDocs JVectorKnnFloatVectorQuery::approximateSearch(JVectorReader& reader, const AcceptDocs* acceptDocs,
                                                       int64_t visitedLimit) const {
@@ -491,6 +579,67 @@ TopDocs JVectorKnnFloatVectorQuery::searchLeaf(JVectorReader& reader, const Fixe
     }
     if (usedExact) *usedExact = true;
     return exactSearch(reader, accept);  // visited limit reached -> exact fallback
+}
+
+std::vector<TopDocs> JVectorKnnFloatVectorQuery::searchLeafBatch(JVectorReader& reader, const std::string& field, const float* targets,
+                                                                 int nq, int dim, int k, int overQueryFactor, float threshold,
+                                                                 float rerankFloor, const FixedBitSet* filter, const FixedBitSet* liveDocs,
+                                                                 int maxDoc, std::vector<uint8_t>* usedExactSearch, bool exactWhenCheaper,
+                                                                 double crossoverSelectivity) {
+    std::vector<TopDocs> out((size_t)std::max(nq, 0));
+    if (usedExactSearch) usedExactSearch->assign((size_t)std::max(nq, 0), 0);
+    const JVectorReader::FieldEntry* fe = reader.fieldEntry(field);
+    if (!fe || nq <= 0) return out;
+    if (dim != fe->dimension) throw IllegalArgumentException("vector dimension differs from the field's");
+    if (std::min(k, fe->size) == 0) return out;  // J/JVectorKnnFloatVectorQuery.java:62-64
+    auto approximate = [&](const AcceptDocs* ad, int64_t visitedLimit, std::vector<uint8_t>& early) {
+        std::vector<std::unique_ptr<TopKnnCollector>> tops;
+        std::vector<std::unique_ptr<JVectorKnnCollector>> wraps;
+        std::vector<JVectorKnnCollector*> ptrs;
+        for (int i = 0; i < nq; i++) {
+            tops.push_back(std::make_unique<TopKnnCollector>(k, visitedLimit));
+            wraps.push_back(std::make_unique<JVectorKnnCollector>(*tops.back(), threshold, rerankFloor, overQueryFactor));
+            ptrs.push_back(wraps.back().get());
+        }
+        reader.searchBatch(field, targets, nq, ptrs, ad);
+        early.assign((size_t)nq, 0);
+        for (int i = 0; i < nq; i++) {
+            out[(size_t)i] = wraps[(size_t)i]->topDocs();
+            early[(size_t)i] = out[(size_t)i].totalHitsIsLowerBound ? 1 : 0;
+            out[(size_t)i].totalHits = (int64_t)out[(size_t)i].scoreDocs.size();
+        }
+    };
+    std::vector<uint8_t> early;
+    if (!filter) {  // AbstractKnnVectorQuery.getLeafResults: no filter -> approximateSearch(liveDocs, Integer.MAX_VALUE)
+        AcceptDocs ad{liveDocs};
+        approximate(liveDocs ? &ad : nullptr, INT32_MAX, early);
+        return out;
+    }
+    FixedBitSet accept(maxDoc);
+    for (int doc = 0; doc < maxDoc; doc++)
+        if (filter->get(doc) && (!liveDocs || liveDocs->get(doc))) accept.set(doc);
+    const int cost = accept.cardinality();
+    const bool allExact = cost <= k || (exactWhenCheaper && (double)cost <= crossoverSelectivity * (double)std::max(fe->size, 1));
+    if (allExact) {
+        out = reader.exactSearchBatch(field, targets, nq, k, accept);
+        if (usedExactSearch) usedExactSearch->assign((size_t)nq, 1);
+        return out;
+    }
+    AcceptDocs ad{&accept};
+    approximate(&ad, cost, early);
+    std::vector<int> redo;
+    for (int i = 0; i < nq; i++)
+        if (early[(size_t)i]) redo.push_back(i);
+    if (!redo.empty()) {  // visited limit reached -> exact fallback, all such queries in one call
+        std::vector<float> sub(redo.size() * (size_t)dim);
+        for (size_t j = 0; j < redo.size(); j++) memcpy(sub.data() + j * (size_t)dim, targets + (size_t)redo[j] * (size_t)dim, (size_t)dim * sizeof(float));
+        std::vector<TopDocs> ex = reader.exactSearchBatch(field, sub.data(), (int)redo.size(), k, accept);
+        for (size_t j = 0; j < redo.size(); j++) {
+            out[(size_t)redo[j]] = std::move(ex[j]);
+            if (usedExactSearch) (*usedExactSearch)[(size_t)redo[j]] = 1;
+        }
+    }
+    return out;
 }
 
 }  // namespace jvector_amd

@@ -208,6 +208,15 @@ public:
     void search(const std::string& field, const int8_t* target, KnnCollector& knnCollector, const AcceptDocs* acceptDocs);
     // exact scorer used by Lucene's fallback: JVectorFloatVectorValues.scorer -> JVectorVectorScorer.score
     std::vector<float> scoreDocs(const std::string& field, const float* target, const std::vector<int>& docIds);
+    // ---- extensions of this engine (not in the reference: Lucene runs one leaf search per query and thread) ----
+    // nq searches with the SAME collector parameters and the SAME acceptDocs in one engine call: what :147-207 does per
+    // query — k, k * overQueryFactor, threshold, rerankFloor, the acceptOrds lambda, the counters, incVisitedCount — for
+    // every target.  collectors[i] receives query i's results.
+    void searchBatch(const std::string& field, const float* targets, int nq, std::vector<JVectorKnnCollector*>& collectors,
+                     const AcceptDocs* acceptDocs);
+    // the exact fallback for nq targets under one acceptDocs: top k of JVectorVectorScorer.score over the accepted docs
+    // that have a vector, by (score desc, doc asc) — HitQueue order (jv_score_ordinals_batch)
+    std::vector<TopDocs> exactSearchBatch(const std::string& field, const float* targets, int nq, int k, const FixedBitSet& accept);
     const FieldEntry* fieldEntry(const std::string& field) const;
     void close() { fieldEntryMap_.clear(); }
 private:
@@ -227,6 +236,18 @@ public:
     TopDocs searchLeaf(JVectorReader& reader, const FixedBitSet* filter, const FixedBitSet* liveDocs, int maxDoc,
                        bool* usedExactSearch = nullptr) const;
     int k() const { return k_; }
+    // The same per-leaf logic for MANY queries of one field that share filter, liveDocs and parameters (extension: the
+    // reference issues them one by one from Lucene's searcher threads).  Every query gets exactly the answer searchLeaf
+    // gives it: cost <= k -> exact; approximate search with visitLimit = cost; queries whose collector early-terminated ->
+    // exact.  Both steps are ONE engine call each (jv_search_batch_ex, jv_score_ordinals_batch).
+    // exactWhenCheaper (default false — a DEVIATION from Lucene's rule, opt-in): when the filter is selective enough that the
+    // batched exact scan is estimated cheaper than the graph search (selectivity <= crossoverSelectivity), skip the graph
+    // search and answer with the exact top k — a different (exact, recall 1) answer than the graph's approximate one.
+    static std::vector<TopDocs> searchLeafBatch(JVectorReader& reader, const std::string& field, const float* targets, int nq,
+                                                int dim, int k, int overQueryFactor, float threshold, float rerankFloor,
+                                                const FixedBitSet* filter, const FixedBitSet* liveDocs, int maxDoc,
+                                                std::vector<uint8_t>* usedExactSearch = nullptr, bool exactWhenCheaper = false,
+                                                double crossoverSelectivity = 0.25);
 private:
     TopDocs exactSearch(JVectorReader& reader, const FixedBitSet& accept) const;
     std::string field_;

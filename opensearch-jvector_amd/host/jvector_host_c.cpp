@@ -87,6 +87,31 @@ int jvh_query_search_leaf(void* reader, const float* target, int dim, int k, int
     });
 }
 
+// the same for nq queries that share filter, liveDocs and parameters (JVectorKnnFloatVectorQuery::searchLeafBatch): out_docs /
+// out_scores [nq][k], out_count / out_used_exact [nq]
+int jvh_query_search_leaf_batch(void* reader, const float* targets, int nq, int dim, int k, int over_query_factor, float threshold,
+                                float rerank_floor, const uint64_t* filter_words, const uint64_t* live_words, int max_doc,
+                                int exact_when_cheaper, double crossover_selectivity, int32_t* out_docs, float* out_scores,
+                                int32_t* out_count, int32_t* out_used_exact) {
+    return guard([&] {
+        std::unique_ptr<FixedBitSet> filter(bitsFrom(filter_words, max_doc)), live(bitsFrom(live_words, max_doc));
+        std::vector<uint8_t> exact;
+        std::vector<TopDocs> res = JVectorKnnFloatVectorQuery::searchLeafBatch(*(JVectorReader*)reader, kField, targets, nq, dim, k,
+                                                                              over_query_factor, threshold, rerank_floor, filter.get(),
+                                                                              live.get(), max_doc, &exact, exact_when_cheaper != 0,
+                                                                              crossover_selectivity);
+        for (int i = 0; i < nq; i++) {
+            const TopDocs& t = res[(size_t)i];
+            out_count[i] = (int32_t)t.scoreDocs.size();
+            for (size_t j = 0; j < (size_t)k; j++) {
+                out_docs[(size_t)i * k + j] = j < t.scoreDocs.size() ? t.scoreDocs[j].doc : -1;
+                out_scores[(size_t)i * k + j] = j < t.scoreDocs.size() ? t.scoreDocs[j].score : 0.0f;
+            }
+            if (out_used_exact) out_used_exact[i] = exact[(size_t)i];
+        }
+    });
+}
+
 // plain Lucene KnnFloatVectorQuery path: a foreign TopKnnCollector, re-wrapped by the reader with the
 // defaults (J/JVectorReader.java:133-144) — what KNNJVectorTests.java:982-1027 exercises concurrently
 int jvh_reader_search_plain_collector(void* reader, const float* target, int k, const uint64_t* accept_words,

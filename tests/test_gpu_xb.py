@@ -266,3 +266,53 @@ def test_two_million_docs_three_selectivities(pkg, pyoracle):
             assert np.array_equal(got[0], plain[0]) and np.array_equal(got[2].view(np.uint32), plain[2].view(np.uint32))
             print(f"sim={sim} scale={scale} sel={sel}: candidates {got[4][0]}, sample {got[4][1]}, re-scored per query {got[4][2] / nq:.0f}")
         gpu.close()
+
+
+def test_batched_leaf_search_equals_the_single_query_leaf_search_and_the_oracle(pkg, pyoracle):
+    """JVectorKnnFloatVectorQuery::searchLeafBatch (host mirror): Lucene's per-leaf rule — cost <= k -> exact; graph search with
+    visitLimit = cost; early-terminated -> exact — for 96 queries under ONE filter in two engine calls.  Every query must get
+    what the one-query searchLeaf gives it AND what the oracle's leaf search gives it (tests/ka_support.py), at selectivities
+    where all, some and none of the graph searches reach the limit; with deletes; and for a field with PQ."""
+    import importlib
+    import ka_support
+    host = importlib.import_module("opensearch_jvector_amd.host")
+    b, bl = pkg.binding, pkg.builder
+    rng = np.random.default_rng(17)
+    n, d, k, oqf, nq = 20000, 64, 10, 5, 96
+    base = pkg.datagen.splitmix_uniform(31, n, d)
+    queries = pkg.datagen.splitmix_uniform(32, nq, d)
+    max_doc = n + 500
+    ord2doc = np.sort(rng.permutation(max_doc)[:n]).astype(np.int32)   # docs without a vector in between
+    mixed = 0
+    for lucene_sim, pq_M in (("EUCLIDEAN", 0), ("MAXIMUM_INNER_PRODUCT", 0), ("EUCLIDEAN", 16)):
+        sim, scale = ka_support.LUCENE_SIM[lucene_sim]
+        ix = bl.build_index_cpu(base, sim, R=16, L=60, score_scale=(scale if pq_M == 0 else 1.0), ord2doc=ord2doc, max_doc=max_doc, pq_M=pq_M)
+        reader = host.JVectorReader(ix, lucene_sim)
+        orc = pyoracle.Oracle(b, ix)
+        deleted = rng.choice(max_doc, 300, replace=False).tolist()
+        for sel, dels in ((0.0004, ()), (0.01, ()), (0.04, deleted), (0.08, ()), (0.15, ()), (0.17, deleted), (0.18, ()), (0.3, deleted),
+                          (None, deleted), (None, ())):
+            fdocs = None if sel is None else np.nonzero(rng.random(max_doc) < sel)[0]
+            docs, scores, count, exact = reader.search_leaf_batch(queries, k, oqf, filter_docs=fdocs, deleted_docs=dels)
+            if 0 < exact.sum() < nq:
+                mixed += 1
+            for i in range(nq):
+                one = reader.search_leaf(queries[i], k, oqf, filter_docs=fdocs, deleted_docs=dels)
+                c = int(count[i])
+                assert docs[i, :c].tolist() == one[0] and bool(exact[i]) == one[3], (lucene_sim, pq_M, sel, i)
+                assert np.array_equal(scores[i, :c].view(np.uint32), np.asarray(one[1], dtype=np.float32).view(np.uint32))
+                if i < 24:
+                    case = dict(k=k, over_query_factor=oqf, deleted_docs=list(dels), filter_docs=None if fdocs is None else fdocs.tolist(),
+                                query=queries[i].tolist())
+                    wd, ws, wex = ka_support.leaf_search(pkg, orc, ix, case)
+                    assert docs[i, :c].tolist() == wd and bool(exact[i]) == wex, (lucene_sim, pq_M, sel, i)
+                    assert np.array_equal(scores[i, :c].view(np.uint32), np.asarray(ws, dtype=np.float32).view(np.uint32))
+            # the opt-in crossover answers with the exact top k whenever the filter is selective enough
+            if sel is not None and sel <= 0.08:
+                xd, xs, xc, xe = reader.search_leaf_batch(queries, k, oqf, filter_docs=fdocs, deleted_docs=dels, exact_when_cheaper=True,
+                                                          crossover_selectivity=0.1)
+                assert xe.all()
+                for i in np.nonzero(exact)[0]:
+                    assert np.array_equal(xd[i], docs[i]) and np.array_equal(xs[i].view(np.uint32), scores[i].view(np.uint32))
+        reader.close()
+    assert mixed >= 1, "no selectivity exercised the mixed case (some queries exact, some approximate)"

@@ -47,7 +47,19 @@ for sel in [None if x == "None" else float(x) for x in os.environ.get("SELS", "N
         torch.cuda.synchronize(); dt = time.time() - t
     st = o[4].cpu().numpy().astype(np.float64).mean(0)
     fl = o[5].cpu().numpy().astype(np.uint32)
-    print(f"selectivity {sel}: {B / dt:9.0f} QPS  visited {st[0]:.0f} expanded {st[2]:.0f}  big-path {int((fl & 1).sum())}  count<10: {int((o[3].cpu().numpy() < 10).sum())}", flush=True)
+    xb = ""
+    if sel is not None and os.environ.get("XB", "1") == "1":   # the batched exact scorer on the same queries and filter
+        xo = [torch.empty((B, 10), dtype=torch.int32, device=dev), torch.empty((B, 10), dtype=torch.int32, device=dev),
+              torch.empty((B, 10), dtype=torch.float32, device=dev), torch.empty((B,), dtype=torch.int32, device=dev)]
+        for it in range(3):
+            torch.cuda.synchronize(); t = time.time()
+            info = ix.score_ordinals_batch_device(q.data_ptr(), B, 10, *[t_.data_ptr() for t_ in xo], d_accept=acc_ptr, accept_num_docs=n,
+                                                  want_info=(it == 2))
+            torch.cuda.synchronize(); dtx = time.time() - t
+        gn, xn = o[0].cpu().numpy(), xo[0].cpu().numpy()
+        rec = float(np.mean([len(set(gn[i]) & set(xn[i])) / 10 for i in range(min(B, 2048))]))
+        xb = f" | exact scan of the filter: {B / dtx:9.0f} QPS (candidates {int(info[0])}, re-scored/query {info[2] / B:.0f}); recall@10 of the graph answer {rec:.4f}"
+    print(f"selectivity {sel}: {B / dt:9.0f} QPS{xb}  visited {st[0]:.0f} expanded {st[2]:.0f}  big-path {int((fl & 1).sum())}  count<10: {int((o[3].cpu().numpy() < 10).sum())}", flush=True)
     if stamps:
         v = dbg.cpu().numpy().astype(np.float64); ne = max(st[2], 1) * B
         names = {15: "find", 0: "candidates + barrier A", 9: "wait for blocks", 1: "mark + log", 2: "ADC + exchange", 3: "boundary + rank + dedupe", 14: "ranks among new keys",
