@@ -34,6 +34,8 @@ hipError_t jvk_xb_mirror(const float* src, long long rows, int d, long long src_
 hipError_t jvk_xb_build_list(const JvIndexDev* ix, const uint64_t* d_accept, long long accept_docs, int32_t* d_counts, int32_t* d_list, hipStream_t s);
 int jvk_xb_list_blocks(int n);
 hipError_t jvk_xb_tile(const JvXbTileArgs* a, int mode, hipStream_t s);
+int jvk_xb_qs_ok(int kp);
+hipError_t jvk_xb_qs(const JvXbTileArgs* a, int mode, int cus, hipStream_t s);
 hipError_t jvk_xb_kth(const float* sample, int ld, int S, int k, float* thr, int B, hipStream_t s);
 hipError_t jvk_xb_rescore(const JvIndexDev* ix, const JvXbRescoreArgs* a, int nq, hipStream_t s);
 hipError_t jvk_set_max_lds(int bytes);
@@ -65,6 +67,7 @@ hipError_t jvk_pqw_set_max_lds(int bytes);
 int jvk_pqw_ok(const JvIndexDev* ix, int cap);
 int jvk_pqw_waves(const JvIndexDev* ix);
 int jvk_pqw_lds_rows(const JvIndexDev* ix, int variant);
+int jvk_pqw_occ5_ok(const JvIndexDev* ix, int cap);
 int jvk_pqw_blocks_per_cu(const JvIndexDev* ix, int cap, int lds_bytes, int variant);
 hipError_t jvk_launch_search_pqw(const JvIndexDev* ix, const JvSearchArgs* a, int lds_bytes, int blocks, int variant, hipStream_t s);
 // the same kernel with a doc filter (jv_kernels_pqwf.hip): pools of up to 16 384 entries
@@ -789,7 +792,9 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
         // few queries: every resident query has a CU (almost) to itself and its time is the launch's — the variant with the
         // whole table in LDS (a third of the scoring pass's instructions, 3 workgroups per CU)
         const int64_t lat_q = OPT(ix, OPT_PQW_LAT_QUERIES) >= 0 ? OPT(ix, OPT_PQW_LAT_QUERIES) : 3 * (int64_t)ix->cu_count;
-        const int pqw_variant = (pqw && nq <= lat_q) ? 1 : 0;
+        // (diagnostics, JV_PQW_OCC5=1: the 96-register instance — nine resident queries per CU instead of eight, jv_kernels_pqw.hip)
+        static const bool occ5_env = getenv("JV_PQW_OCC5") != nullptr;
+        const int pqw_variant = (pqw && nq <= lat_q) ? 1 : ((pqw && occ5_env && jvk_pqw_occ5_ok(&ix->dev, ap.cand_cap + 64)) ? 2 : 0);
         if (pqw) {
             // the first launch keeps what it can: an expansion log four times as long (it lives in HBM) and, where the LDS
             // budget of the same residency and the same capacity class allow it, 128 instead of 64 boundary-tie slots —
@@ -2763,6 +2768,23 @@ static int xb_ensure_mirror(jv_index* ix) {
     return JV_OK;
 }
 
+// one pass of the matrix-core kernel over ta.rows candidates x ta.B queries: the query-stationary kernel (rounds of 256 queries,
+// candidates streamed as whole rows) where the k range fits a wave's registers, else the LDS-tiled one (option "xb_no_qs" / env
+// JV_XB_NO_QS force the latter: A/B runs)
+static int xb_pass(jv_index* ix, JvXbTileArgs& ta, int mode) {
+    static const bool no_qs = getenv("JV_XB_NO_QS") != nullptr;
+    if (!no_qs && jvk_xb_qs_ok(ta.kp)) {
+        for (int q0 = 0; q0 < ta.B; q0 += 256) {
+            ta.qbase = q0;
+            HIPCHK(jvk_xb_qs(&ta, mode, ix->cu_count, ix->xb.stream));
+        }
+        ta.qbase = 0;
+        return JV_OK;
+    }
+    HIPCHK(jvk_xb_tile(&ta, mode, ix->xb.stream));
+    return JV_OK;
+}
+
 // d_* = device pointers on the index's device; d_ords = nullptr: every ordinal is a candidate (C = n).  Enqueues on x.stream.
 static int xb_run(jv_index* ix, const float* d_queries, int nq, int topK, const int32_t* d_ords, int C, uint32_t flags,
                   int32_t* d_nodes, int32_t* d_docs, float* d_scores, int32_t* d_count, int64_t* info) {
@@ -2806,8 +2828,9 @@ static int xb_run(jv_index* ix, const float* d_queries, int nq, int topK, const 
         ra.out_info = x.d_info;
         if (pre) {
             const int panels = (B + 127) / 128;
+            const size_t qrows = (size_t)(B + 255) / 256 * 256;   // (the query-stationary kernel reads whole rounds of 256 rows)
             int rc;
-            if ((rc = xb_grow(x, &x.d_qb, &x.qb_cap, (size_t)panels * 128 * kp)) != JV_OK) return rc;
+            if ((rc = xb_grow(x, &x.d_qb, &x.qb_cap, qrows * kp)) != JV_OK) return rc;
             if (x.round_cap < (size_t)panels * 128) {
                 size_t c1 = x.round_cap, c2 = x.round_cap, c3 = x.round_cap;
                 if ((rc = xb_grow(x, &x.d_qn2, &c1, (size_t)panels * 128)) != JV_OK) return rc;
@@ -2817,7 +2840,7 @@ static int xb_run(jv_index* ix, const float* d_queries, int nq, int topK, const 
             }
             if ((rc = xb_grow(x, &x.d_sample, &x.sample_cap, (size_t)B * S)) != JV_OK) return rc;
             if ((rc = xb_grow(x, &x.d_surv, &x.surv_cap, (size_t)B * XB_SURV_CAP)) != JV_OK) return rc;
-            HIPCHK(hipMemsetAsync(x.d_qb, 0, (size_t)panels * 128 * kp * 2, st));
+            HIPCHK(hipMemsetAsync(x.d_qb, 0, qrows * kp * 2, st));
             HIPCHK(jvk_xb_mirror(dq, B, dv.d, dv.d, kp, x.d_qb, x.d_qn2, 1, st));
             HIPCHK(hipMemsetAsync(x.d_surv_cnt, 0, (size_t)B * 4, st));
             XB_STEP("bf16 queries");
@@ -2840,7 +2863,7 @@ static int xb_run(jv_index* ix, const float* d_queries, int nq, int topK, const 
             ta.rows = S;
             ta.sample = x.d_sample;
             ta.sample_ld = S;
-            HIPCHK(jvk_xb_tile(&ta, 0, st));
+            if ((rc = xb_pass(ix, ta, 0)) != JV_OK) return rc;
             XB_STEP("sample pass");
             HIPCHK(jvk_xb_kth(x.d_sample, S, S, topK, x.d_thr, B, st));
             XB_STEP("k-th select");
@@ -2851,7 +2874,7 @@ static int xb_run(jv_index* ix, const float* d_queries, int nq, int topK, const 
             ta.surv_cnt = x.d_surv_cnt;
             ta.surv = x.d_surv;
             ta.surv_cap = XB_SURV_CAP;
-            HIPCHK(jvk_xb_tile(&ta, 1, st));
+            if ((rc = xb_pass(ix, ta, 1)) != JV_OK) return rc;
             XB_STEP("filter pass");
             ra.surv_cnt = x.d_surv_cnt;
             ra.surv = x.d_surv;
@@ -3052,7 +3075,8 @@ int jv_xb_debug_bounds(jv_index* index, const float* queries, int32_t nq, const 
     hipStream_t st = x.stream;
     if ((rc = xb_grow(x, &x.d_queries, &x.queries_cap, (size_t)nq * dv.d)) != JV_OK) return rc;
     if ((rc = xb_grow(x, &x.d_list, &x.list_cap, (size_t)count)) != JV_OK) return rc;
-    if ((rc = xb_grow(x, &x.d_qb, &x.qb_cap, (size_t)panels * 128 * kp)) != JV_OK) return rc;
+    const size_t qrows = (size_t)(nq + 255) / 256 * 256;
+    if ((rc = xb_grow(x, &x.d_qb, &x.qb_cap, qrows * kp)) != JV_OK) return rc;
     if (x.round_cap < (size_t)panels * 128) {
         size_t c1 = x.round_cap, c2 = x.round_cap, c3 = x.round_cap;
         if ((rc = xb_grow(x, &x.d_qn2, &c1, (size_t)panels * 128)) != JV_OK) return rc;
@@ -3063,7 +3087,7 @@ int jv_xb_debug_bounds(jv_index* index, const float* queries, int32_t nq, const 
     if ((rc = xb_grow(x, &x.d_sample, &x.sample_cap, (size_t)nq * count)) != JV_OK) return rc;
     HIPCHK(hipMemcpyAsync(x.d_queries, queries, (size_t)nq * dv.d * 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(x.d_list, ordinals, (size_t)count * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemsetAsync(x.d_qb, 0, (size_t)panels * 128 * kp * 2, st));
+    HIPCHK(hipMemsetAsync(x.d_qb, 0, qrows * kp * 2, st));
     HIPCHK(jvk_xb_mirror(x.d_queries, nq, dv.d, dv.d, kp, x.d_qb, x.d_qn2, 1, st));
     JvXbTileArgs ta;
     memset(&ta, 0, sizeof(ta));
@@ -3087,7 +3111,7 @@ int jv_xb_debug_bounds(jv_index* index, const float* queries, int32_t nq, const 
     for (int mode = 0; mode <= 2; mode += 2) {
         float* dst = mode == 0 ? out_lower : out_upper;
         if (!dst) continue;
-        HIPCHK(jvk_xb_tile(&ta, mode, st));
+        if ((rc = xb_pass(index, ta, mode)) != JV_OK) return rc;
         HIPCHK(hipMemcpyAsync(dst, x.d_sample, (size_t)nq * count * 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
     }

@@ -16,6 +16,13 @@ static const pqw_kernel_t g_pqw_kernels[4][3][4] = {
     {JV_PQW_ROW(0, 4, 3, 16), JV_PQW_ROW(1, 4, 3, 16), JV_PQW_ROW(2, 4, 3, 16)},
 };
 
+// Diagnostic instance (JV_PQW_OCC5=1, VERDICT r4 #1a): the register budget of FIVE waves per SIMD (96 VGPRs) with the whole table in
+// registers (NL must be a multiple of 4 — the register rows are permuted four at a time — and NL = 4 leaves 19.8 KB of LDS per query:
+// eight per CU again), so that nine two-wave workgroups fit a CU instead of eight — d = 768, PQ-32, pools beyond 1 024 entries only.
+// tools/kernel_resources.py: 637 VGPR spills / 436 B of scratch per lane against 43 / 168 of the 128-register instance.
+static const pqw_kernel_t g_pqw_occ5 = jv_search_pqw_kernel<12, 2, 2, 5, 0>;
+static bool pqw_occ5_ok(const JvIndexDev* ix, int cap);
+
 static int pqw_nch_slot(const JvIndexDev* ix) {
     if (ix->nvq_M > 0) return 0;  // the NVQ decoder lives in the "any d" instances only (score_rows)
     if (ix->stride != ix->nch * 64) return 0;
@@ -26,14 +33,17 @@ extern "C" int jvk_pqw_waves(const JvIndexDev* ix) { return ix->pq_M / 16; }
 extern "C" const void* jvk_pqw12_kernel(int waves, int capk, int nch_slot);  // jv_kernels_pqw12.hip: twelve / eight waves per query (PQ-192 / PQ-128)
 extern "C" hipError_t jvk_pqw12_set_max_lds(int bytes);
 // NL of the instances: table rows per wave kept in LDS (PQ-192: eight, both variants)
-extern "C" int jvk_pqw_lds_rows(const JvIndexDev* ix, int variant) { return ix->pq_M >= 128 ? 8 : (variant ? 16 : 4); }
+extern "C" int jvk_pqw_lds_rows(const JvIndexDev* ix, int variant) { return ix->pq_M >= 128 ? 8 : (variant == 1 ? 16 : (variant == 2 ? 0 : 4)); }
 // shapes this kernel runs: one wave per 16-subspace chunk, one lane per stored neighbour, whole log groups per 64-entry chunk
 extern "C" int jvk_pqw_ok(const JvIndexDev* ix, int cap) {
     if (!(ix->pq_M == 32 || ix->pq_M == 64 || ix->pq_M == 128 || ix->pq_M == 192) || ix->sim == 2 || !ix->pq_fused || ix->num_upper != 0) return 0;
     if (ix->R < 1 || ix->R > JV_WAVE || 64 % ((JV_WAVE / ix->R) * 8) != 0) return 0;
     return cap <= 2048 && ix->n < (1 << 30) ? 1 : 0;
 }
+static bool pqw_occ5_ok(const JvIndexDev* ix, int cap) { return ix->pq_M == 32 && pqw_capk(cap) == 2 && pqw_nch_slot(ix) == 2; }
+extern "C" int jvk_pqw_occ5_ok(const JvIndexDev* ix, int cap) { return pqw_occ5_ok(ix, cap) ? 1 : 0; }
 static pqw_kernel_t pqw_pick(const JvIndexDev* ix, int cap, int variant) {
+    if (variant == 2) return g_pqw_occ5;
     if (ix->pq_M >= 128) return (pqw_kernel_t)jvk_pqw12_kernel(ix->pq_M / 16, pqw_capk(cap), pqw_nch_slot(ix));
     return g_pqw_kernels[(variant ? 2 : 0) + (ix->pq_M == 64 ? 1 : 0)][pqw_capk(cap)][pqw_nch_slot(ix)];
 }
@@ -41,6 +51,10 @@ static pqw_kernel_t pqw_pick(const JvIndexDev* ix, int cap, int variant) {
 extern "C" hipError_t jvk_pqw_set_max_lds(int bytes) {
     {
         hipError_t e = jvk_pqw12_set_max_lds(bytes);
+        if (e != hipSuccess) return e;
+    }
+    {
+        hipError_t e = hipFuncSetAttribute((const void*)g_pqw_occ5, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (e != hipSuccess) return e;
     }
     for (int w = 0; w < 4; w++)

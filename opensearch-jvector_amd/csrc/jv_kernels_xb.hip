@@ -361,6 +361,237 @@ extern "C" hipError_t jvk_xb_tile(const JvXbTileArgs* a, int mode, hipStream_t s
 }
 
 // ---------------------------------------------------------------------------------------------
+// The QUERY-STATIONARY tile kernel (kp <= 768): what the tile kernel above does, restructured for the regime the path lives
+// in — a few hundred queries, candidates streamed ONCE.  Above, every 128-candidate tile re-reads the whole bf16 query panel
+// from L2 (as many bytes as the candidates themselves) and fetches candidate rows in 128-B slivers one k step ahead: 2 x 16 KB
+// of candidate bytes in flight per CU, 13-17 % of the HBM roof (profiles/r05_xb).  Here
+//   * a wave keeps the A fragments of its 32 queries for the WHOLE k range in registers (NK16 x 4 = 192 VGPRs at kp = 768),
+//     loaded once per workgroup: 8 waves = 256 queries per round, two waves per SIMD;
+//   * candidates arrive as WHOLE rows (kp x 2 contiguous bytes: DRAM pages, not slivers), 32 rows per stage, three stages in
+//     LDS — two in flight while the third is multiplied: ~100 KB of candidate bytes in flight per CU;
+//   * EVERY vector-memory instruction of the loop is an LDS-DMA copy (global_load_lds): the stage's rows, its 32 ordinals
+//     (one stage further ahead, read back from LDS to form the row addresses) and its 32 norms.  No instruction waits for a
+//     register from memory, so nothing the compiler inserts can drain the copies in flight (vmcnt retires in order: one
+//     ordinary load's wait would); the only waits are the two counted ones written below.
+// One persistent workgroup per CU.  Same bounds, same outputs as the tile kernel (xb_bounds, restated as per-query and
+// per-candidate factors so that the 16 accumulator elements of a lane share them).
+// ---------------------------------------------------------------------------------------------
+// LDS image of one 64-wide k chunk of a stage: four groups of 8 rows x 128 B.  A ds_read_b128 serves 16 lanes = 16 consecutive
+// rows = two groups at a time, so the groups of a pair sit on opposite halves of the 256-B bank row: bases 0 / 1152 / 2176 / 3328
+// (1 024 B each, no overlap).  3 stages x 12 chunks x 4 352 B + 7 168 B of per-query / per-stage words = 163 840 B: the whole LDS.
+#define XQ_KCH 4352
+__device__ __forceinline__ int xq_group_off(int g) { return g * 1024 + (g == 0 ? 0 : (g == 3 ? 256 : 128)); }
+__device__ __forceinline__ void xb_glds4(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 4, 0, 0);
+}
+// v = a * (mq * mc) + (bq + bc),  e = keq * kec + (sq + sc) + c0   (see xb_bounds: the same interval, factored)
+__device__ __forceinline__ f32x4 xq_query_factors(int sim, float qn2, float kappa) {
+    const float qn = sqrtf(qn2);
+    if (sim == 0) return (f32x4){2.0f, -qn2, 2.0f * kappa * qn, 1.2e-5f * qn2};
+    if (sim == 1) return (f32x4){1.0f, 0.0f, kappa * qn, 0.0f};
+    return (f32x4){1.0f / qn, 0.0f, kappa, 0.0f};
+}
+
+template <int NK16, int MODE>
+__global__ __launch_bounds__(512) void jvx_qs_kernel(const JvXbTileArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NW = 8;
+    constexpr int NK64 = NK16 / 4;                 // 64-wide k chunks per row
+    constexpr int STAGE = NK64 * XQ_KCH;           // LDS bytes of one stage (32 rows)
+    constexpr int NCH = NK64 * 4;                  // 1-KB copies per stage
+    constexpr int LPW = (NCH + NW - 1) / NW;       // copies per wave per stage
+    constexpr int kp = NK16 * 16;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, r31 = lane & 31;
+    f32x4* s_qc = (f32x4*)(smem + 3 * STAGE);                    // [256] per query: mq, bq, keq, sq
+    float* s_thr = (float*)(smem + 3 * STAGE + 256 * 16);        // [256] bar
+    int* s_ord = (int*)(smem + 3 * STAGE + 256 * 20);            // [2][64] ordinals, one stage further ahead than the rows
+    float* s_cn2 = (float*)(smem + 3 * STAGE + 256 * 20 + 512);  // [3][64] norms of the stages in LDS
+    int* s_val = (int*)(smem + 3 * STAGE + 256 * 20 + 512 + 768); // [3][64] 1 = the list entry is an ordinal of this index
+    if (tid < 256) {
+        const int q = a.qbase + tid;
+        const float n2 = q < a.B ? a.qnorm2[q] : 0.0f;
+        s_qc[tid] = xq_query_factors(a.sim, n2, a.kappa);
+        s_thr[tid] = (MODE == 1 && q < a.B) ? a.thr[q] : 0.0f;
+    }
+    const bool active = a.qbase + w * 32 < a.B;   // (a wave without queries still copies and meets the barriers)
+    // A fragments: query row w * 32 + (lane & 31), k = 16 ks + 8 h ... + 7
+    bf16x8 qf[NK16];
+    {
+        const char* qrow = (const char*)a.qb + (size_t)(a.qbase + w * 32 + r31) * (size_t)kp * 2 + h * 16;
+#pragma unroll
+        for (int ks = 0; ks < NK16; ks++) qf[ks] = *(const bf16x8*)(qrow + ks * 32);
+        // a USE of every fragment here: the compiler waits for these loads now.  Left pending into the stage loop, its wait
+        // insertion puts a vmcnt(0) in front of the first matrix instruction of EVERY stage — and drains the copies in flight.
+#pragma unroll
+        for (int ks = 0; ks < NK16; ks++) asm volatile("" ::"v"(qf[ks]));
+    }
+    const int nsub = (a.rows + 31) / 32;           // 32-row stages of this launch
+    const int G = gridDim.x;
+    const int lr = lane >> 3, lp = (lane & 7) ^ lr;
+    // list position of row j of stage t (clamped into the list: rows behind its end are copies of the last one, dropped in the epilogue)
+    auto list_pos = [&](int t, int j) -> long long {
+        long long ci = (long long)t * 32 + j;
+        if (ci >= a.rows) ci = a.rows - 1;
+        const long long idx = ci * a.cstride;
+        return idx >= a.C ? (long long)a.C - 1 : idx;
+    };
+    // wave 0: the 32 ordinals of stage t -> s_ord[slot] (lanes >= 32 repeat lane 31's; without a list the ordinal IS the position)
+    auto issue_ord = [&](int t, int slot) {
+        if (t >= nsub) return;
+        const long long idx = list_pos(t, r31);
+        if (a.ords) xb_glds4(a.ords + idx, s_ord + slot * 64);
+        else s_ord[slot * 64 + lane] = (int)idx;
+    };
+    // stage t -> LDS buffer buf, ordinals from s_ord[slot]; wave 0 also requests the 32 norms
+    auto issue_rows = [&](int buf, int slot, int nslot) {
+        unsigned char* base = smem + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < LPW; i++) {
+            const int c = w + NW * i;              // chunk: k chunk c >> 2, row group c & 3
+            if (NCH % NW == 0 || c < NCH) {
+                const int kc = c >> 2, g = c & 3;
+                int ord = s_ord[slot * 64 + 8 * g + lr];
+                ord = (ord < 0 || ord >= a.n) ? 0 : ord;
+                xb_glds16((const char*)a.vb + (size_t)ord * (size_t)kp * 2 + kc * 128 + lp * 16, base + kc * XQ_KCH + xq_group_off(g));
+            }
+        }
+        if (w == 0) {
+            int ord = s_ord[slot * 64 + r31];
+            const bool ok = ord >= 0 && ord < a.n;
+            ord = ok ? ord : 0;
+            s_val[nslot * 64 + lane] = ok ? 1 : 0;
+            xb_glds4(a.vnorm2 + ord, s_cn2 + nslot * 64);
+        }
+    };
+    // fragment read offset of candidate row r31 inside a k chunk
+    const int foff = xq_group_off(r31 >> 3) + (r31 & 7) * 128, fx = r31 & 7;
+    int sw[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) sw[j] = foff + (((2 * j + h) ^ fx) << 4);
+
+    // ---- prologue: ordinals of the first three stages, rows of the first two ----
+    const int t0 = blockIdx.x;
+    if (w == 0) issue_ord(t0, 0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (t0 < nsub) issue_rows(0, 0, 0);
+    if (w == 0) issue_ord(t0 + G, 1);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // (the loop's order — the ordinals two stages ahead BEFORE the rows one stage ahead — or the counted wait below would let
+    //  them slip; slot 0 was read by every wave before the barrier above)
+    if (w == 0) issue_ord(t0 + 2 * G, 0);
+    if (t0 + G < nsub) issue_rows(1, 1, 1);
+    int buf = 0, oslot = 0, nslot = 0;      // buffer / norm slot of stage t; ordinal slot of stage t + 2
+    for (int t = t0; t < nsub; t += G) {
+        // stage t has landed once at most the copies of stage t + 1 (and wave 0's norm request) are outstanding; wave 0's
+        // ordinals of stage t + 2 were requested before those, so they are in LDS too
+        if (t + G < nsub) {
+            if (w == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW + 1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // A
+        // requests, oldest first: the ordinals of stage t + 3, then the rows and norms of stage t + 2
+        {
+            const int ob = oslot ^ 1;
+            if (w == 0) issue_ord(t + 3 * G, ob);   // (slot ob held stage t + 1's ordinals: read before barrier B of the previous iteration)
+            if (t + 2 * G < nsub) {
+                int b2 = buf + 2, n2 = nslot + 2;
+                b2 = b2 >= 3 ? b2 - 3 : b2;
+                n2 = n2 >= 3 ? n2 - 3 : n2;
+                issue_rows(b2, oslot, n2);
+            }
+        }
+        if (active) {
+            const unsigned char* base = smem + buf * STAGE;
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[e] = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < NK16; ks++) {
+                const bf16x8 fc = *(const bf16x8*)(base + (ks >> 2) * XQ_KCH + sw[ks & 3]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[ks], fc, acc, 0, 0, 0);
+                // the register file is the query: keep the scheduler from hoisting more than a few fragment reads
+                if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- epilogue: lane = candidate r31 of this stage ----
+            // (an OPAQUE copy of the lane id, made here: the sixteen per-row LDS addresses and predicates derived from it are then
+            //  formed after the multiply instead of hoisted out of the stage loop, where they would be live — and spilled, every
+            //  reload a vmcnt(0) that drains the copies in flight — across the 192 registers of the query)
+            int lane_o = lane;
+            asm volatile("" : "+v"(lane_o));
+            const int h = lane_o >> 5, r31 = lane_o & 31;
+            const long long ci = (long long)t * 32 + r31;
+            const bool cin = ci < a.rows;
+            const float cn2 = s_cn2[nslot * 64 + r31];
+            const bool cval = cin && s_val[nslot * 64 + r31] != 0;   // (an invalid list entry: row 0 was staged in its place)
+            float mc = 1.0f, bc = 0.0f, kec = 1.0f, sc = 0.0f, c0 = 2e-5f;
+            if (a.sim == 0) bc = -cn2, kec = sqrtf(cn2), sc = 1.2e-5f * cn2, c0 = 1e-6f;
+            else if (a.sim == 1) kec = sqrtf(cn2), c0 = 1e-6f;
+            else mc = 1.0f / sqrtf(cn2);
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) {
+                const int row = w * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                const int q = a.qbase + row;
+                const f32x4 qc = s_qc[row];
+                const float v = fmaf(acc[reg] * qc[0], mc, qc[1] + bc);
+                float e = fmaf(qc[2], kec, qc[3] + sc) + c0;
+                e = fmaf(e, 1.000001f, 4e-7f * fabsf(v));
+                if (MODE == 0 || MODE == 2) {
+                    if (cin && q < a.B) a.sample[(size_t)q * a.sample_ld + ci] = !cval ? -__builtin_inff() : (MODE == 0 ? v - e : v + e);
+                } else {
+                    // NaN-proof: "certainly worse" must be TRUE to drop a candidate
+                    if (cval && q < a.B && !(v + e < s_thr[row])) {
+                        const int pos = atomicAdd(a.surv_cnt + q, 1);
+                        if (pos < a.surv_cap) a.surv[(size_t)q * a.surv_cap + pos] = (int32_t)list_pos(t, r31);
+                    }
+                }
+                if ((reg & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // B: every fragment read of this buffer (and of the ordinal / norm slots) has returned before any wave restages it
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        buf = buf == 2 ? 0 : buf + 1;
+        nslot = nslot == 2 ? 0 : nslot + 1;
+        oslot ^= 1;
+    }
+}
+
+template <int NK16>
+static hipError_t xq_launch(const JvXbTileArgs* a, int mode, int blocks, hipStream_t s) {
+    const int lds = 3 * (NK16 / 4) * XQ_KCH + 256 * 20 + 512 + 768 + 768;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)jvx_qs_kernel<NK16, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)jvx_qs_kernel<NK16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)jvx_qs_kernel<NK16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    if (mode == 0) jvx_qs_kernel<NK16, 0><<<blocks, 512, lds, s>>>(*a);
+    else if (mode == 1) jvx_qs_kernel<NK16, 1><<<blocks, 512, lds, s>>>(*a);
+    else jvx_qs_kernel<NK16, 2><<<blocks, 512, lds, s>>>(*a);
+    return hipGetLastError();
+}
+// one round of up to 256 queries (a->qbase ...)
+extern "C" int jvk_xb_qs_ok(int kp) { return kp == 768 || kp == 512 || kp == 384 || kp == 256 || kp == 128; }
+extern "C" hipError_t jvk_xb_qs(const JvXbTileArgs* a, int mode, int cus, hipStream_t s) {
+    if (a->rows <= 0 || a->B <= 0) return hipSuccess;
+    const int nsub = (a->rows + 31) / 32;
+    const int blocks = nsub < cus ? nsub : cus;
+    switch (a->kp) {
+        case 768: return xq_launch<48>(a, mode, blocks, s);
+        case 512: return xq_launch<32>(a, mode, blocks, s);
+        case 384: return xq_launch<24>(a, mode, blocks, s);
+        case 256: return xq_launch<16>(a, mode, blocks, s);
+        case 128: return xq_launch<8>(a, mode, blocks, s);
+        default: return hipErrorNotSupported;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // A per-query bar from the sample row: a value L such that AT LEAST k sample entries are >= L (any such value is a valid bar;
 // the closer to the true k-th largest, the fewer survivors).  Three reads of the row (L2 hits): min / max of the finite
 // entries, a 2 048-bucket histogram over [min, max] (linear buckets spread a bell-shaped score distribution over the LDS

@@ -15,6 +15,7 @@ struct JvXbTileArgs {
     const uint16_t* qb;     // bf16 queries [panels * 128][kp], zero rows behind B
     const float* qnorm2;    // [B]
     int32_t B, panels;
+    int32_t qbase;          // query-stationary kernel: first query of this launch's round of <= 256
     int32_t sim;
     float kappa;            // relative half-width of the bf16 product's error, in units of |q||c|
     float* sample;          // mode 0: [B][sample_ld] lower bounds

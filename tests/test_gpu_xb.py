@@ -99,7 +99,7 @@ def test_the_bound_contains_the_exact_value(pkg):
     lib.jv_xb_debug_bounds.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.jv_xb_debug_bounds.restype = C.c_int
     rng = np.random.default_rng(5)
-    for d in (64, 200, 768, 1536):
+    for d in (64, 128, 200, 500, 768, 1536):
         n, nq = 4096, 130
         base = rng.standard_normal((n, d)).astype(np.float32)
         base[:512] = np.abs(base[:512]) * 3 + 1                      # far from the origin: worst case for the L2 cancellation
