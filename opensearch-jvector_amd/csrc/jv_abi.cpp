@@ -2773,12 +2773,29 @@ static int xb_ensure_mirror(jv_index* ix) {
 // JV_XB_NO_QS force the latter: A/B runs)
 static int xb_pass(jv_index* ix, JvXbTileArgs& ta, int mode) {
     static const bool no_qs = getenv("JV_XB_NO_QS") != nullptr;
+    static const int dbg = getenv("JV_XB_DBG") ? atoi(getenv("JV_XB_DBG")) : 0;
+    ta.dbg = dbg;
+    // JV_XB_STAMPS=1: cycles per phase of the query-stationary kernel (wave 1 of every workgroup), printed per pass
+    static const bool stamps = getenv("JV_XB_STAMPS") != nullptr;
+    static unsigned long long* d_stamps = nullptr;
+    if (stamps && !d_stamps) HIPCHK(hipMalloc((void**)&d_stamps, 64));
+    if (stamps) HIPCHK(hipMemsetAsync(d_stamps, 0, 64, ix->xb.stream));
+    ta.stamps = stamps ? d_stamps : nullptr;
     if (!no_qs && jvk_xb_qs_ok(ta.kp)) {
         for (int q0 = 0; q0 < ta.B; q0 += 256) {
             ta.qbase = q0;
             HIPCHK(jvk_xb_qs(&ta, mode, ix->cu_count, ix->xb.stream));
         }
         ta.qbase = 0;
+        if (stamps) {
+            unsigned long long h[8];
+            HIPCHK(hipMemcpyAsync(h, d_stamps, 64, hipMemcpyDeviceToHost, ix->xb.stream));
+            HIPCHK(hipStreamSynchronize(ix->xb.stream));
+            const int nsub = (ta.rows + 31) / 32;
+            const double per = (double)std::max(1, nsub);
+            fprintf(stderr, "[jvgpu xb stamps] mode %d rows %d: cycles per stage (summed over workgroups / stages): wait+barrier A %.0f, requests %.0f, multiply %.0f, epilogue %.0f, barrier B %.0f\n",
+                    mode, ta.rows, h[0] / per, h[1] / per, h[2] / per, h[3] / per, h[4] / per);
+        }
         return JV_OK;
     }
     HIPCHK(jvk_xb_tile(&ta, mode, ix->xb.stream));

@@ -380,6 +380,7 @@ extern "C" hipError_t jvk_xb_tile(const JvXbTileArgs* a, int mode, hipStream_t s
 // rows = two groups at a time, so the groups of a pair sit on opposite halves of the 256-B bank row: bases 0 / 1152 / 2176 / 3328
 // (1 024 B each, no overlap).  3 stages x 12 chunks x 4 352 B + 7 168 B of per-query / per-stage words = 163 840 B: the whole LDS.
 #define XQ_KCH 4352
+#define XQ_PF 2       // fragment reads in flight ahead of the multiply
 __device__ __forceinline__ int xq_group_off(int g) { return g * 1024 + (g == 0 ? 0 : (g == 3 ? 256 : 128)); }
 __device__ __forceinline__ void xb_glds4(const void* g, void* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 4, 0, 0);
@@ -390,6 +391,36 @@ __device__ __forceinline__ f32x4 xq_query_factors(int sim, float qn2, float kapp
     if (sim == 0) return (f32x4){2.0f, -qn2, 2.0f * kappa * qn, 1.2e-5f * qn2};
     if (sim == 1) return (f32x4){1.0f, 0.0f, kappa * qn, 0.0f};
     return (f32x4){1.0f / qn, 0.0f, kappa, 0.0f};
+}
+
+// The FILTER pass's test, folded.  A candidate survives unless its upper bound is certainly below the bar:  v + e >= bar  with
+// v, e of xb_bounds.  Solved for the accumulator a, with e replaced by a slightly LARGER separable bound (|v| <= 2.01 (|q|^2 + |c|^2)
+// for L2, <= 1.01 |q||c| for the dot product; 2 |q||c| <= |q|^2 + |c|^2) — more survivors, never fewer:
+//     survives  <=>  !( a < P_q + Q_c - R_q * |c| )
+// three vector instructions per accumulator element instead of ~15 and a branch.  Every constant is rounded towards "survive"
+// (1e-6 relative on each term covers the fp32 evaluation of the right-hand side).  q >= B: P = +inf (never survives).
+//   L2 :  P = (bar + |q|^2 (1 - s) - c) / 2,  Q = |c|^2 (1 - s) / 2,  R = k' |q|      s = 1.2e-5 (1 + 1e-6) + 4e-7 * 2.01
+//   dot:  P = bar - c,                        Q = 0,                  R = (k' + 4.04e-7) |q|
+//   cos:  P = 0,                              Q = 0,                  R = -(bar - E) |q|,  E = k' + 2.05e-5   (a >= (bar - E) |q||c|)
+__device__ __forceinline__ f32x4 xq_filter_constants(int sim, float qn2, float bar, float kappa, bool live) {
+    const float qn = sqrtf(qn2);
+    const float k1 = kappa * 1.000001f;
+    float P, R;
+    if (sim == 0) {
+        const float s_ = 1.2e-5f * 1.000001f + 4e-7f * 2.01f;
+        P = 0.5f * (bar + qn2 * (1.0f - s_) - 1.000001e-6f);
+        P = P - 1e-6f * (fabsf(bar) + qn2);
+        R = k1 * qn * 1.000001f;
+    } else if (sim == 1) {
+        P = bar - 1.000001e-6f - 1e-6f * fabsf(bar);
+        R = (k1 + 4.04e-7f) * qn * 1.000001f;
+    } else {
+        const float d = bar - (k1 + 2.05e-5f);
+        P = 0.0f;
+        R = -d * qn * (d >= 0.0f ? 0.999998f : 1.000002f);
+    }
+    if (!live) P = __builtin_inff(), R = 0.0f;
+    return (f32x4){P, R, 0.0f, 0.0f};
 }
 
 template <int NK16, int MODE>
@@ -412,8 +443,9 @@ __global__ __launch_bounds__(512) void jvx_qs_kernel(const JvXbTileArgs a) {
     if (tid < 256) {
         const int q = a.qbase + tid;
         const float n2 = q < a.B ? a.qnorm2[q] : 0.0f;
-        s_qc[tid] = xq_query_factors(a.sim, n2, a.kappa);
-        s_thr[tid] = (MODE == 1 && q < a.B) ? a.thr[q] : 0.0f;
+        if (MODE == 1) s_qc[tid] = xq_filter_constants(a.sim, n2, q < a.B ? a.thr[q] : __builtin_inff(), a.kappa, q < a.B);
+        else s_qc[tid] = xq_query_factors(a.sim, n2, a.kappa);
+        s_thr[tid] = 0.0f;
     }
     const bool active = a.qbase + w * 32 < a.B;   // (a wave without queries still copies and meets the barriers)
     // A fragments: query row w * 32 + (lane & 31), k = 16 ks + 8 h ... + 7
@@ -483,6 +515,8 @@ __global__ __launch_bounds__(512) void jvx_qs_kernel(const JvXbTileArgs a) {
     if (w == 0) issue_ord(t0 + 2 * G, 0);
     if (t0 + G < nsub) issue_rows(1, 1, 1);
     int buf = 0, oslot = 0, nslot = 0;      // buffer / norm slot of stage t; ordinal slot of stage t + 2
+    unsigned long long st_acc[5] = {0, 0, 0, 0, 0}, st_last = __builtin_readcyclecounter();
+#define XQ_STAMP(i) if (a.stamps) { const unsigned long long t_ = __builtin_readcyclecounter(); st_acc[i] += t_ - st_last; st_last = t_; }
     for (int t = t0; t < nsub; t += G) {
         // stage t has landed once at most the copies of stage t + 1 (and wave 0's norm request) are outstanding; wave 0's
         // ordinals of stage t + 2 were requested before those, so they are in LDS too
@@ -493,8 +527,9 @@ __global__ __launch_bounds__(512) void jvx_qs_kernel(const JvXbTileArgs a) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // A
+        XQ_STAMP(0)
         // requests, oldest first: the ordinals of stage t + 3, then the rows and norms of stage t + 2
-        {
+        auto requests = [&]() {
             const int ob = oslot ^ 1;
             if (w == 0) issue_ord(t + 3 * G, ob);   // (slot ob held stage t + 1's ordinals: read before barrier B of the previous iteration)
             if (t + 2 * G < nsub) {
@@ -503,19 +538,30 @@ __global__ __launch_bounds__(512) void jvx_qs_kernel(const JvXbTileArgs a) {
                 n2 = n2 >= 3 ? n2 - 3 : n2;
                 issue_rows(b2, oslot, n2);
             }
-        }
+        };
+        if (!(a.dbg & 4)) requests();
+        XQ_STAMP(1)
         if (active) {
             const unsigned char* base = smem + buf * STAGE;
             f32x16 acc;
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[e] = 0.0f;
+            // fragment reads run XQ_PF steps ahead of the matrix instructions they feed (the order is pinned: left to itself the
+            // scheduler issues read - wait - multiply, and a stage is then 48 exposed LDS round trips: 6 us instead of ~1.5)
+            bf16x8 fc[XQ_PF + 1];
+            if (!(a.dbg & 1)) {
+#pragma unroll
+            for (int j = 0; j < XQ_PF; j++) fc[j] = *(const bf16x8*)(base + (j >> 2) * XQ_KCH + sw[j & 3]);
 #pragma unroll
             for (int ks = 0; ks < NK16; ks++) {
-                const bf16x8 fc = *(const bf16x8*)(base + (ks >> 2) * XQ_KCH + sw[ks & 3]);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[ks], fc, acc, 0, 0, 0);
-                // the register file is the query: keep the scheduler from hoisting more than a few fragment reads
-                if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                if (ks + XQ_PF < NK16) fc[(ks + XQ_PF) % (XQ_PF + 1)] = *(const bf16x8*)(base + ((ks + XQ_PF) >> 2) * XQ_KCH + sw[(ks + XQ_PF) & 3]);
+                __builtin_amdgcn_sched_barrier(0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[ks], fc[ks % (XQ_PF + 1)], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
+            }
+            XQ_STAMP(2)
+            if (!(a.dbg & 2)) {
             // ---- epilogue: lane = candidate r31 of this stage ----
             // (an OPAQUE copy of the lane id, made here: the sixteen per-row LDS addresses and predicates derived from it are then
             //  formed after the multiply instead of hoisted out of the stage loop, where they would be live — and spilled, every
@@ -527,36 +573,56 @@ __global__ __launch_bounds__(512) void jvx_qs_kernel(const JvXbTileArgs a) {
             const bool cin = ci < a.rows;
             const float cn2 = s_cn2[nslot * 64 + r31];
             const bool cval = cin && s_val[nslot * 64 + r31] != 0;   // (an invalid list entry: row 0 was staged in its place)
-            float mc = 1.0f, bc = 0.0f, kec = 1.0f, sc = 0.0f, c0 = 2e-5f;
-            if (a.sim == 0) bc = -cn2, kec = sqrtf(cn2), sc = 1.2e-5f * cn2, c0 = 1e-6f;
-            else if (a.sim == 1) kec = sqrtf(cn2), c0 = 1e-6f;
-            else mc = 1.0f / sqrtf(cn2);
+            if (MODE == 1) {
+                const float cn = sqrtf(cn2);
+                const float Qc = a.sim == 0 ? 0.5f * cn2 * (1.0f - (1.2e-5f * 1.000001f + 4e-7f * 2.01f)) * 0.999999f : 0.0f;
+                uint32_t keep = 0u;
 #pragma unroll
-            for (int reg = 0; reg < 16; reg++) {
-                const int row = w * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                const int q = a.qbase + row;
-                const f32x4 qc = s_qc[row];
-                const float v = fmaf(acc[reg] * qc[0], mc, qc[1] + bc);
-                float e = fmaf(qc[2], kec, qc[3] + sc) + c0;
-                e = fmaf(e, 1.000001f, 4e-7f * fabsf(v));
-                if (MODE == 0 || MODE == 2) {
-                    if (cin && q < a.B) a.sample[(size_t)q * a.sample_ld + ci] = !cval ? -__builtin_inff() : (MODE == 0 ? v - e : v + e);
-                } else {
-                    // NaN-proof: "certainly worse" must be TRUE to drop a candidate
-                    if (cval && q < a.B && !(v + e < s_thr[row])) {
-                        const int pos = atomicAdd(a.surv_cnt + q, 1);
-                        if (pos < a.surv_cap) a.surv[(size_t)q * a.surv_cap + pos] = (int32_t)list_pos(t, r31);
-                    }
+                for (int reg = 0; reg < 16; reg++) {
+                    const int row = w * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                    const f32x4 qc = s_qc[row];
+                    const float bar = fmaf(-qc[1], cn, qc[0] + Qc);
+                    keep |= !(acc[reg] < bar) ? (1u << reg) : 0u;   // (NaN-proof: "certainly worse" must be TRUE to drop a candidate)
                 }
-                if ((reg & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                keep = cval ? keep : 0u;
+                while (keep) {   // rare: a few survivors per query per 10^5 candidates
+                    const int reg = __ffs((int)keep) - 1;
+                    keep &= keep - 1u;
+                    const int q = a.qbase + w * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                    const int pos = atomicAdd(a.surv_cnt + q, 1);
+                    if (pos < a.surv_cap) a.surv[(size_t)q * a.surv_cap + pos] = (int32_t)list_pos(t, r31);
+                }
+            } else {
+                float mc = 1.0f, bc = 0.0f, kec = 1.0f, sc = 0.0f, c0 = 2e-5f;
+                if (a.sim == 0) bc = -cn2, kec = sqrtf(cn2), sc = 1.2e-5f * cn2, c0 = 1e-6f;
+                else if (a.sim == 1) kec = sqrtf(cn2), c0 = 1e-6f;
+                else mc = 1.0f / sqrtf(cn2);
+#pragma unroll
+                for (int reg = 0; reg < 16; reg++) {
+                    const int row = w * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                    const int q = a.qbase + row;
+                    const f32x4 qc = s_qc[row];
+                    const float v = fmaf(acc[reg] * qc[0], mc, qc[1] + bc);
+                    float e = fmaf(qc[2], kec, qc[3] + sc) + c0;
+                    e = fmaf(e, 1.000001f, 4e-7f * fabsf(v));
+                    if (cin && q < a.B) a.sample[(size_t)q * a.sample_ld + ci] = !cval ? -__builtin_inff() : (MODE == 0 ? v - e : v + e);
+                    if ((reg & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
             }
         }
+        XQ_STAMP(3)
+        if (a.dbg & 4) requests();
         // B: every fragment read of this buffer (and of the ordinal / norm slots) has returned before any wave restages it
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        XQ_STAMP(4)
         buf = buf == 2 ? 0 : buf + 1;
         nslot = nslot == 2 ? 0 : nslot + 1;
         oslot ^= 1;
     }
+    if (a.stamps && w == 1 && lane == 0)
+        for (int i = 0; i < 5; i++) atomicAdd(a.stamps + i, st_acc[i]);
+#undef XQ_STAMP
 }
 
 template <int NK16>
@@ -610,13 +676,19 @@ __global__ __launch_bounds__(256) void jvx_kth_kernel(const float* __restrict__ 
     const float inf = __builtin_inff();
     float lo = inf, hi = -inf;
     int bad = 0, fin = 0;
-    for (int i = t; i < S; i += 256) {
-        const float v = row[i];
-        if (v != v || v == inf) bad = 1;
-        else if (v != -inf) {
-            lo = fminf(lo, v);
-            hi = fmaxf(hi, v);
-            fin++;
+    for (int i0 = t; i0 < S; i0 += 1024) {   // four independent loads per step (one at a time, a pass is ~100 exposed L2 round trips)
+        float vv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) vv[u] = i0 + 256 * u < S ? row[i0 + 256 * u] : -inf;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const float v = vv[u];
+            if (v != v || v == inf) bad = 1;
+            else if (v != -inf) {
+                lo = fminf(lo, v);
+                hi = fmaxf(hi, v);
+                fin++;
+            }
         }
     }
 #pragma unroll
@@ -640,12 +712,18 @@ __global__ __launch_bounds__(256) void jvx_kth_kernel(const float* __restrict__ 
         return;
     }
     const float scale = hi > lo ? (float)(XB_KTH_BUCKETS - 1) / (hi - lo) : 0.0f;
-    for (int i = t; i < S; i += 256) {
-        const float v = row[i];
-        if (v != -inf) {
-            int b = (int)((v - lo) * scale);
-            b = b < 0 ? 0 : (b > XB_KTH_BUCKETS - 1 ? XB_KTH_BUCKETS - 1 : b);
-            atomicAdd(&s_hist[b], 1);
+    for (int i0 = t; i0 < S; i0 += 1024) {
+        float vv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) vv[u] = i0 + 256 * u < S ? row[i0 + 256 * u] : -inf;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const float v = vv[u];
+            if (v != -inf) {
+                int b = (int)((v - lo) * scale);
+                b = b < 0 ? 0 : (b > XB_KTH_BUCKETS - 1 ? XB_KTH_BUCKETS - 1 : b);
+                atomicAdd(&s_hist[b], 1);
+            }
         }
     }
     __syncthreads();
@@ -672,12 +750,18 @@ __global__ __launch_bounds__(256) void jvx_kth_kernel(const float* __restrict__ 
     __syncthreads();
     const int cut = s_cut;
     float m = inf;
-    for (int i = t; i < S; i += 256) {
-        const float v = row[i];
-        if (v != -inf) {
-            int b = (int)((v - lo) * scale);
-            b = b < 0 ? 0 : (b > XB_KTH_BUCKETS - 1 ? XB_KTH_BUCKETS - 1 : b);
-            if (b >= cut) m = fminf(m, v);
+    for (int i0 = t; i0 < S; i0 += 1024) {
+        float vv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) vv[u] = i0 + 256 * u < S ? row[i0 + 256 * u] : -inf;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const float v = vv[u];
+            if (v != -inf) {
+                int b = (int)((v - lo) * scale);
+                b = b < 0 ? 0 : (b > XB_KTH_BUCKETS - 1 ? XB_KTH_BUCKETS - 1 : b);
+                if (b >= cut) m = fminf(m, v);
+            }
         }
     }
 #pragma unroll
@@ -767,7 +851,7 @@ __global__ __launch_bounds__(256) void jvx_rescore_kernel(const JvIndexDev ix, c
         const int pos = __popcll(mk & ((1ull << lane) - 1ull));
         if (ok) todo[pos] = ord;
         __syncthreads();
-        if (m > 0) score_rows<NCHT>(ix, q_lds, todo, m, todo_score, qnorm2, ix.score_scale, lane);
+        if (m > 0) score_rows<NCHT, 2>(ix, q_lds, todo, m, todo_score, qnorm2, ix.score_scale, lane);  // (16 rows in flight per wave at d = 768: a survivor list is a few passes of dependent HBM round trips)
         __syncthreads();
         int64_t key = KEY_MIN;
         if (ok) key = make_key(todo_score[pos], doc);

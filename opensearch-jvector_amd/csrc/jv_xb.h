@@ -16,6 +16,8 @@ struct JvXbTileArgs {
     const float* qnorm2;    // [B]
     int32_t B, panels;
     int32_t qbase;          // query-stationary kernel: first query of this launch's round of <= 256
+    unsigned long long* stamps;  // diagnostics (JV_XB_STAMPS): 8 cycle accumulators of wave 1 of every workgroup, or nullptr
+    int32_t dbg;            // diagnostics (JV_XB_DBG): bit 0 skips the multiply loop, bit 1 the epilogue — timing only, wrong answers
     int32_t sim;
     float kappa;            // relative half-width of the bf16 product's error, in units of |q||c|
     float* sample;          // mode 0: [B][sample_ld] lower bounds
