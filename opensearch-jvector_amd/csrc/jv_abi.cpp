@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -27,6 +28,7 @@
 #include "../../include/jvgpu.h"
 #include "jv_device.h"
 #include "jv_xb.h"
+#include "jv_serve_host.h"
 
 extern "C" {
 // batched exact scorer (jv_kernels_xb.hip)
@@ -346,6 +348,7 @@ struct jv_index {
     struct JvQueryServer* server = nullptr;  // device-resident query server (created by the first eligible one-query call)
     struct JvQueryServer* server_f = nullptr;  // the same for one-query calls WITH a doc filter (one-wave filtered pool kernel)
     std::mutex server_mu;
+    std::condition_variable server_cv;  // a server's last caller has left (server_get waits for it before it rebuilds a ring)
 };
 enum { LAUNCH_PQW = 0, LAUNCH_PQP, LAUNCH_PQF, LAUNCH_LDS, LAUNCH_BIG, LAUNCH_SERVE, SERVED_QUERIES };
 
@@ -1229,19 +1232,29 @@ int server_launch_locked(Server* sv) {  // sv->mu held, grid not alive
 // the index's server, able to hold pools of `need_cap` entries; nullptr (with *rc set) when it cannot be provided
 Server* server_get(jv_index* ix, int kind, int need_cap, int* rc) {
     *rc = JV_OK;
-    std::lock_guard<std::mutex> lk(ix->server_mu);
+    std::unique_lock<std::mutex> lk(ix->server_mu);
     Server*& ref = kind == 0 ? ix->server : ix->server_f;
     // (the caller's reference is taken HERE, under ix->server_mu: a concurrent call that needs a larger pool waits for
     //  inflight == 0 under the same lock before it frees the server — counted after the lock was dropped, a caller could be
     //  left writing into a freed ring)
-    if (ref && ref->cap_max >= need_cap) {
-        ref->inflight++;
-        return ref;
-    }
-    if (ref) {  // a larger beam than the ring was planned for: rebuild it once nothing is in flight
-        Server* old = ref;
-        while (old->inflight.load() > 0) sched_yield();
-        server_destroy_one(ix, ref);
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(200);
+    for (;;) {
+        if (ref && ref->cap_max >= need_cap) {
+            ref->inflight++;
+            return ref;
+        }
+        if (!ref) break;
+        // a larger beam than the ring was planned for: rebuild it once nothing is in flight.  The wait RELEASES ix->server_mu
+        // (round 4 spun on `inflight` with sched_yield while holding it: every one-query caller of the index stalled for a whole
+        // in-flight query, without a bound); callers that arrive meanwhile still use the old ring.  Under steady traffic on the
+        // old ring the deadline passes and THIS call takes the launch path — no caller waits for ever.
+        if (ref->inflight.load() == 0) {
+            server_destroy_one(ix, ref);
+            break;
+        }
+        if (ix->server_cv.wait_until(lk, std::min(deadline, std::chrono::steady_clock::now() + std::chrono::milliseconds(2))) == std::cv_status::timeout &&
+            std::chrono::steady_clock::now() >= deadline)
+            return nullptr;  // (rc = JV_OK: "no server for this call" -> launch path)
     }
     if (hipSetDevice(ix->device) != hipSuccess) {
         *rc = fail(JV_EDEVICE, "hipSetDevice failed");
@@ -1383,7 +1396,7 @@ int serve_query(jv_index* ix, const float* query, int32_t topK, int32_t rerankK,
         int fslot;
         ~Leave() {
             if (fslot >= 0) filter_release(ix, fslot);
-            sv->inflight--;
+            if (--sv->inflight == 0) ix->server_cv.notify_all();
         }
     } leave{sv, ix, -1};  // (server_get took the reference)
     if (kind == 1 && cap > sv->cap_max) return 1;
@@ -1402,13 +1415,11 @@ int serve_query(jv_index* ix, const float* query, int32_t topK, int32_t rerankK,
         }
         if (hipStreamSynchronize(sv->up_stream) != hipSuccess) return fail(JV_EDEVICE, "filter upload failed");
     }
-    const uint32_t seq = sv->reserve.fetch_add(1);
-    const int si = (int)(seq & (uint32_t)(sv->slots - 1));
-    for (int spins = 0; sv->slot_free[si].load(std::memory_order_acquire) != seq; spins++) {  // the slot's previous occupant is still reading its row
-        if (spins > 64) sched_yield();
-    }
+    // the ticket protocol's caller side: csrc/jv_serve_host.h (shared with the sanitizer test, tests/native/serve_sim.cpp)
+    int si = 0;
+    const uint32_t seq = jvsh_take_slot(sv, &si);
     unsigned char* sp = sv->ring + (size_t)si * (size_t)sv->slot_bytes;
-    JvServeSlot* slot = (JvServeSlot*)sp;
+    JvServeSlot* slot = jvsh_slot(sv, si);
     slot->topK = topK;
     slot->rk = rerankK;
     slot->visit_limit = visit_limit > 0 ? (int32_t)std::min<int64_t>(visit_limit, INT32_MAX) : 0;
@@ -1418,51 +1429,21 @@ int serve_query(jv_index* ix, const float* query, int32_t topK, int32_t rerankK,
     slot->done = 0;
     slot->count = 0;
     slot->flags = 0;
-    slot->ticket = (int32_t)seq;  // (a grid only answers a slot whose content belongs to the ticket it claimed)
+    // (a grid only answers a slot whose content belongs to the ticket it claimed; an atomic store: a grid that claimed an
+    //  ABANDONED ticket of this slot's previous occupant may be reading the word right now)
+    __atomic_store_n(&slot->ticket, (int32_t)seq, __ATOMIC_RELAXED);
     memcpy(sp + JV_SERVE_QUERY_OFF, query, (size_t)ix->dev.d * sizeof(float));
-    // publish in ticket order
-    for (int spins = 0; (uint32_t)__atomic_load_n(&sv->h_words[JV_SH_TAIL], __ATOMIC_ACQUIRE) != seq; spins++) {
-        if (spins > 256) sched_yield();
-    }
-    __atomic_store_n(&sv->h_words[JV_SH_TAIL], (int32_t)(seq + 1), __ATOMIC_RELEASE);
-    struct timespec t0;
-    clock_gettime(CLOCK_MONOTONIC, &t0);
-    auto ensure_alive = [&]() -> int {
+    jvsh_publish(sv, seq);
+    auto ensure_alive = [&](auto&& give_up) -> int {
         if (__atomic_load_n(&sv->h_words[JV_SH_ALIVE], __ATOMIC_ACQUIRE) != 0) return JV_OK;
         std::lock_guard<std::mutex> lk(sv->mu);
         if (__atomic_load_n(&sv->h_words[JV_SH_ALIVE], __ATOMIC_ACQUIRE) != 0) return JV_OK;
         hipStreamSynchronize(sv->stream);  // (the previous grid has signalled its exit: let its launch retire)
-        return server_launch_locked(sv);
+        const int r = server_launch_locked(sv);
+        if (r != JV_OK) give_up();  // (under sv->mu: no other caller can start a grid before the slot is marked abandoned)
+        return r;
     };
-    if ((rc = ensure_alive()) != JV_OK) {
-        // nobody answers this call: the ticket stays published, so the slot is marked abandoned before it is handed on — the
-        // grid that claims the ticket later finds another generation in the slot and skips it
-        __atomic_store_n(&slot->ticket, (int32_t)(seq ^ 0x40000000u), __ATOMIC_RELEASE);
-        sv->slot_free[si].store(seq + (uint32_t)sv->slots, std::memory_order_release);
-        return rc;
-    }
-    // sleep through most of the expected latency, then poll
-    const int est = sv->lat_us.load(std::memory_order_relaxed);
-    long nap_ns = (long)est * 600;  // 0.6 x
-    for (int it = 0;; it++) {
-        if (__atomic_load_n(&slot->done, __ATOMIC_ACQUIRE) != 0) break;
-        if (it < 3 && est < 200) {
-            sched_yield();
-            continue;
-        }
-        struct timespec ts = {0, std::max<long>(20000, std::min<long>(nap_ns, 5000000))};
-        nanosleep(&ts, nullptr);
-        nap_ns = std::max<long>(20000, (long)est * 25);  // then every est / 40
-        if ((it & 7) == 7 && (rc = ensure_alive()) != JV_OK) {
-            __atomic_store_n(&slot->ticket, (int32_t)(seq ^ 0x40000000u), __ATOMIC_RELEASE);
-            sv->slot_free[si].store(seq + (uint32_t)sv->slots, std::memory_order_release);
-            return rc;
-        }
-    }
-    struct timespec t1;
-    clock_gettime(CLOCK_MONOTONIC, &t1);
-    const int us = (int)std::min<int64_t>(1000000, (int64_t)(t1.tv_sec - t0.tv_sec) * 1000000 + (t1.tv_nsec - t0.tv_nsec) / 1000);
-    sv->lat_us.store((est * 7 + us) / 8, std::memory_order_relaxed);
+    if ((rc = jvsh_wait_done(sv, slot, seq, si, ensure_alive)) != JV_OK) return rc;
     const uint32_t f = (uint32_t)slot->flags;
     int ret = JV_OK;
     if (f & (JV_FLAG_OVERFLOW | JV_FLAG_FAILED)) {
@@ -1481,7 +1462,7 @@ int serve_query(jv_index* ix, const float* query, int32_t topK, int32_t rerankK,
         if (out_flags) *out_flags = (int32_t)(f & (JV_FLAG_BIG | JV_FLAG_EARLY));
         ix->launches[SERVED_QUERIES]++;
     }
-    sv->slot_free[si].store(seq + (uint32_t)sv->slots, std::memory_order_release);
+    jvsh_release(sv, seq, si);
     return ret;
 }
 
