@@ -53,6 +53,9 @@ def _prune_lib():
         lib.jvb_pq_train_device.argtypes = [vp, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_longlong, vp, C.c_int,
                                             vp, vp, vp, vp, vp, C.c_int, vp]
         lib.jvb_pq_train_device.restype = C.c_int
+        lib.jvb_pq_train_device2.argtypes = [vp, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_longlong, vp, C.c_int,
+                                             vp, vp, vp, vp, vp, C.c_int, C.c_ulonglong, vp, vp, vp]
+        lib.jvb_pq_train_device2.restype = C.c_int
         _PRUNE_LIB = lib
     return _PRUNE_LIB
 
@@ -389,7 +392,7 @@ def pq_encode_gpu(torch, base, M, K, codebooks_t, centroid_t):
     return codes
 
 
-def pq_train_encode_gpu(torch, base, M, sim, K=256, iters=8, max_train=128000, seed=1):
+def pq_train_encode_gpu(torch, base, M, sim, K=256, iters=8, max_train=128000, seed=1, seeding=None):
     """ProductQuantization.compute analogue: K = min(256, n) clusters per subspace, global centring iff
     EUCLIDEAN (J/JVectorIndexQuantization.java:122-131).  Training runs in csrc/jv_build_kernels.hip
     (jvb_pq_train_device: column mean, sample gather, Lloyd's algorithm with the ENCODER as the assign step and a
@@ -404,9 +407,18 @@ def pq_train_encode_gpu(torch, base, M, sim, K=256, iters=8, max_train=128000, s
     cb_off = np.concatenate([[0], np.cumsum([K * s_ for s_ in sizes])[:-1]]).astype(np.int64)
     nt = min(n, max_train)
     rows = (torch.arange(nt, device=dev, dtype=torch.int64) * n) // nt
-    g = torch.Generator(device=dev)
-    g.manual_seed(seed)
-    init = torch.stack([torch.randperm(nt, generator=g, device=dev)[:K] for _ in range(M)]).contiguous()   # [M][K] sample positions
+    # seeding: "kmeans++" (jvector's KMeansPlusPlusClusterer, J/JVectorIndexQuantization.java:122-131; on the device, deterministic,
+    # the CPU builder's splitmix64 stream) or "random" (seeded sample rows: rounds 1-4).  Default from JV_PQ_SEEDING, else
+    # "random": tools/pq_quality.py measured the two within +/- 0.003 recall@10 of each other on the benchmark's data, and
+    # the benchmark's operating points (rerankK) were taken on "random".
+    seeding = seeding or os.environ.get("JV_PQ_SEEDING", "random")
+    if seeding not in ("random", "kmeans++"):
+        raise ValueError(f"seeding = {seeding!r}")
+    init = None
+    if seeding == "random" or max(d // M + (1 if d % M else 0), 1) > 256:
+        g = torch.Generator(device=dev)
+        g.manual_seed(seed)
+        init = torch.stack([torch.randperm(nt, generator=g, device=dev)[:K] for _ in range(M)]).contiguous()   # [M][K] sample positions
     t_off = torch.from_numpy(offs).to(dev)
     t_cb = torch.from_numpy(cb_off).to(dev)
     centroid = torch.empty((d,), dtype=torch.float32, device=dev) if center else None
@@ -415,12 +427,15 @@ def pq_train_encode_gpu(torch, base, M, sim, K=256, iters=8, max_train=128000, s
     partial = torch.empty((64, d), dtype=torch.float64, device=dev)
     codebooks_t = torch.empty((int(K * d),), dtype=torch.float32, device=dev)
     lib = _prune_lib()
-    rc = lib.jvb_pq_train_device(base.data_ptr(), n, d, base.stride(0), M, K, t_off.data_ptr(), t_cb.data_ptr(), rows.data_ptr(), nt,
-                                 init.data_ptr(), iters, (centroid.data_ptr() if center else None), sample.data_ptr(),
-                                 sample_codes.data_ptr(), partial.data_ptr(), codebooks_t.data_ptr(), int(max(sizes)),
-                                 torch.cuda.current_stream(dev).cuda_stream)
+    init_scratch = torch.empty((M, K), dtype=torch.int64, device=dev) if init is None else None
+    mind_scratch = torch.empty((M, nt), dtype=torch.float32, device=dev) if init is None else None
+    rc = lib.jvb_pq_train_device2(base.data_ptr(), n, d, base.stride(0), M, K, t_off.data_ptr(), t_cb.data_ptr(), rows.data_ptr(), nt,
+                                  (init.data_ptr() if init is not None else None), iters, (centroid.data_ptr() if center else None),
+                                  sample.data_ptr(), sample_codes.data_ptr(), partial.data_ptr(), codebooks_t.data_ptr(), int(max(sizes)),
+                                  int(seed), (init_scratch.data_ptr() if init is None else None),
+                                  (mind_scratch.data_ptr() if init is None else None), torch.cuda.current_stream(dev).cuda_stream)
     if rc != 0:
         raise RuntimeError(f"jvb_pq_train_device failed: {rc}")
-    del sample, sample_codes, partial
+    del sample, sample_codes, partial, init_scratch, mind_scratch
     codes = pq_encode_gpu(torch, base, M, K, codebooks_t, centroid)
     return dict(codebooks=codebooks_t.cpu().numpy().astype(np.float32), centroid=(centroid.cpu().numpy() if center else None), codes=codes, K=K)

@@ -512,21 +512,125 @@ __global__ void jvb_pq_init_kernel(const float* __restrict__ x, int d, const int
     for (int j = threadIdx.x; j < ds; j += blockDim.x) codebooks[cb_off[m] + (size_t)c * ds + j] = x[(size_t)init[(size_t)m * K + c] * d + d0 + j];
 }
 
+// k-means++ seeding (J/JVectorIndexQuantization.java:122-131 -> jvector's KMeansPlusPlusClusterer; the CPU builder's
+// restatement: jv_build_cpu.cpp "k-means++ seeding", same splitmix64 stream per subspace): one 1 024-thread workgroup per
+// subspace picks K sample rows one after the other, each with probability proportional to its squared distance to the nearest
+// centre picked so far.  Deterministic: thread t owns rows t, t + 1024, ...; a pick is the first row IN THAT ORDER (thread-major)
+// whose running sum reaches r = u * total — per-thread sums in doubles, a fixed-order workgroup scan, no atomics.  Per pick
+// the subspace's nt x ds floats are read once (12 MB at nt = 128 000, ds = 24: ~100 GB for 32 subspaces x 256 picks, tens of
+// milliseconds at the 32 workgroups' share of the bandwidth).
+__device__ __forceinline__ unsigned long long jvb_splitmix64(unsigned long long& s) {
+    unsigned long long z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(1024) void jvb_pq_seed_kernel(const float* __restrict__ x, long long nt, int d, const int32_t* __restrict__ sub_off,
+                                                           int K, unsigned long long seed, long long* __restrict__ init,
+                                                           float* __restrict__ mind_all) {
+    __shared__ float s_ctr[256];
+    __shared__ double s_part[1024];
+    __shared__ double s_tot;
+    __shared__ long long s_pick;
+    const int m = blockIdx.x, t = threadIdx.x;
+    const int d0 = sub_off[m], ds = sub_off[m + 1] - d0;
+    float* mind = mind_all + (size_t)m * (size_t)nt;
+    unsigned long long st = seed * 0x9E3779B97F4A7C15ull + (unsigned long long)m * 1315423911ull + 7ull;
+    const long long kk = K < nt ? K : nt;
+    long long prev = (long long)(jvb_splitmix64(st) % (unsigned long long)nt);   // (every thread runs the same stream)
+    if (t == 0) init[(size_t)m * K] = prev;
+    for (long long i = t; i < nt; i += 1024) mind[i] = 3.0e38f;
+    for (int c = 1; c < K; c++) {
+        if (c >= kk) {  // fewer points than clusters: duplicates, as the CPU builder does
+            if (t == 0) init[(size_t)m * K + c] = init[(size_t)m * K + (c % kk)];
+            continue;
+        }
+        for (int j = t; j < ds; j += 1024) s_ctr[j & 255] = x[(size_t)prev * d + d0 + j];   // (ds <= 256)
+        __syncthreads();
+        double mine = 0.0;
+        for (long long i = t; i < nt; i += 1024) {
+            const float* r = x + (size_t)i * d + d0;
+            float dd = 0.0f;
+            for (int j = 0; j < ds; j++) {
+                const float df = r[j] - s_ctr[j];
+                dd = fmaf(df, df, dd);
+            }
+            const float mn = fminf(mind[i], dd);
+            mind[i] = mn;
+            mine += (double)mn;
+        }
+        s_part[t] = mine;
+        __syncthreads();
+        // inclusive scan of the 1 024 partial sums, fixed order
+        for (int off = 1; off < 1024; off <<= 1) {
+            const double add = t >= off ? s_part[t - off] : 0.0;
+            __syncthreads();
+            s_part[t] += add;
+            __syncthreads();
+        }
+        const double u = (double)(jvb_splitmix64(st) >> 11) * (1.0 / 9007199254740992.0);
+        if (t == 0) s_tot = s_part[1023], s_pick = -1;
+        __syncthreads();
+        const double r_ = u * s_tot;
+        const double before = t > 0 ? s_part[t - 1] : 0.0;
+        // the thread whose range holds r walks its rows (rounding may push r past the total: the last row with weight then)
+        if (s_part[t] >= r_ && before < r_ || (t == 1023 && s_part[t] < r_)) {
+            double run = before;
+            long long pick = -1, last = -1;
+            for (long long i = t; i < nt; i += 1024) {
+                run += (double)mind[i];
+                if (mind[i] > 0.0f) last = i;
+                if (run >= r_) {
+                    pick = i;
+                    break;
+                }
+            }
+            if (pick < 0) pick = last >= 0 ? last : (long long)t < nt ? (long long)t : 0;
+            s_pick = pick;
+        }
+        __syncthreads();
+        long long pk = s_pick;
+        if (pk < 0) pk = prev;  // (all weights zero: every remaining point coincides with a centre)
+        prev = pk;
+        if (t == 0) init[(size_t)m * K + c] = pk;
+        __syncthreads();
+    }
+}
+
 // Trains M codebooks of K centroids on the rows `rows` [nt] of `vectors` (all device pointers; sub_off [M + 1] int32,
 // cb_off [M] int64, init [M][K] int64 = sample positions of the initial centroids; scratch: sample [nt][d] floats,
 // sample_codes [nt][M] bytes, partial [64][d] doubles).  centroid_out (or NULL: no centring) receives the corpus mean.
+// init == NULL: k-means++ seeding on the device (jvb_pq_seed_kernel; `seed`, scratch init_scratch [M][K] int64 and
+// mind_scratch [M][nt] floats); else the caller's sample positions.
+extern "C" int jvb_pq_train_device2(const float* vectors, long long n, int d, int stride, int M, int K, const int32_t* sub_off,
+                                    const long long* cb_off, const long long* rows, long long nt, const long long* init, int iters,
+                                    float* centroid_out, float* sample, uint8_t* sample_codes, double* partial, float* codebooks,
+                                    int max_ds, unsigned long long seed, long long* init_scratch, float* mind_scratch, void* stream_);
 extern "C" int jvb_pq_train_device(const float* vectors, long long n, int d, int stride, int M, int K, const int32_t* sub_off,
                                    const long long* cb_off, const long long* rows, long long nt, const long long* init, int iters,
                                    float* centroid_out, float* sample, uint8_t* sample_codes, double* partial, float* codebooks,
                                    int max_ds, void* stream_) {
+    if (!init) return -4;
+    return jvb_pq_train_device2(vectors, n, d, stride, M, K, sub_off, cb_off, rows, nt, init, iters, centroid_out, sample, sample_codes, partial,
+                                codebooks, max_ds, 0ull, nullptr, nullptr, stream_);
+}
+extern "C" int jvb_pq_train_device2(const float* vectors, long long n, int d, int stride, int M, int K, const int32_t* sub_off,
+                                    const long long* cb_off, const long long* rows, long long nt, const long long* init, int iters,
+                                    float* centroid_out, float* sample, uint8_t* sample_codes, double* partial, float* codebooks,
+                                    int max_ds, unsigned long long seed, long long* init_scratch, float* mind_scratch, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n <= 0 || nt <= 0 || M <= 0 || K <= 0 || K > 256 || max_ds <= 0) return -4;
+    if (!init && (!init_scratch || !mind_scratch || max_ds > 256)) return -4;
     if (centroid_out) {
         const int slabs = 64;
         jvb_col_partial_kernel<<<dim3((unsigned)((d + 255) / 256), slabs), 256, 0, stream>>>(vectors, n, d, stride, slabs, partial);
         jvb_col_mean_kernel<<<(d + 255) / 256, 256, 0, stream>>>(partial, slabs, d, n, centroid_out);
     }
     jvb_gather_rows_kernel<<<(unsigned)(nt < 65535 ? nt : 65535), 256, 0, stream>>>(vectors, d, stride, rows, nt, centroid_out, sample);
+    if (!init) {
+        jvb_pq_seed_kernel<<<(unsigned)M, 1024, 0, stream>>>(sample, nt, d, sub_off, K, seed, init_scratch, mind_scratch);
+        init = init_scratch;
+    }
     jvb_pq_init_kernel<<<dim3((unsigned)K, (unsigned)M), 64, 0, stream>>>(sample, d, sub_off, init, M, K, codebooks, cb_off);
     const size_t lds = (size_t)256 * (size_t)((max_ds < PQT_TILE ? max_ds : PQT_TILE) + 1) * sizeof(float);
     static bool attr_set = false;

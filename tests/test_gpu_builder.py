@@ -183,11 +183,11 @@ def test_wide_ef_construction_and_back_to_back_builds_with_different_degrees(pkg
         gpu.close()
         return float(np.mean([len(set(got.nodes[i]) & set(truth[i])) / 10 for i in range(nq)]))
 
-    ref = recall(*gb.build_graph_gpu(torch, bt, 0, R=32, L=100, verbose=False, refine_passes=1), 32)
+    ref = {p: recall(*gb.build_graph_gpu(torch, bt, 0, R=32, L=100, verbose=False, refine_passes=p), 32) for p in (0, 1)}
     for L, passes in ((128, 1), (200, 0), (200, 1)):
         adj, entry = gb.build_graph_gpu(torch, bt, 0, R=32, L=L, verbose=False, refine_passes=passes)
         assert adj.shape == (n, 32) and int((adj >= n).sum()) == 0
-        assert recall(adj, entry, 32) >= ref - 0.02, (L, passes, ref)
+        assert recall(adj, entry, 32) >= ref[passes] - 0.01, (L, passes, ref)   # (measured: 0.949 / 0.914 / 0.952 against 0.9445 / 0.9085)
     # same n, different degree, back to back
     a16, e16 = gb.build_graph_gpu(torch, bt, 0, R=16, L=100, verbose=False)
     a48, e48 = gb.build_graph_gpu(torch, bt, 0, R=48, L=100, verbose=False)
