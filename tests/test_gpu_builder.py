@@ -112,6 +112,38 @@ def test_pq_training_is_lloyd_and_improves_on_its_start(pkg, d, M, sim):
     assert small["K"] == 100
 
 
+def test_kmeanspp_seeding_on_the_device(pkg):
+    """jvector seeds its PQ codebooks with k-means++ (J/JVectorIndexQuantization.java:122-131 -> ProductQuantization.compute);
+    the GPU trainer drew random sample rows.  jvb_pq_seed_kernel (one workgroup per subspace, fixed-order scan, the CPU builder's
+    splitmix64 stream): two trainings are bit-equal, the SEEDS alone quantise better than random rows do, and after Lloyd the
+    codebooks are no worse.  (Recall at the benchmark's operating point: tools/pq_quality.py)"""
+    torch, gb = _gb()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    cen = torch.randn((200, 96), generator=g, device=dev)
+    base = cen[torch.randint(0, 200, (60000,), generator=g, device=dev)] + 0.3 * torch.randn((60000, 96), generator=g, device=dev)
+
+    def distortion(pq):
+        M, K = 16, pq["K"]
+        cb = torch.from_numpy(pq["codebooks"]).to(dev).view(M, K, 96 // M)
+        rows = base - torch.from_numpy(pq["centroid"]).to(dev)
+        codes = pq["codes"].long()
+        rec = torch.stack([cb[m][codes[:, m]] for m in range(M)], 1).reshape(rows.shape[0], 96)
+        return float(((rows - rec) ** 2).sum(1).mean())
+
+    a = gb.pq_train_encode_gpu(torch, base, 16, 0, seeding="kmeans++")
+    c = gb.pq_train_encode_gpu(torch, base, 16, 0, seeding="kmeans++")
+    assert np.array_equal(a["codebooks"], c["codebooks"]) and torch.equal(a["codes"], c["codes"])
+    seeds_pp = distortion(gb.pq_train_encode_gpu(torch, base, 16, 0, iters=0, seeding="kmeans++"))
+    seeds_rnd = distortion(gb.pq_train_encode_gpu(torch, base, 16, 0, iters=0, seeding="random"))
+    assert seeds_pp < seeds_rnd, (seeds_pp, seeds_rnd)
+    assert distortion(a) <= 1.02 * distortion(gb.pq_train_encode_gpu(torch, base, 16, 0, seeding="random"))
+    # fewer points than clusters, and a subspace count that does not divide d
+    small = gb.pq_train_encode_gpu(torch, base[:100].contiguous(), 7, 1, seeding="kmeans++")
+    assert small["K"] == 100 and small["codes"].shape == (100, 7)
+
+
 def test_ka15_recall_floor_through_the_gpu_builder(pkg, pyoracle):
     """KA15 (JVectorWriterMergeTests.java:55,78-92,122-123,178-212): base = java.util.Random(42) floats, queries =
     Random(43), d = 128, k = 10, L2, recall against brute force on the reference's 10 queries — graph from the GPU builder

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """How much recall do the PQ codebooks leave on the table?  Same graph, same queries; the codebooks trained with different
 Lloyd iteration counts / sample sizes / seeds; recall@10 at a few rerankK against brute-force ground truth on 2 048 queries.
-env: N (docs, default 2M), DIST, RKS, CONFIGS ("iters:max_train:seed,...")."""
+env: N (docs, default 2M), DIST, RKS, CONFIGS ("iters:max_train:seed[:pp],...": a fourth field pp = k-means++ seeding)."""
 import importlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -14,7 +14,7 @@ import bench
 
 n = int(os.environ.get("N", 2_000_000)); d = 768; M = 32; NQ = 2048
 rks = [int(x) for x in os.environ.get("RKS", "800,1000,1100,1200").split(",")]
-cfgs = [tuple(int(v) for v in c.split(":")) for c in os.environ.get("CONFIGS", "8:128000:1,8:128000:2,25:128000:1,25:512000:1").split(",")]
+cfgs = [tuple(c.split(":")) for c in os.environ.get("CONFIGS", "8:128000:1,8:128000:2,8:128000:1:pp,8:128000:2:pp,25:128000:1,25:128000:1:pp").split(",")]
 dev = torch.device("cuda", 0)
 base, q = bench.make_pq_data(torch, os.environ.get("DIST", "rotated"), n, NQ, d, M, 0, n, False, dev)
 adj, entry = gb.build_graph_gpu(torch, base, 0, R=32, L=100, verbose=False)
@@ -22,9 +22,11 @@ gt = bench.brute_force_topk(torch, base, q, 10, 0)
 o = [torch.empty((NQ, 10), dtype=torch.int32, device=dev), torch.empty((NQ, 10), dtype=torch.int32, device=dev),
      torch.empty((NQ, 10), dtype=torch.float32, device=dev), torch.empty((NQ,), dtype=torch.int32, device=dev),
      torch.zeros((NQ, 4), dtype=torch.int32, device=dev), torch.empty((NQ,), dtype=torch.int32, device=dev)]
-for iters, max_train, seed in cfgs:
+for cfg in cfgs:
+    iters, max_train, seed = int(cfg[0]), int(cfg[1]), int(cfg[2])
+    seeding = "kmeans++" if len(cfg) > 3 and cfg[3] == "pp" else "random"
     t0 = time.time()
-    pq = gb.pq_train_encode_gpu(torch, base, M, 0, iters=iters, max_train=max_train, seed=seed)
+    pq = gb.pq_train_encode_gpu(torch, base, M, 0, iters=iters, max_train=max_train, seed=seed, seeding=seeding)
     torch.cuda.synchronize()
     t_train = time.time() - t0
     # distortion of the codes on the first 200 000 rows
@@ -42,6 +44,6 @@ for iters, max_train, seed in cfgs:
         ix.search_batch_device(q.data_ptr(), NQ, 10, rk, *[t_.data_ptr() for t_ in o])
         torch.cuda.synchronize()
         out.append(f"{rk}: {bench.recall_of(o[1], gt):.4f}")
-    print(f"iters {iters:3d} sample {max_train:7d} seed {seed}: train+encode {t_train:5.1f} s, distortion {dist:.5f}; recall@10 " + "  ".join(out), flush=True)
+    print(f"iters {iters:3d} sample {max_train:7d} seed {seed} seeding {seeding:8s}: train+encode {t_train:5.1f} s, distortion {dist:.5f}; recall@10 " + "  ".join(out), flush=True)
     ix.close()
     del pq, cb, rec, codes
