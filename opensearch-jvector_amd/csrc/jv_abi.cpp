@@ -75,8 +75,8 @@ hipError_t jvk_launch_search_pqw(const JvIndexDev* ix, const JvSearchArgs* a, in
 // the same kernel with a doc filter (jv_kernels_pqwf.hip): pools of up to 16 384 entries
 hipError_t jvk_pqwf_set_max_lds(int bytes);
 int jvk_pqwf_ok(const JvIndexDev* ix, int cap);
-int jvk_pqwf_max_entries(void);
-int jvk_pqwf_lds_rows(int cap);
+int jvk_pqwf_max_entries(const JvIndexDev* ix);
+int jvk_pqwf_lds_rows(const JvIndexDev* ix, int cap);
 int jvk_pqwf_blocks_per_cu(const JvIndexDev* ix, int cap, int lds_bytes);
 hipError_t jvk_launch_search_pqwf(const JvIndexDev* ix, const JvSearchArgs* a, int lds_bytes, int blocks, hipStream_t s);
 // device-resident query server (jv_kernels_pqs.hip)
@@ -766,7 +766,10 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
                           (rk + 64 + ix->dev.R > 256 || OPT(ix, OPT_LUTR_MIN_QUERIES) == 0 || lutr_applies || pqwf_applies);
     // (shapes whose table leaves the GENERIC kernel no room — g.fast_ok false, e.g. PQ-128 at wide beams — still run the
     //  several-waves kernel, which keeps the table in registers + LDS rows)
-    if ((!force_big || (OPT(ix, OPT_FORCE_BIG) == 0 && !g.lutg && pqw_applies)) && (pqp_plain || pqp_filt) && pqf_index && rk + 64 + ix->dev.R <= jvk_pqp_max_entries() && OPT(ix, OPT_NO_PQF) == 0 &&
+    // (round 5: the default codecs — PQ-128 / PQ-192, tables beyond the LDS — WITH a doc filter run the several-waves filtered
+    //  kernel first as well (jv_kernels_pqw12f.hip); the HBM-table rung only redoes what comes back flagged)
+    const bool pqwf_wide = pqwf_applies && ix->dev.pq_M >= 128 && thr <= 0.0f && !ix->build_client;
+    if ((!force_big || (OPT(ix, OPT_FORCE_BIG) == 0 && ((!g.lutg && pqw_applies) || pqwf_wide))) && (pqp_plain || pqp_filt) && (pqf_index || pqwf_wide) && rk + 64 + ix->dev.R <= jvk_pqp_max_entries() && OPT(ix, OPT_NO_PQF) == 0 &&
         OPT(ix, OPT_NO_PQP) == 0) {
         JvSearchArgs ap = a;
         if (filtered && a.accept_stride == 0 && ix->dev.ord2doc && nq >= 16) {
@@ -814,12 +817,12 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
         // filtered kernel below — 2 x the pool first, then the largest pools that keep 4, 3, 2, 1 workgroups per CU — with two /
         // four waves per query, two fused blocks per scoring pass and the table's rows in registers + LDS.
         const bool pqwf = filtered && OPT(ix, OPT_NO_PQW) == 0 && jvk_pqwf_ok(&ix->dev, ap.cand_cap) && nq >= OPT(ix, OPT_PQW_MIN_QUERIES);
-        auto planF = [&](JvSearchArgs& x, bool regs) { return pqwf ? plan_pqw_lds(ix, x, 0, jvk_pqwf_lds_rows(x.cand_cap)) : plan(x, regs); };
+        auto planF = [&](JvSearchArgs& x, bool regs) { return pqwf ? plan_pqw_lds(ix, x, 0, jvk_pqwf_lds_rows(&ix->dev, x.cand_cap)) : plan(x, regs); };
         auto blocksF = [&](int cap, int lds_b, int lutr_) { return pqwf ? jvk_pqwf_blocks_per_cu(&ix->dev, cap, lds_b) : jvk_pqp_blocks_per_cu(&ix->dev, cap, lds_b, lutr_, 1); };
         auto launchF = [&](const JvSearchArgs& x, int lds_b, int blocks_, int lutr_) {
             return pqwf ? jvk_launch_search_pqwf(&ix->dev, &x, lds_b, blocks_, stream) : jvk_launch_search_pqp(&ix->dev, &x, lds_b, blocks_, lutr_, stream);
         };
-        const int max_entries_f = pqwf ? jvk_pqwf_max_entries() : jvk_pqp_max_entries_filtered();
+        const int max_entries_f = pqwf ? jvk_pqwf_max_entries(&ix->dev) : jvk_pqp_max_entries_filtered();
         const int lds = pqw ? plan_pqw_lds(ix, ap, pqw_variant) : (pqwf ? planF(ap, false) : plan(ap, lutr != 0));
         // second launch for what outgrows the first (more than 63 ties at the rerankK boundary, a longer expansion log):
         // table in LDS, as many tie slots as the largest pool class allows, 4x the log; walks the flag array

@@ -15,8 +15,10 @@ static const pqwf_kernel_t g_pqwf_kernels[2][5][4] = {
     {JV_PQWF_ROW(1, 2, 3, 4), JV_PQWF_ROW(2, 2, 3, 4), JV_PQWF_ROW(3, 2, 2, 0), JV_PQWF_ROW(4, 2, 2, 0), JV_PQWF_ROW(5, 2, 2, 0)},
     {JV_PQWF_ROW(1, 4, 4, 4), JV_PQWF_ROW(2, 4, 4, 4), JV_PQWF_ROW(3, 4, 3, 0), JV_PQWF_ROW(4, 4, 2, 0), JV_PQWF_ROW(5, 4, 2, 0)},
 };
-// table rows a wave keeps in LDS for a pool of `cap` entries
-extern "C" int jvk_pqwf_lds_rows(int cap) { return cap <= 2048 ? 4 : 0; }
+// table rows a wave keeps in LDS for a pool of `cap` entries (PQ-128 / PQ-192: always eight, jv_kernels_pqw12f.hip)
+extern "C" int jvk_pqwf_lds_rows(const JvIndexDev* ix, int cap) { return ix->pq_M >= 128 ? 8 : (cap <= 2048 ? 4 : 0); }
+extern "C" const void* jvk_pqw12f_kernel(int waves, int capk, int nch);
+extern "C" hipError_t jvk_pqw12f_set_max_lds(int bytes);
 
 static int pqwf_nch_slot(const JvIndexDev* ix) {
     if (ix->nvq_M > 0) return 0;  // the NVQ decoder lives in the "any d" instances only (score_rows)
@@ -24,16 +26,24 @@ static int pqwf_nch_slot(const JvIndexDev* ix) {
     return ix->nch == 2 ? 1 : ix->nch == 12 ? 2 : ix->nch == 24 ? 3 : 0;
 }
 static int pqwf_capk(int cap) { return cap <= 1024 ? 1 : cap <= 2048 ? 2 : cap <= 4096 ? 3 : cap <= 8192 ? 4 : 5; }
-extern "C" int jvk_pqwf_max_entries(void) { return 16384; }
+extern "C" int jvk_pqwf_max_entries(const JvIndexDev* ix) { return ix->pq_M >= 128 ? 4096 : 16384; }
 // shapes this kernel runs (jvk_pqw_ok's, with the filtered key's 29 ordinal bits)
 extern "C" int jvk_pqwf_ok(const JvIndexDev* ix, int cap) {
-    if (!(ix->pq_M == 32 || ix->pq_M == 64) || ix->sim == 2 || !ix->pq_fused || ix->num_upper != 0) return 0;
+    if (!(ix->pq_M == 32 || ix->pq_M == 64 || ix->pq_M == 128 || ix->pq_M == 192) || ix->sim == 2 || !ix->pq_fused || ix->num_upper != 0) return 0;
     if (ix->R < 1 || ix->R > JV_WAVE || 64 % ((JV_WAVE / ix->R) * 8) != 0) return 0;
-    return cap <= 16384 && ix->n < (1 << 29) ? 1 : 0;
+    if (ix->pq_M >= 128 && ix->nvq_M > 0) return 0;  // (the default-codec instances carry no NVQ decoder)
+    return cap <= jvk_pqwf_max_entries(ix) && ix->n < (1 << 29) ? 1 : 0;
 }
-static pqwf_kernel_t pqwf_pick(const JvIndexDev* ix, int cap) { return g_pqwf_kernels[ix->pq_M == 64 ? 1 : 0][pqwf_capk(cap) - 1][pqwf_nch_slot(ix)]; }
+static pqwf_kernel_t pqwf_pick(const JvIndexDev* ix, int cap) {
+    if (ix->pq_M >= 128) return (pqwf_kernel_t)jvk_pqw12f_kernel(ix->pq_M / 16, pqwf_capk(cap), ix->stride == ix->nch * 64 ? ix->nch : 0);
+    return g_pqwf_kernels[ix->pq_M == 64 ? 1 : 0][pqwf_capk(cap) - 1][pqwf_nch_slot(ix)];
+}
 
 extern "C" hipError_t jvk_pqwf_set_max_lds(int bytes) {
+    {
+        hipError_t e = jvk_pqw12f_set_max_lds(bytes);
+        if (e != hipSuccess) return e;
+    }
     for (int w = 0; w < 2; w++)
         for (int c = 0; c < 5; c++)
             for (int s = 0; s < 4; s++) {

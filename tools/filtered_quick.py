@@ -16,8 +16,9 @@ n = int(os.environ.get("N", 2_000_000)); d = 768; M = 32; rk = int(os.environ.ge
 dev = torch.device("cuda", 0)
 base, q = bench.make_pq_data(torch, os.environ.get("DIST", "aligned"), n, B, d, M, 0, n, False, dev)
 adj, entry = gb.build_graph_gpu(torch, base, 0, R=32, L=100, verbose=False)
-pq = gb.pq_train_encode_gpu(torch, base, M, 0)
-desc, keep = b.make_desc_device(n, d, 32, base.data_ptr(), adj.data_ptr(), entry, 0, pq_M=M, pq_K=pq["K"], pq_codebooks=pq["codebooks"],
+CM = int(os.environ.get("CODEC_M", M))   # the codec's subspaces (192 = the plugin's default for 768-d fields); the DATA keeps the PQ-32 block structure
+pq = gb.pq_train_encode_gpu(torch, base, CM, 0)
+desc, keep = b.make_desc_device(n, d, 32, base.data_ptr(), adj.data_ptr(), entry, 0, pq_M=CM, pq_K=pq["K"], pq_codebooks=pq["codebooks"],
                                 pq_centroid=pq["centroid"], pq_codes_ptr=pq["codes"].data_ptr(), borrow=True, extra_flags=b.DESC_FUSED_ADC)
 ix = b.GpuIndex(desc=desc, keepalive=keep, flags=b.DESC_BORROW)
 for key, val in os.environ.items():   # JV_OPT_<name>=<int> -> per-index option
