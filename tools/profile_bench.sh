@@ -21,7 +21,8 @@ for C in FETCH_SIZE WRITE_SIZE; do
   c=$(find $d -name "*counter_collection.csv" | head -1)
   [ -n "$c" ] && cp $c $OUT/pmc_$C.csv
 done
-# SQ instruction / wait counters of the main kernels (is the kernel vector-issue bound?), one pass per group
+# SQ instruction / wait counters of the main kernels (is the kernel vector-issue bound?), one pass per group (SKIP_SQ=1: not this time)
+[ "${SKIP_SQ:-0}" = "1" ] && { ls -la $OUT; exit 0; }
 i=0
 for SET in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS"; do
