@@ -2702,7 +2702,8 @@ static bool xb_trace() {
         }                                                                                                    \
     } while (0)
 #define XB_ROUND_QUERIES 1024   /* queries per round (8 panels of 128): the candidates are read once per round */
-#define XB_SURV_CAP 4096        /* survivor slots per query; a query that overflows scans the whole list */
+#define XB_SURV_CAP 16384       /* survivor slots per query; a query that overflows scans the whole list (one workgroup: the backstop, not a path —
+                                   at 5M candidates a 4 096-slot list overflowed for 2 of 256 queries and their scans took 320 ms, round 5) */
 
 extern "C++" {
 template <typename T>
@@ -2805,7 +2806,7 @@ static int xb_run(jv_index* ix, const float* d_queries, int nq, int topK, const 
         pre = x.mirror_state == 1;
     }
     if (pre) {
-        S = std::min(C, std::max(4096, std::min(32768, C / 8)));
+        S = std::min(C, std::max(4096, std::min(65536, C / 8)));   // (about k * C / S candidates clear the bar of a k-of-S sample)
         if ((int64_t)topK * 4 > S) pre = false;
     }
     const int kp = x.kp;
