@@ -1090,6 +1090,7 @@ struct JvQueryServer {
     std::mutex mu;                  // launch / stop
     std::atomic<int> inflight{0};
     std::atomic<int> lat_us{3000};  // running estimate of one query's latency (how long a caller sleeps before it polls)
+    std::atomic<int64_t> last_call_ms{0};  // when a one-query call last took a slot (servers_free_lds: "may be restarted any moment")
 };
 namespace {
 typedef JvQueryServer Server;
@@ -1159,10 +1160,20 @@ void free_with_servers_paused(void* p, bool host) {
 
 // g_servers_mu held: LDS bytes per CU the server grids of this device occupy.  alive_only = false counts every EXISTING server:
 // a grid that is not running now may be started by the next one-query call — before a kernel enqueued now gets its CUs
+static int64_t now_ms() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (int64_t)ts.tv_sec * 1000 + ts.tv_nsec / 1000000;
+}
+// alive_only = false: also the grids that MAY start before a kernel enqueued now gets its CUs — servers that answered a call
+// within the last second (a server nobody has called for longer is not about to be restarted: counting every EXISTING server,
+// as round 4 did, switched the retry rungs off for the rest of the process after the first one-query call — ADVICE r4)
 static int servers_held_lds_locked(int device, bool alive_only = true) {
     int held = 0;
+    const int64_t now = alive_only ? 0 : now_ms();
     for (Server* sv : g_servers)
-        if (sv->ix->device == device && sv->h_words && (!alive_only || __atomic_load_n(&sv->h_words[JV_SH_ALIVE], __ATOMIC_ACQUIRE) != 0))
+        if (sv->ix->device == device && sv->h_words &&
+            (__atomic_load_n(&sv->h_words[JV_SH_ALIVE], __ATOMIC_ACQUIRE) != 0 || (!alive_only && now - sv->last_call_ms.load(std::memory_order_relaxed) < 1000)))
             held += (sv->blocks / std::max(1, sv->ix->cu_count)) * sv->lds;
     return held;
 }
@@ -1420,6 +1431,7 @@ int serve_query(jv_index* ix, const float* query, int32_t topK, int32_t rerankK,
     }
     // the ticket protocol's caller side: csrc/jv_serve_host.h (shared with the sanitizer test, tests/native/serve_sim.cpp)
     int si = 0;
+    sv->last_call_ms.store(now_ms(), std::memory_order_relaxed);
     const uint32_t seq = jvsh_take_slot(sv, &si);
     unsigned char* sp = sv->ring + (size_t)si * (size_t)sv->slot_bytes;
     JvServeSlot* slot = jvsh_slot(sv, si);
@@ -1890,7 +1902,9 @@ static int search_batch_device_impl(jv_index* index, const float* d_queries, int
         }
     }
     c->last_clock = ++index->async_clock;
-    if (c->last_stream && c->last_stream != s) HIPCHK(hipStreamWaitEvent(s, c->last_use, 0));
+    // (always: a destroyed stream's handle value can come back as a NEW stream, which is not ordered behind the old one's use of
+    //  this context — ADVICE r4; waiting for an event that has completed costs nothing)
+    if (c->last_stream) HIPCHK(hipStreamWaitEvent(s, c->last_use, 0));
     if (!hip_stream) {
         // No caller stream: the library's own (non-blocking) stream.  A caller that produced the queries on the legacy default
         // stream (handle 0 — what a CUDA-style runtime hands out as "the current stream") expects to be ordered behind that work:
