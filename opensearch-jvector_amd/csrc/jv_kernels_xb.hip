@@ -41,7 +41,6 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(4))) int i32x4_t;
 
 #define XB_TM 128          // candidates per tile
 #define XB_TN 128          // queries per tile (panel)
@@ -381,7 +380,7 @@ extern "C" hipError_t jvk_xb_tile(const JvXbTileArgs* a, int mode, hipStream_t s
 // rows = two groups at a time, so the groups of a pair sit on opposite halves of the 256-B bank row: bases 0 / 1152 / 2176 / 3328
 // (1 024 B each, no overlap).  3 stages x 12 chunks x 4 352 B + 7 168 B of per-query / per-stage words = 163 840 B: the whole LDS.
 #define XQ_KCH 4352
-#define XQ_PF 1       // fragment reads in flight ahead of the multiply (2 measured the same and costs four registers the filter mode does not have)
+#define XQ_PF 2       // fragment reads in flight ahead of the multiply
 __device__ __forceinline__ int xq_group_off(int g) { return g * 1024 + (g == 0 ? 0 : (g == 3 ? 256 : 128)); }
 __device__ __forceinline__ void xb_glds4(const void* g, void* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 4, 0, 0);
@@ -498,6 +497,11 @@ __global__ __launch_bounds__(512) void jvx_qs_kernel(const JvXbTileArgs a) {
             xb_glds4(a.vnorm2 + ord, s_cn2 + nslot * 64);
         }
     };
+    // fragment read offset of candidate row r31 inside a k chunk
+    const int foff = xq_group_off(r31 >> 3) + (r31 & 7) * 128, fx = r31 & 7;
+    int sw[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) sw[j] = foff + (((2 * j + h) ^ fx) << 4);
 
     // ---- prologue: ordinals of the first three stages, rows of the first two ----
     const int t0 = blockIdx.x;
@@ -539,18 +543,6 @@ __global__ __launch_bounds__(512) void jvx_qs_kernel(const JvXbTileArgs a) {
         XQ_STAMP(1)
         if (active) {
             const unsigned char* base = smem + buf * STAGE;
-            // fragment read offsets of candidate row (lane & 31) inside a k chunk, formed HERE from an opaque copy of the lane id: as
-            // loop invariants they live across the epilogue and the copy requests, where the register file peaks — one of them was
-            // spilled, and its reload (a vmcnt(0)) sat in front of every stage's multiply
-            int sw[4];
-            {
-                int lq = lane;
-                asm volatile("" : "+v"(lq));
-                const int hq = lq >> 5, rq = lq & 31;
-                const int foff = xq_group_off(rq >> 3) + (rq & 7) * 128, fx = rq & 7;
-#pragma unroll
-                for (int j = 0; j < 4; j++) sw[j] = foff + (((2 * j + hq) ^ fx) << 4);
-            }
             f32x16 acc;
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[e] = 0.0f;
@@ -564,10 +556,7 @@ __global__ __launch_bounds__(512) void jvx_qs_kernel(const JvXbTileArgs a) {
             for (int ks = 0; ks < NK16; ks++) {
                 if (ks + XQ_PF < NK16) fc[(ks + XQ_PF) % (XQ_PF + 1)] = *(const bf16x8*)(base + ((ks + XQ_PF) >> 2) * XQ_KCH + sw[(ks + XQ_PF) & 3]);
                 __builtin_amdgcn_sched_barrier(0);
-                // MODE 1: D[candidate][query] — a lane owns ONE query and 16 candidates, so the query's test constants are two
-                // registers for the whole launch; the sample modes keep D[query][candidate] (their stores are coalesced over candidates)
-                if (MODE == 1) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fc[ks % (XQ_PF + 1)], qf[ks], acc, 0, 0, 0);
-                else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[ks], fc[ks % (XQ_PF + 1)], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[ks], fc[ks % (XQ_PF + 1)], acc, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
             }
@@ -580,43 +569,30 @@ __global__ __launch_bounds__(512) void jvx_qs_kernel(const JvXbTileArgs a) {
             int lane_o = lane;
             asm volatile("" : "+v"(lane_o));
             const int h = lane_o >> 5, r31 = lane_o & 31;
+            const long long ci = (long long)t * 32 + r31;
+            const bool cin = ci < a.rows;
+            const float cn2 = s_cn2[nslot * 64 + r31];
+            const bool cval = cin && s_val[nslot * 64 + r31] != 0;   // (an invalid list entry: row 0 was staged in its place)
             if (MODE == 1) {
-                // lane = query w * 32 + r31 (its P and R: two registers); accumulator element reg = candidate (reg & 3) + 8 (reg >> 2) + 4 h of
-                // the stage.  The 16 candidates' norms come as four 16-B LDS reads; invalid list entries carry a NaN norm (-> "keep"),
-                // masked below.
-                const float2 qc = *(const float2*)(s_qc + w * 32 + r31);   // P, R
-                const float s_ = 1.2e-5f * 1.000001f + 4e-7f * 2.01f;
-                const int row0 = t * 32 + 4 * h;
-                uint32_t keep = 0u, okm = 0u;
-                const float* cnp = s_cn2 + nslot * 64 + 4 * h;
-                const int* vlp = s_val + nslot * 64 + 4 * h;
+                const float cn = sqrtf(cn2);
+                const float Qc = a.sim == 0 ? 0.5f * cn2 * (1.0f - (1.2e-5f * 1.000001f + 4e-7f * 2.01f)) * 0.999999f : 0.0f;
+                uint32_t keep = 0u;
 #pragma unroll
-                for (int g4 = 0; g4 < 4; g4++) {
-                    const f32x4 c2 = *(const f32x4*)(cnp + 8 * g4);
-                    const i32x4_t vv = *(const i32x4_t*)(vlp + 8 * g4);
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const float cnj = sqrtf(c2[j]);
-                        const float Qc = a.sim == 0 ? 0.5f * c2[j] * (1.0f - s_) * 0.999999f : 0.0f;
-                        const float bar = fmaf(-qc.y, cnj, qc.x + Qc);
-                        keep |= !(acc[4 * g4 + j] < bar) ? (1u << (4 * g4 + j)) : 0u;   // (NaN-proof: "certainly worse" must be TRUE to drop a candidate)
-                        okm |= (vv[j] != 0 && row0 + 8 * g4 + j < a.rows) ? (1u << (4 * g4 + j)) : 0u;
-                    }
+                for (int reg = 0; reg < 16; reg++) {
+                    const int row = w * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                    const f32x4 qc = s_qc[row];
+                    const float bar = fmaf(-qc[1], cn, qc[0] + Qc);
+                    keep |= !(acc[reg] < bar) ? (1u << reg) : 0u;   // (NaN-proof: "certainly worse" must be TRUE to drop a candidate)
                 }
-                keep &= okm;
-                const int q = a.qbase + w * 32 + r31;
-                if (q >= a.B) keep = 0u;
+                keep = cval ? keep : 0u;
                 while (keep) {   // rare: a few survivors per query per 10^5 candidates
                     const int reg = __ffs((int)keep) - 1;
                     keep &= keep - 1u;
+                    const int q = a.qbase + w * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
                     const int pos = atomicAdd(a.surv_cnt + q, 1);
-                    if (pos < a.surv_cap) a.surv[(size_t)q * a.surv_cap + pos] = (int32_t)list_pos(t, (reg & 3) + 8 * (reg >> 2) + 4 * h);
+                    if (pos < a.surv_cap) a.surv[(size_t)q * a.surv_cap + pos] = (int32_t)list_pos(t, r31);
                 }
             } else {
-                const long long ci = (long long)t * 32 + r31;
-                const bool cin = ci < a.rows;
-                const float cn2 = s_cn2[nslot * 64 + r31];
-                const bool cval = cin && s_val[nslot * 64 + r31] != 0;   // (an invalid list entry: row 0 was staged in its place)
                 float mc = 1.0f, bc = 0.0f, kec = 1.0f, sc = 0.0f, c0 = 2e-5f;
                 if (a.sim == 0) bc = -cn2, kec = sqrtf(cn2), sc = 1.2e-5f * cn2, c0 = 1e-6f;
                 else if (a.sim == 1) kec = sqrtf(cn2), c0 = 1e-6f;
