@@ -262,6 +262,14 @@ int jv_score_ordinals_batch_device(jv_index* index, const float* d_queries, int3
                                    int32_t* d_out_nodes, int32_t* d_out_docs, float* d_out_scores, int32_t* d_out_count,
                                    int64_t* out_info, void* hip_stream);
 
+/* The same for ONE query — what Lucene's exactSearch is per leaf and query, issued the way the reference issues it: one call per
+ * searcher thread.  Calls in flight at the same time on one handle that carry the SAME doc filter (same accept_key or content hash,
+ * same length, bits compared) and the same topK are combined inside the library into one jv_score_ordinals_batch call (group
+ * commit, as jv_search does); per-call semantics are unchanged and a lone caller pays no delay.  Counters "exact_calls" /
+ * "exact_batches" (jv_index_get_counter) show the combining.  An explicit ordinal list (accept_doc_words == NULL) is answered alone. */
+int jv_exact_search(jv_index* index, const float* query, const jv_exact_batch_params* params, int32_t* out_nodes,
+                    int32_t* out_docs, float* out_scores, int32_t* out_count);
+
 /* Merge per-shard top-k lists (the step Lucene's TopDocs.merge performs over leaves, and the
  * exchange step of the doc-range sharded multi-GPU layout): `lists` rows of `k` (doc, score)
  * pairs each (doc < 0 = empty slot) -> best k by (score desc, doc asc).  DEVICE pointers,

@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "jv_score_ordinals", "jv_merge_topk_device", "jv_index_get_info", "jv_set_option", "jv_last_error",
     "jv_abi_version", "jv_search_ex", "jv_search_batch_ex", "jv_index_set_option", "jv_index_get_counter", "jv_shard_group_create",
     "jv_shard_group_destroy", "jv_search_sharded_batch", "jv_search_sharded_batch_ex", "jv_shard_group_set_option",
-    "jv_score_ordinals_batch", "jv_score_ordinals_batch_device",
+    "jv_score_ordinals_batch", "jv_score_ordinals_batch_device", "jv_exact_search",
 ]
 XB_NO_PREFILTER, XB_TOPK_MAX, XB_INFO_WORDS = 0x1, 1024, 4
 QFLAG_RETRIED_BIG, QFLAG_EARLY_TERMINATED = 0x1, 0x2
@@ -244,6 +244,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.jv_score_ordinals_batch.restype = C.c_int
     lib.jv_score_ordinals_batch_device.argtypes = [vp, vp, i32, C.POINTER(JvExactBatchParams), vp, vp, vp, vp, vp, vp]
     lib.jv_score_ordinals_batch_device.restype = C.c_int
+    lib.jv_exact_search.argtypes = [vp, vp, C.POINTER(JvExactBatchParams), vp, vp, vp, vp]
+    lib.jv_exact_search.restype = C.c_int
     lib.jv_merge_topk_device.argtypes = [i32, vp, vp, i32, i32, i32, vp, vp, vp]
     lib.jv_merge_topk_device.restype = C.c_int
     lib.jv_index_get_info.argtypes = [vp, C.POINTER(JvIndexInfo)]
@@ -458,6 +460,28 @@ class GpuIndex:
         _check(self.lib, self.lib.jv_score_ordinals_batch(self.handle, q.ctypes.data, nq, C.byref(p), nodes.ctypes.data, docs.ctypes.data,
                                                           scores.ctypes.data, count.ctypes.data, info.ctypes.data))
         return nodes, docs, scores, count, info
+
+    def exact_search(self, query: np.ndarray, topK: int, accept: np.ndarray, accept_num_docs: int, accept_key: int = 0):
+        """jv_exact_search: ONE query under a doc filter (Lucene's exactSearch per leaf and query); concurrent calls with the same
+        filter are combined into batch calls inside the library.  Returns (nodes [topK], docs, scores, count)."""
+        q = np.ascontiguousarray(query, dtype=np.float32).reshape(self.d)
+        nodes = np.full(topK, -1, dtype=np.int32)
+        docs = np.full(topK, -1, dtype=np.int32)
+        scores = np.zeros(topK, dtype=np.float32)
+        count = np.zeros(1, dtype=np.int32)
+        acc = np.ascontiguousarray(accept, dtype=np.uint64)
+        p = JvExactBatchParams()
+        p.struct_size = C.sizeof(JvExactBatchParams)
+        p.topK = topK
+        p.accept_doc_words = acc.ctypes.data
+        p.accept_num_docs = accept_num_docs
+        p.ordinals = None
+        p.count = 0
+        p.flags = 0
+        p.accept_key = accept_key
+        _check(self.lib, self.lib.jv_exact_search(self.handle, q.ctypes.data, C.byref(p), nodes.ctypes.data, docs.ctypes.data,
+                                                  scores.ctypes.data, count.ctypes.data))
+        return nodes, docs, scores, int(count[0])
 
     def score_ordinals_batch_device(self, d_queries: int, nq: int, topK: int, d_nodes: int, d_docs: int, d_scores: int, d_count: int,
                                     d_accept: int = 0, accept_num_docs: int = 0, d_ordinals: int = 0, count: int = 0, flags: int = 0,

@@ -317,6 +317,12 @@ struct XbState {
     int64_t* h_info = nullptr;      // pinned: [0..1] kernel counters, [2] list length
     uint64_t* d_accept = nullptr; size_t accept_cap = 0;  // filter words when the cache has no slot
     int64_t bytes = 0;
+    // one-query calls (jv_exact_search): group commit — while one batch runs, later arrivals queue; the next leader takes every
+    // queued call with ITS filter and topK as one batch
+    std::mutex cmu;
+    std::deque<struct XbPending*> cqueue;
+    bool cleader = false;
+    std::atomic<int64_t> exact_calls{0}, exact_batches{0};
 };
 
 struct JvQueryServer;
@@ -1846,6 +1852,8 @@ int jv_index_get_counter(const jv_index* index, const char* name, int64_t* out) 
             *out = index->launches[i].load();
             return JV_OK;
         }
+    if (strcmp(name, "exact_calls") == 0) { *out = index->xb.exact_calls.load(); return JV_OK; }
+    if (strcmp(name, "exact_batches") == 0) { *out = index->xb.exact_batches.load(); return JV_OK; }
     return fail(JV_EINVAL, "unknown counter '%s'", name);
 }
 
@@ -3072,6 +3080,117 @@ int jv_score_ordinals_batch_device(jv_index* index, const float* d_queries, int3
     HIPCHK(hipStreamWaitEvent(caller, ev, 0));
     if (!hip_stream) HIPCHK(hipStreamSynchronize(x.stream));
     return JV_OK;
+}
+
+// One caller's jv_exact_search waiting to be served (lives on the caller's stack)
+struct XbPending {
+    const float* query;
+    int32_t topK;
+    const uint64_t* words;
+    int64_t ndocs;
+    uint64_t key;
+    int32_t* out_nodes;
+    int32_t* out_docs;
+    float* out_scores;
+    int32_t* out_count;
+    int rc = 0;
+    char err[256];
+    bool done = false, promoted = false;
+    std::condition_variable cv;
+};
+
+// ONE query under a doc filter — what Lucene's exactSearch is per leaf and query (AbstractKnnVectorQuery.exactSearch over
+// JVectorVectorScorer.score, J/JVectorVectorScorer.java:36-53) and how the reference issues it: one call per searcher thread
+// (T/index/engine/JVectorConcurrentQueryTests.java:78-138).  Calls in flight at the same time that carry the SAME filter (same key or
+// content hash, same length, bits compared) and the same topK are answered as ONE jv_score_ordinals_batch call: the first arrival
+// leads; while its batch runs, later arrivals queue, and the oldest of them leads the next batch.  A lone caller pays no delay.
+int jv_exact_search(jv_index* index, const float* query, const jv_exact_batch_params* p, int32_t* out_nodes, int32_t* out_docs,
+                    float* out_scores, int32_t* out_count) {
+    int rc = xb_check(index, query, 1, p);
+    if (rc != JV_OK) return rc;
+    if (!p->accept_doc_words) return jv_score_ordinals_batch(index, query, 1, p, out_nodes, out_docs, out_scores, out_count, nullptr);  // (lists are not combined)
+    XbState& x = index->xb;
+    x.exact_calls++;
+    XbPending me;
+    me.query = query;
+    me.topK = p->topK;
+    me.words = p->accept_doc_words;
+    me.ndocs = p->accept_num_docs;
+    const size_t nwords = (size_t)((p->accept_num_docs + 63) / 64);
+    me.key = p->accept_key ? p->accept_key : hash_words(p->accept_doc_words, nwords);
+    me.out_nodes = out_nodes;
+    me.out_docs = out_docs;
+    me.out_scores = out_scores;
+    me.out_count = out_count;
+    me.err[0] = 0;
+    std::unique_lock<std::mutex> lk(x.cmu);
+    if (x.cleader) {
+        x.cqueue.push_back(&me);
+        me.cv.wait(lk, [&] { return me.done || me.promoted; });
+        if (me.done) {
+            if (me.rc != JV_OK) g_last_error = me.err;
+            return me.rc;
+        }
+    } else {
+        x.cleader = true;
+    }
+    // ---- leader: every queued call with this filter and topK, this one included ----
+    std::vector<XbPending*> mine{&me};
+    for (auto it = x.cqueue.begin(); it != x.cqueue.end() && mine.size() < XB_ROUND_QUERIES;) {
+        XbPending* o = *it;
+        if (o->topK == me.topK && o->key == me.key && o->ndocs == me.ndocs &&
+            (o->words == me.words || memcmp(o->words, me.words, nwords * 8) == 0)) {   // (the key only FINDS candidates: the bits decide)
+            mine.push_back(o);
+            it = x.cqueue.erase(it);
+        } else {
+            ++it;
+        }
+    }
+    lk.unlock();
+    const int nq = (int)mine.size(), d = index->dev.d, k = me.topK;
+    int brc = JV_OK;
+    std::string berr;
+    if (nq == 1) {
+        brc = jv_score_ordinals_batch(index, query, 1, p, out_nodes, out_docs, out_scores, out_count, nullptr);
+        if (brc != JV_OK) berr = g_last_error;
+    } else {
+        std::vector<float> q((size_t)nq * d);
+        std::vector<int32_t> nodes((size_t)nq * k), docs((size_t)nq * k), count((size_t)nq);
+        std::vector<float> scores((size_t)nq * k);
+        for (int i = 0; i < nq; i++) memcpy(q.data() + (size_t)i * d, mine[(size_t)i]->query, (size_t)d * sizeof(float));
+        jv_exact_batch_params bp = *p;
+        bp.accept_key = me.key;
+        brc = jv_score_ordinals_batch(index, q.data(), nq, &bp, nodes.data(), docs.data(), scores.data(), count.data(), nullptr);
+        if (brc != JV_OK) berr = g_last_error;
+        else
+            for (int i = 0; i < nq; i++) {
+                XbPending* o = mine[(size_t)i];
+                if (o->out_nodes) memcpy(o->out_nodes, nodes.data() + (size_t)i * k, (size_t)k * 4);
+                if (o->out_docs) memcpy(o->out_docs, docs.data() + (size_t)i * k, (size_t)k * 4);
+                if (o->out_scores) memcpy(o->out_scores, scores.data() + (size_t)i * k, (size_t)k * 4);
+                if (o->out_count) *o->out_count = count[(size_t)i];
+            }
+    }
+    x.exact_batches++;
+    lk.lock();
+    for (size_t i = 1; i < mine.size(); i++) {
+        XbPending* o = mine[i];
+        o->rc = brc;
+        snprintf(o->err, sizeof(o->err), "%s", berr.c_str());
+        o->done = true;
+        o->cv.notify_one();
+    }
+    if (!x.cqueue.empty()) {   // hand the lead to the oldest waiting call
+        XbPending* nx = x.cqueue.front();
+        x.cqueue.pop_front();
+        nx->promoted = true;
+        nx->cv.notify_one();
+    } else {
+        x.cleader = false;
+    }
+    lk.unlock();
+    if (brc != JV_OK) g_last_error = berr;
+    return brc;
 }
 
 // Diagnostics (tests/test_gpu_xb.py; not part of include/jvgpu.h): the interval [lower, upper] the matrix-core pass

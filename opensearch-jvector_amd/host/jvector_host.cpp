@@ -537,6 +537,25 @@ TopDocs JVectorKnnFloatVectorQuery::approximateSearch(JVectorReader& reader, con
 
 TopDocs JVectorKnnFloatVectorQuery::exactSearch(JVectorReader& reader, const FixedBitSet& accept) const {
     const JVectorReader::FieldEntry* fe = reader.fieldEntry(field_);
+    if (k_ >= 1 && k_ <= JV_XB_TOPK_MAX && accept.length() > 0) {
+        // Round 5: one engine call — the accepted docs that have a vector are found, scored (JVectorVectorScorer.score's exact
+        // scores) and cut to the best k by (score desc, doc asc) on the device; searcher threads that fall back at the same time
+        // under the same filter are answered as one batch inside the library (jv_exact_search's group commit)
+        std::vector<int32_t> docs((size_t)k_);
+        std::vector<float> scores((size_t)k_);
+        int32_t count = 0;
+        jv_exact_batch_params p;
+        memset(&p, 0, sizeof(p));
+        p.struct_size = sizeof(p);
+        p.topK = k_;
+        p.accept_doc_words = accept.getBits();
+        p.accept_num_docs = accept.length();
+        throwForStatus(jv_exact_search(fe->index, target_.data(), &p, nullptr, docs.data(), scores.data(), &count));
+        TopDocs t;
+        for (int i = 0; i < count; i++) t.scoreDocs.push_back({docs[(size_t)i], scores[(size_t)i]});
+        t.totalHits = (int64_t)t.scoreDocs.size();
+        return t;
+    }
     std::vector<int> docs;
     for (int doc = 0; doc < accept.length(); doc++)
         if (accept.get(doc) && doc < fe->graphNodeIdToDocMap.maxDoc() &&

@@ -316,3 +316,44 @@ def test_batched_leaf_search_equals_the_single_query_leaf_search_and_the_oracle(
                     assert np.array_equal(xd[i], docs[i]) and np.array_equal(xs[i].view(np.uint32), scores[i].view(np.uint32))
         reader.close()
     assert mixed >= 1, "no selectivity exercised the mixed case (some queries exact, some approximate)"
+
+
+def test_concurrent_one_query_exact_searches_are_combined(pkg, pyoracle):
+    """jv_exact_search: Lucene's exactSearch for ONE query, the way the reference issues it — one call per searcher thread
+    (T/index/engine/JVectorConcurrentQueryTests.java:78-138).  48 threads under two different filters and two topK values: every
+    answer equals the oracle's scan, and the library answered them in fewer engine calls than there were callers (group commit)."""
+    import threading
+    b = pkg.binding
+    rng = np.random.default_rng(23)
+    n, d = 60000, 96
+    base = pkg.datagen.splitmix_uniform(51, n, d)
+    ident = np.arange(n, dtype=np.int32)
+    ix = _index(b, base, 0)
+    gpu = b.GpuIndex(ix)
+    orc = pyoracle.Oracle(b, ix)
+    queries = pkg.datagen.splitmix_uniform(52, 48 * 6, d)
+    filters = []
+    for sel in (0.2, 0.05):
+        docs = np.nonzero(rng.random(n) < sel)[0].astype(np.int32)
+        filters.append((docs, b.accept_words(docs, n)))
+    bad = []
+
+    def caller(t):
+        for it in range(6):
+            qi = t * 6 + it
+            docs, words = filters[(t + it) % 2]
+            k = 10 if t % 3 else 25
+            nodes, dcs, sc, cnt = gpu.exact_search(queries[qi], k, words, n)
+            wn, wd, ws = _want(orc, queries[qi], docs, ident, k)
+            if cnt != len(wn) or not np.array_equal(dcs[:cnt], wd) or not np.array_equal(sc[:cnt].view(np.uint32), ws.view(np.uint32)):
+                bad.append(qi)
+
+    ts = [threading.Thread(target=caller, args=(t,)) for t in range(48)]
+    [t.start() for t in ts]
+    [t.join(timeout=120) for t in ts]
+    assert not any(t.is_alive() for t in ts), "a caller is stuck"
+    assert not bad, bad[:5]
+    calls, batches = gpu.counter("exact_calls"), gpu.counter("exact_batches")
+    assert calls == 48 * 6 and batches < calls, (calls, batches)
+    print(f"{calls} one-query exact searches answered in {batches} engine calls")
+    gpu.close()
