@@ -239,6 +239,7 @@ int jv_score_ordinals(jv_index* index, const float* query, const int32_t* ordina
  * ran), [2] rows re-scored in fp32 summed over the queries, [3] queries whose survivor list overflowed (they scanned the
  * whole list).  topK <= JV_XB_TOPK_MAX (JV_EUNSUPPORTED beyond: score the ordinals with jv_score_ordinals). */
 #define JV_XB_NO_PREFILTER 0x1u
+#define JV_XB_FORCE_PREFILTER 0x2u /* diagnostics: run the matrix-core pass for lists shorter than 2 048 entries as well (tests, fuzz) */
 #define JV_XB_TOPK_MAX 1024
 #define JV_XB_INFO_WORDS 4
 typedef struct jv_exact_batch_params {

@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "jv_shard_group_destroy", "jv_search_sharded_batch", "jv_search_sharded_batch_ex", "jv_shard_group_set_option",
     "jv_score_ordinals_batch", "jv_score_ordinals_batch_device", "jv_exact_search",
 ]
-XB_NO_PREFILTER, XB_TOPK_MAX, XB_INFO_WORDS = 0x1, 1024, 4
+XB_NO_PREFILTER, XB_FORCE_PREFILTER, XB_TOPK_MAX, XB_INFO_WORDS = 0x1, 0x2, 1024, 4
 QFLAG_RETRIED_BIG, QFLAG_EARLY_TERMINATED = 0x1, 0x2
 
 

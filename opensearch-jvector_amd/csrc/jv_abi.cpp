@@ -2821,7 +2821,7 @@ static int xb_run(jv_index* ix, const float* d_queries, int nq, int topK, const 
     }
     HIPCHK(hipMemsetAsync(x.d_info, 0, 4 * sizeof(int64_t), st));
     int S = 0;
-    bool pre = !(flags & JV_XB_NO_PREFILTER) && C >= 2048;
+    bool pre = !(flags & JV_XB_NO_PREFILTER) && (C >= 2048 || ((flags & JV_XB_FORCE_PREFILTER) && C >= 1));
     if (pre) {
         int rc = xb_ensure_mirror(ix);
         if (rc != JV_OK) return rc;
@@ -2829,7 +2829,7 @@ static int xb_run(jv_index* ix, const float* d_queries, int nq, int topK, const 
     }
     if (pre) {
         S = std::min(C, std::max(4096, std::min(65536, C / 8)));   // (about k * C / S candidates clear the bar of a k-of-S sample)
-        if ((int64_t)topK * 4 > S) pre = false;
+        if ((int64_t)topK * 4 > S && !(flags & JV_XB_FORCE_PREFILTER)) pre = false;
     }
     const int kp = x.kp;
     // kappa: (2u + u^2) with u = 2^-8 (bf16 round to nearest even, both operands) + fp32 accumulation of kp products in

@@ -82,6 +82,40 @@ def run(budget, seed0):
                     i = bad[0]
                     print(" got ", got.nodes[i][:10], got.stats[i], "\n want", want.nodes[i][:10], want.stats[i])
                 return False
+        # the batched exact scorer on the same index (jv_score_ordinals_batch: bf16 matrix-core pre-filter forced on for these
+        # short lists half of the time, canonical re-score) against the oracle's scan + (score desc, doc asc)
+        docs_of = ord2doc if ord2doc is not None else np.arange(n, dtype=np.int32)
+        for _ in range(2):
+            nd = ix.max_doc if ord2doc is not None else n
+            kx = int(rng.choice([1, 5, 10, 50, 200]))
+            nqx = int(rng.integers(1, nq + 1))
+            flags = int(rng.choice([0, b.XB_FORCE_PREFILTER, b.XB_FORCE_PREFILTER, b.XB_NO_PREFILTER]))
+            mode = int(rng.integers(0, 3))
+            if mode == 0:
+                frac = float(rng.choice([0.95, 0.4, 0.1, 0.01]))
+                accd = np.nonzero(rng.random(nd) < frac)[0]
+                cand = np.nonzero(np.isin(docs_of, accd) & (docs_of >= 0))[0].astype(np.int32)
+                got = gpu.score_ordinals_batch(q[:nqx], kx, accept=b.accept_words(accd, nd), accept_num_docs=nd, flags=flags)
+            elif mode == 1:
+                lst = np.concatenate([rng.integers(0, n, size=int(rng.integers(1, 2 * n))), [-1, n, n + 7]]).astype(np.int32)
+                lst = np.unique(lst)   # (duplicates in a caller's list are returned as given: not what Lucene produces)
+                cand = lst[(lst >= 0) & (lst < n)]
+                cand = cand[docs_of[cand] >= 0]
+                got = gpu.score_ordinals_batch(q[:nqx], kx, ordinals=lst, flags=flags)
+            else:
+                cand = np.nonzero(docs_of >= 0)[0].astype(np.int32)
+                got = gpu.score_ordinals_batch(q[:nqx], kx, flags=flags)
+            checks += 1
+            for i in range(nqx):
+                sc = orc.score_ordinals(q[i], cand)
+                dd = docs_of[cand]
+                order = np.lexsort((dd, -sc.astype(np.float64)))[:kx]
+                m = len(order)
+                if not (got[3][i] == m and np.array_equal(got[1][i, :m], dd[order]) and np.array_equal(got[0][i, :m], cand[order]) and
+                        np.array_equal(got[2][i, :m].view(np.uint32), sc[order].view(np.uint32))):
+                    print(f"MISMATCH (exact batch) seed={seed} n={n} d={d} sim={sim} ties={ties} k={kx} nq={nqx} mode={mode} flags={flags} query={i} info={got[4]}")
+                    print(" got ", got[1][i, :10], got[2][i, :5], "\n want", dd[order][:10], sc[order][:5])
+                    return False
         gpu.close()
         cases += 1
     print(f"fuzz ok: {cases} indexes, {checks} search configurations, {time.time() - t0:.0f}s")
