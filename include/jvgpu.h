@@ -285,7 +285,7 @@ typedef struct jv_index_info {
     int64_t hbm_bytes;          /* bytes resident in HBM for this index          */
     int32_t row_stride_floats;  /* padded vector row stride                       */
     int32_t fused_adc;          /* 1 if the fused layout is present               */
-    int64_t scratch_bytes;      /* HBM scratch currently held on behalf of this index: launch contexts (staging, spill
+    int64_t scratch_bytes;      /* HBM scratch currently held on behalf of this index: the batched exact scorer's bf16 mirror (once built), launch contexts (staging, spill
                                    tables, expansion logs), cached filters, and the device's SHARED HBM-scratch rung    */
     int64_t filter_cache_hits, filter_cache_misses;
 } jv_index_info;

@@ -1840,6 +1840,7 @@ int jv_index_get_info(const jv_index* index, jv_index_info* out) {
         out->filter_cache_hits = ix->filter_hits;
         out->filter_cache_misses = ix->filter_misses;
     }
+    scratch += ix->xb.bytes;  // (the batched exact scorer's bf16 mirror of the vectors and its per-call buffers)
     out->scratch_bytes = scratch;
     return JV_OK;
 }
