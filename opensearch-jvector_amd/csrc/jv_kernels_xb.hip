@@ -667,19 +667,20 @@ extern "C" hipError_t jvk_xb_qs(const JvXbTileArgs* a, int mode, int cus, hipStr
 // than k finite ones, get -inf: every candidate survives (correct, merely slow).
 // ---------------------------------------------------------------------------------------------
 #define XB_KTH_BUCKETS 2048
-__global__ __launch_bounds__(256) void jvx_kth_kernel(const float* __restrict__ sample, int ld, int S, int k, float* __restrict__ thr) {
+#define XB_KT 1024   // threads: a row of 25 000 - 65 000 floats is read three times
+__global__ __launch_bounds__(XB_KT) void jvx_kth_kernel(const float* __restrict__ sample, int ld, int S, int k, float* __restrict__ thr) {
     __shared__ int s_hist[XB_KTH_BUCKETS];
-    __shared__ float s_red[8];
-    __shared__ int s_cut;
+    __shared__ float s_red[2 * (XB_KT / 64)];
+    __shared__ int s_cut, s_bad;
     const int q = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
     const float* row = sample + (size_t)q * ld;
     const float inf = __builtin_inff();
     float lo = inf, hi = -inf;
     int bad = 0, fin = 0;
-    for (int i0 = t; i0 < S; i0 += 1024) {   // four independent loads per step (one at a time, a pass is ~100 exposed L2 round trips)
+    for (int i0 = t; i0 < S; i0 += 4 * XB_KT) {   // four independent loads per step (one at a time, a pass is ~100 exposed L2 round trips)
         float vv[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) vv[u] = i0 + 256 * u < S ? row[i0 + 256 * u] : -inf;
+        for (int u = 0; u < 4; u++) vv[u] = i0 + XB_KT * u < S ? row[i0 + XB_KT * u] : -inf;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const float v = vv[u];
@@ -698,24 +699,26 @@ __global__ __launch_bounds__(256) void jvx_kth_kernel(const float* __restrict__ 
     }
     bad = __ballot(bad != 0) != 0ull;
     fin = jv_wave_sum_int(fin);
-    if (lane == 0) s_red[w] = lo, s_red[4 + w] = hi;
-    for (int i = t; i < XB_KTH_BUCKETS; i += 256) s_hist[i] = 0;
-    if (t == 0) s_cut = 0;
+    if (lane == 0) s_red[w] = lo, s_red[XB_KT / 64 + w] = hi;
+    for (int i = t; i < XB_KTH_BUCKETS; i += XB_KT) s_hist[i] = 0;
+    if (t == 0) s_cut = 0, s_bad = 0;
     __syncthreads();
-    if (lane == 0) atomicAdd(&s_cut, bad ? (1 << 30) : fin);
-    lo = fminf(fminf(s_red[0], s_red[1]), fminf(s_red[2], s_red[3]));
-    hi = fmaxf(fmaxf(s_red[4], s_red[5]), fmaxf(s_red[6], s_red[7]));
+    if (lane == 0) atomicAdd(&s_cut, fin);
+    if (lane == 0 && bad) atomicOr(&s_bad, 1);
+    lo = s_red[0], hi = s_red[XB_KT / 64];
+#pragma unroll
+    for (int i = 1; i < XB_KT / 64; i++) lo = fminf(lo, s_red[i]), hi = fmaxf(hi, s_red[XB_KT / 64 + i]);
     __syncthreads();
     const int total = s_cut;
-    if (total >= (1 << 30) || total < k) {
+    if (s_bad != 0 || total < k) {
         if (t == 0) thr[q] = -inf;
         return;
     }
     const float scale = hi > lo ? (float)(XB_KTH_BUCKETS - 1) / (hi - lo) : 0.0f;
-    for (int i0 = t; i0 < S; i0 += 1024) {
+    for (int i0 = t; i0 < S; i0 += 4 * XB_KT) {
         float vv[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) vv[u] = i0 + 256 * u < S ? row[i0 + 256 * u] : -inf;
+        for (int u = 0; u < 4; u++) vv[u] = i0 + XB_KT * u < S ? row[i0 + XB_KT * u] : -inf;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const float v = vv[u];
@@ -750,10 +753,10 @@ __global__ __launch_bounds__(256) void jvx_kth_kernel(const float* __restrict__ 
     __syncthreads();
     const int cut = s_cut;
     float m = inf;
-    for (int i0 = t; i0 < S; i0 += 1024) {
+    for (int i0 = t; i0 < S; i0 += 4 * XB_KT) {
         float vv[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) vv[u] = i0 + 256 * u < S ? row[i0 + 256 * u] : -inf;
+        for (int u = 0; u < 4; u++) vv[u] = i0 + XB_KT * u < S ? row[i0 + XB_KT * u] : -inf;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const float v = vv[u];
@@ -769,11 +772,15 @@ __global__ __launch_bounds__(256) void jvx_kth_kernel(const float* __restrict__ 
     __syncthreads();
     if (lane == 0) s_red[w] = m;
     __syncthreads();
-    if (t == 0) thr[q] = fminf(fminf(s_red[0], s_red[1]), fminf(s_red[2], s_red[3]));
+    if (t == 0) {
+        float r = s_red[0];
+        for (int i = 1; i < XB_KT / 64; i++) r = fminf(r, s_red[i]);
+        thr[q] = r;
+    }
 }
 extern "C" hipError_t jvk_xb_kth(const float* sample, int ld, int S, int k, float* thr, int B, hipStream_t s) {
     if (B <= 0) return hipSuccess;
-    jvx_kth_kernel<<<B, 256, 0, s>>>(sample, ld, S, k, thr);
+    jvx_kth_kernel<<<B, XB_KT, 0, s>>>(sample, ld, S, k, thr);
     return hipGetLastError();
 }
 
@@ -783,10 +790,11 @@ extern "C" hipError_t jvk_xb_kth(const float* sample, int ld, int S, int k, floa
 // keys that beat the running k-th best collect in an LDS buffer that is bitonic-sorted and cut back to k when it fills.
 // ---------------------------------------------------------------------------------------------
 #define XB_KCAP 4096
+#define XB_RT 512   // threads of a re-score workgroup: 8 waves x 64 survivors per round (a 185-entry list is ONE round of two 16-row passes per wave, not four)
 __device__ __forceinline__ void xb_sort_desc(int64_t* keys, int32_t* pay, int n_pow2, int tid) {
     for (int size = 2; size <= n_pow2; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int i = tid; i < (n_pow2 >> 1); i += 256) {
+            for (int i = tid; i < (n_pow2 >> 1); i += XB_RT) {
                 const int lo = (i / stride) * (stride << 1) + (i % stride);
                 const int hi = lo + stride;
                 const bool desc = ((lo & size) == 0);
@@ -805,7 +813,7 @@ __device__ __forceinline__ void xb_sort_desc(int64_t* keys, int32_t* pay, int n_
 }
 
 template <int NCHT>
-__global__ __launch_bounds__(256) void jvx_rescore_kernel(const JvIndexDev ix, const JvXbRescoreArgs a) {
+__global__ __launch_bounds__(XB_RT) void jvx_rescore_kernel(const JvIndexDev ix, const JvXbRescoreArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int q = blockIdx.x;
@@ -816,13 +824,13 @@ __global__ __launch_bounds__(256) void jvx_rescore_kernel(const JvIndexDev ix, c
     int32_t* pay = (int32_t*)(smem + off);
     off += (size_t)XB_KCAP * 4;
     float* todo_score = (float*)(smem + off) + w * 64;
-    off += 4 * 64 * 4;
+    off += (XB_RT / 64) * 64 * 4;
     int32_t* todo = (int32_t*)(smem + off) + w * 64;
-    off += 4 * 64 * 4;
+    off += (XB_RT / 64) * 64 * 4;
     int* s_cnt = (int*)(smem + off);
 
     const float* query = a.queries + (size_t)q * ix.d;
-    for (int i = tid; i < ix.nch * 64; i += 256) q_lds[i] = i < ix.d ? query[i] : 0.0f;
+    for (int i = tid; i < ix.nch * 64; i += XB_RT) q_lds[i] = i < ix.d ? query[i] : 0.0f;
     if (tid == 0) *s_cnt = 0;
     __syncthreads();
     float qnorm2 = 0.0f;
@@ -837,7 +845,7 @@ __global__ __launch_bounds__(256) void jvx_rescore_kernel(const JvIndexDev ix, c
         atomicAdd((unsigned long long*)a.out_info + 0, (unsigned long long)total);
         if (all && a.surv_cnt && !a.force_all) atomicAdd((unsigned long long*)a.out_info + 1, 1ull);
     }
-    for (int base = 0; base < total; base += 256) {
+    for (int base = 0; base < total; base += XB_RT) {
         const int idx = base + tid;
         int ord = -1, doc = -1;
         if (idx < total) {
@@ -867,10 +875,10 @@ __global__ __launch_bounds__(256) void jvx_rescore_kernel(const JvIndexDev ix, c
         }
         __syncthreads();
         const int cnt = *s_cnt;
-        if (cnt + 256 > XB_KCAP) {  // (workgroup-uniform) sort, keep the best k, raise the bar
+        if (cnt + XB_RT > XB_KCAP) {  // (workgroup-uniform) sort, keep the best k, raise the bar
             int np = 1;
             while (np < cnt) np <<= 1;
-            for (int i = cnt + tid; i < np; i += 256) keys[i] = KEY_MIN, pay[i] = -1;
+            for (int i = cnt + tid; i < np; i += XB_RT) keys[i] = KEY_MIN, pay[i] = -1;
             __syncthreads();
             xb_sort_desc(keys, pay, np, tid);
             const int keep = cnt < k ? cnt : k;
@@ -884,11 +892,11 @@ __global__ __launch_bounds__(256) void jvx_rescore_kernel(const JvIndexDev ix, c
     const int cnt = *s_cnt;
     int np = 1;
     while (np < cnt) np <<= 1;
-    for (int i = cnt + tid; i < np; i += 256) keys[i] = KEY_MIN, pay[i] = -1;
+    for (int i = cnt + tid; i < np; i += XB_RT) keys[i] = KEY_MIN, pay[i] = -1;
     __syncthreads();
     if (cnt > 1) xb_sort_desc(keys, pay, np, tid);
     const int outn = cnt < k ? cnt : k;
-    for (int i = tid; i < k; i += 256) {
+    for (int i = tid; i < k; i += XB_RT) {
         const bool v = i < outn;
         const int64_t key = v ? keys[i] : 0;
         if (a.out_nodes) a.out_nodes[(size_t)q * k + i] = v ? pay[i] : -1;
@@ -898,7 +906,7 @@ __global__ __launch_bounds__(256) void jvx_rescore_kernel(const JvIndexDev ix, c
     if (tid == 0 && a.out_count) a.out_count[q] = outn;
 }
 
-extern "C" int jvk_xb_rescore_lds(const JvIndexDev* ix) { return ix->nch * 64 * 4 + XB_KCAP * 12 + 2 * 4 * 64 * 4 + 16; }
+extern "C" int jvk_xb_rescore_lds(const JvIndexDev* ix) { return ix->nch * 64 * 4 + XB_KCAP * 12 + 2 * (XB_RT / 64) * 64 * 4 + 16; }
 extern "C" hipError_t jvk_xb_rescore(const JvIndexDev* ix, const JvXbRescoreArgs* a, int nq, hipStream_t s) {
     if (nq <= 0) return hipSuccess;
     const int lds = jvk_xb_rescore_lds(ix);
@@ -912,9 +920,9 @@ extern "C" hipError_t jvk_xb_rescore(const JvIndexDev* ix, const JvXbRescoreArgs
         attr_done = true;
     }
     const bool fixed = ix->nvq_M == 0 && ix->vectors && ix->stride == ix->nch * 64;
-    if (fixed && ix->nch == 2) jvx_rescore_kernel<2><<<nq, 256, lds, s>>>(*ix, *a);
-    else if (fixed && ix->nch == 12) jvx_rescore_kernel<12><<<nq, 256, lds, s>>>(*ix, *a);
-    else if (fixed && ix->nch == 24) jvx_rescore_kernel<24><<<nq, 256, lds, s>>>(*ix, *a);
-    else jvx_rescore_kernel<0><<<nq, 256, lds, s>>>(*ix, *a);
+    if (fixed && ix->nch == 2) jvx_rescore_kernel<2><<<nq, XB_RT, lds, s>>>(*ix, *a);
+    else if (fixed && ix->nch == 12) jvx_rescore_kernel<12><<<nq, XB_RT, lds, s>>>(*ix, *a);
+    else if (fixed && ix->nch == 24) jvx_rescore_kernel<24><<<nq, XB_RT, lds, s>>>(*ix, *a);
+    else jvx_rescore_kernel<0><<<nq, XB_RT, lds, s>>>(*ix, *a);
     return hipGetLastError();
 }
