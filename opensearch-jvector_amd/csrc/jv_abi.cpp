@@ -72,6 +72,9 @@ int jvk_pqw_lds_rows(const JvIndexDev* ix, int variant);
 int jvk_pqw_occ5_ok(const JvIndexDev* ix, int cap);
 int jvk_pqw_blocks_per_cu(const JvIndexDev* ix, int cap, int lds_bytes, int variant);
 hipError_t jvk_launch_search_pqw(const JvIndexDev* ix, const JvSearchArgs* a, int lds_bytes, int blocks, int variant, hipStream_t s);
+int jvk_visited_blocks_per_cu(int slots);
+int jvk_visited_lds_bytes(int slots);
+hipError_t jvk_launch_visited(const JvVisArgs* a, int blocks, hipStream_t s);
 // the same kernel with a doc filter (jv_kernels_pqwf.hip): pools of up to 16 384 entries
 hipError_t jvk_pqwf_set_max_lds(int bytes);
 int jvk_pqwf_ok(const JvIndexDev* ix, int cap);
@@ -135,7 +138,7 @@ int fail(int code, const char* fmt, ...) {
 //   direct_completion                    combined one-query calls: rows land in pinned memory, every caller is woken by its own query's completion word
 //   lutr_min_queries                     launches with more queries keep the PQ look-up table in registers (-1 = 4 per CU)
 //   dbg_ptr                              diagnostic build only
-enum OptId { OPT_LDS_VISITED_SLOTS, OPT_LDS_CANDIDATES, OPT_FORCE_BIG, OPT_FORCE_GENERAL, OPT_NO_ESCALATION, OPT_DBG_PTR, OPT_NO_PQF, OPT_NO_PQP, OPT_NO_LUTR, OPT_LUTR_MIN_QUERIES, OPT_PQP_BLOCKS_PER_CU, OPT_NO_PQW, OPT_PQW_MIN_QUERIES, OPT_PQW_LAT_QUERIES, OPT_PQF_ONLY, OPT_SPILL_TABLES, OPT_SPILL_SLOTS, OPT_BIG_BLOCKS, OPT_BIG_CAND_CAP, OPT_BIG_BUDGET_MB, OPT_COMBINE, OPT_COMBINE_LEADERS, OPT_COMBINE_MAX_BATCH, OPT_MAX_CONTEXTS, OPT_FILTER_CACHE, OPT_DIRECT_COMPLETION, OPT_LAZY_BIG, OPT_SERVE, OPT_SERVE_WGS_PER_CU, OPT_SERVE_IDLE_MS, OPT_ASYNC_CONTEXTS, OPT_COUNT };
+enum OptId { OPT_LDS_VISITED_SLOTS, OPT_LDS_CANDIDATES, OPT_FORCE_BIG, OPT_FORCE_GENERAL, OPT_NO_ESCALATION, OPT_DBG_PTR, OPT_NO_PQF, OPT_NO_PQP, OPT_NO_LUTR, OPT_LUTR_MIN_QUERIES, OPT_PQP_BLOCKS_PER_CU, OPT_NO_PQW, OPT_PQW_MIN_QUERIES, OPT_PQW_LAT_QUERIES, OPT_PQF_ONLY, OPT_SPILL_TABLES, OPT_SPILL_SLOTS, OPT_BIG_BLOCKS, OPT_BIG_CAND_CAP, OPT_BIG_BUDGET_MB, OPT_COMBINE, OPT_COMBINE_LEADERS, OPT_COMBINE_MAX_BATCH, OPT_MAX_CONTEXTS, OPT_FILTER_CACHE, OPT_DIRECT_COMPLETION, OPT_LAZY_BIG, OPT_SERVE, OPT_SERVE_WGS_PER_CU, OPT_SERVE_IDLE_MS, OPT_ASYNC_CONTEXTS, OPT_VISITED_AFTER, OPT_VISITED_SLOTS, OPT_VISITED_ARENA_UNITS, OPT_COUNT };
 struct OptName { const char* name; int64_t def; };
 const OptName kOptNames[OPT_COUNT] = {
     {"lds_visited_slots", 0},
@@ -169,6 +172,9 @@ const OptName kOptNames[OPT_COUNT] = {
     {"serve_wgs_per_cu", 2},
     {"serve_idle_ms", 100},
     {"async_contexts", 4},
+    {"visited_after", 1},
+    {"visited_slots", 16384},      // hash slots of jv_visited_kernel's set (tests: a small set sends every log through several classes)
+    {"visited_arena_units", 0},    // > 0: the log arena's size in 16-byte units (tests: a small arena sends logs back to the in-kernel count)
 };
 struct Opts {
     std::atomic<int64_t> v[OPT_COUNT];
@@ -221,13 +227,19 @@ struct Ctx {
     hipEvent_t ev_null = nullptr;  // device-pointer API without a caller stream: what the legacy default stream had in flight at call time
     int32_t* h_mark = nullptr;   // pinned: stream marker written by jv_mark_kernel, polled by the host (see wait_mark)
     int32_t mark_seq = 0;
-    int32_t* work_counter = nullptr;  // 16 words: [0] big-path dequeue, [1] spill-table allocator, [2..7] rung counters, [8..15] filtered pool rungs
+    int32_t* work_counter = nullptr;  // 24 words: [0] big-path dequeue, [1] spill-table allocator, [2..7] rung counters, [8..15] filtered pool rungs, [16] log-arena cursor
     // pool of visited-set spill tables of the generic kernels (allocated on the first launch that can use it)
     uint32_t* spill = nullptr;
     int spill_tables = 0, spill_slots = 0;
     // register-pool kernel: per-resident-workgroup expansion logs
     int32_t* pqp_log = nullptr;
     size_t pqp_log_ints = 0;
+    // visited counts after the launch (jv_kernels_vis.hip): copies of the batch's expansion logs + per-query offset / length
+    int32_t* vis_arena = nullptr;
+    size_t vis_arena_units = 0;  // 16-byte units
+    uint32_t* vis_off = nullptr;
+    int32_t* vis_n = nullptr;
+    size_t vis_nq_cap = 0;
 };
 
 // One caller's jv_search waiting to be served.  Lives on the caller's stack.
@@ -398,7 +410,7 @@ int ctx_create(jv_index* ix, Ctx** out) {
     Ctx* c = new Ctx();
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->last_use, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipMalloc((void**)&c->work_counter, 16 * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&c->work_counter, 24 * sizeof(int32_t));
     if (e != hipSuccess) {
         delete c;
         return fail(JV_EDEVICE, "context creation failed: %s", hipGetErrorString(e));
@@ -424,6 +436,9 @@ void ctx_destroy(Ctx* c) {
     jv_free(c->work_counter);
     jv_free(c->spill);
     jv_free(c->pqp_log);
+    jv_free(c->vis_arena);
+    jv_free(c->vis_off);
+    jv_free(c->vis_n);
     if (c->last_use) hipEventDestroy(c->last_use);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -689,7 +704,7 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
     a.dbg = (int64_t*)(uintptr_t)OPT(ix, OPT_DBG_PTR);  // always 0 unless a diagnostic run set it
     const bool force_big = OPT(ix, OPT_FORCE_BIG) != 0 || !g.fast_ok;
     trace_point(c, 3, stream);
-    HIPCHK(hipMemsetAsync(c->work_counter, 0, 16 * sizeof(int32_t), stream));
+    HIPCHK(hipMemsetAsync(c->work_counter, 0, 24 * sizeof(int32_t), stream));
     trace_point(c, 4, stream);
     // Launches that only REDO flagged rows (second pool launch, 4x-hash escalation) need large workgroups; beside a live query-
     // server grid they used to ask the grid to leave (servers_yield_lds) on EVERY batch call, flagged rows or not — a stop the
@@ -706,6 +721,68 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
         if (phase == 1 && d_accept == nullptr && servers_free_lds(ix->device) < lds_bytes) return false;
         servers_yield_lds(ix->device, lds_bytes);
         return true;
+    };
+    // Visited counts after the launch (jv_kernels_vis.hip, round 5): a several-waves launch without a visit limit and without
+    // completion words copies every query's expansion log into an arena (2 x rerankK + 256 entries per query on average, at most
+    // 8 GB; a log that finds no room is counted inside the search kernel as before) and jv_visited_kernel counts the batch.
+    auto vis_attach = [&](JvSearchArgs& x) -> int {
+        if (OPT(ix, OPT_VISITED_AFTER) == 0 || done != nullptr || a.visit_limit > 0) return JV_OK;
+        // (its workgroups need 78 KB of LDS: beside a query-server grid — existing, running or not, see retry_rung_ok above — they
+        //  would wait for the grid to idle out; such a batch counts inside the search kernel
+        //  — unless it is a throughput batch, which asks the grids to leave as the search launch itself does)
+        if (nq >= 4 * ix->cu_count) servers_yield_lds(ix->device, jvk_visited_lds_bytes(16384));
+        else if (servers_free_lds(ix->device) < jvk_visited_lds_bytes(16384)) return JV_OK;
+        const size_t per_q = ((size_t)x.pqp_log_cap + 3) / 4;  // 16-byte units of the longest log
+        if ((size_t)nq * per_q >= ((size_t)1 << 32)) return JV_OK;  // (the cursor is 32 bits wide)
+        size_t units = std::min<size_t>((size_t)nq * std::min<size_t>(per_q, ((size_t)2 * rk + 256 + 3) / 4), (size_t)1 << 29);
+        if (OPT(ix, OPT_VISITED_ARENA_UNITS) > 0) units = (size_t)OPT(ix, OPT_VISITED_ARENA_UNITS);
+        if (units > c->vis_arena_units) {
+            if (c->vis_arena) HIPCHK(jv_free(c->vis_arena));
+            c->vis_arena = nullptr;
+            c->vis_arena_units = 0;
+            if (hipMalloc((void**)&c->vis_arena, units * 16) != hipSuccess) {
+                (void)hipGetLastError();  // no room for the arena: the search kernel counts
+                c->vis_arena = nullptr;
+                return JV_OK;
+            }
+            c->vis_arena_units = units;
+        }
+        if ((size_t)nq > c->vis_nq_cap) {
+            if (c->vis_off) HIPCHK(jv_free(c->vis_off));
+            if (c->vis_n) HIPCHK(jv_free(c->vis_n));
+            c->vis_off = nullptr;
+            c->vis_n = nullptr;
+            c->vis_nq_cap = 0;
+            HIPCHK(hipMalloc((void**)&c->vis_off, (size_t)nq * sizeof(uint32_t)));
+            HIPCHK(hipMalloc((void**)&c->vis_n, (size_t)nq * sizeof(int32_t)));
+            c->vis_nq_cap = (size_t)nq;
+        }
+        HIPCHK(hipMemsetAsync(c->vis_n, 0, (size_t)nq * sizeof(int32_t), stream));
+        x.vis_arena = c->vis_arena;
+        x.vis_cap_units = (uint32_t)std::min<size_t>(OPT(ix, OPT_VISITED_ARENA_UNITS) > 0 ? units : c->vis_arena_units, 0x7FFFFFFFull);
+        x.vis_cursor = (uint32_t*)(c->work_counter + 16);
+        x.vis_off = c->vis_off;
+        x.vis_n = c->vis_n;
+        return JV_OK;
+    };
+    auto vis_count = [&](const JvSearchArgs& x) -> int {
+        if (!x.vis_arena) return JV_OK;
+        JvVisArgs v{};
+        v.adj = ix->dev.adj;
+        v.R = ix->dev.R;
+        v.entry = ix->dev.entry;
+        v.arena = x.vis_arena;
+        v.vis_off = x.vis_off;
+        v.vis_n = x.vis_n;
+        v.nq = nq;
+        int slots = 16384;
+        if (OPT(ix, OPT_VISITED_SLOTS) >= 256 && OPT(ix, OPT_VISITED_SLOTS) < 16384) slots = next_pow2((int)OPT(ix, OPT_VISITED_SLOTS));
+        v.slots = slots;
+        v.out_stats = x.out_stats;
+        v.dbg = x.dbg ? (unsigned long long*)x.dbg + 16 : nullptr;  // (diagnostic runs: the words behind the search kernel's sixteen)
+        static const int per_cu = jvk_visited_blocks_per_cu(16384);
+        HIPCHK(jvk_launch_visited(&v, std::min(nq, ix->cu_count * per_cu), stream));
+        return JV_OK;
     };
     // PQ tables beyond the LDS (g.lutg: the reference's default 192 subspaces): on the fused layout the several-waves kernel
     // takes them first — twelve waves hold the table in registers + LDS rows — and the HBM-scratch rung (table in HBM) only
@@ -733,7 +810,9 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
             ap.pqp_log = c->pqp_log;
             ap.pqp_counter = c->work_counter + 6;
             servers_yield_lds(ix->device, lds);
+            if ((rc = vis_attach(ap)) != JV_OK) return rc;
             HIPCHK(jvk_launch_search_pqw(&ix->dev, &ap, lds, blocks, 0, stream));
+            if ((rc = vis_count(ap)) != JV_OK) return rc;
             ix->launches[LAUNCH_PQW]++;
             wide_first = true;
         }
@@ -910,8 +989,11 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
                 for (int i = 0; i < nrungs; i++) lds_max = std::max(lds_max, rungs[i].lds);
                 servers_yield_lds(ix->device, lds_max);
             }
-            if (pqw) HIPCHK(jvk_launch_search_pqw(&ix->dev, &ap, lds, blocks, pqw_variant, stream));
-            else if (pqwf) HIPCHK(launchF(ap, lds, blocks, 0));
+            if (pqw) {
+                if ((rc = vis_attach(ap)) != JV_OK) return rc;
+                HIPCHK(jvk_launch_search_pqw(&ix->dev, &ap, lds, blocks, pqw_variant, stream));
+                if ((rc = vis_count(ap)) != JV_OK) return rc;
+            } else if (pqwf) HIPCHK(launchF(ap, lds, blocks, 0));
             else HIPCHK(jvk_launch_search_pqp(&ix->dev, &ap, lds, blocks, lutr, stream));
             ix->launches[(pqw || pqwf) ? LAUNCH_PQW : LAUNCH_PQP]++;
             trace_point(c, 5, stream);

@@ -102,6 +102,27 @@ struct JvSearchArgs {
     int32_t done_all;            // completion words are also set for rows that come back flagged (no later rung in server mode)
     int32_t* done;           // optional completion words in host-visible memory: 1 once query i's row is final (see jv_pqw_body.h)
     int32_t pqw_lut_off;     // several-waves kernel: LDS byte offset of the table rows kept in LDS ([W][NL][256] floats)
+    // visited counts taken AFTER the search launch by jv_visited_kernel (jv_kernels_vis.hip, round 5): a query without a visit
+    // limit copies its expansion log into the arena instead of counting inside the search kernel
+    int32_t* vis_arena;      // [vis_cap_units * 4] ints, or nullptr = count inside the search kernel
+    uint32_t vis_cap_units;  // arena size in 16-byte units
+    uint32_t* vis_cursor;    // units handed out so far (zeroed per call)
+    uint32_t* vis_off;       // [nq] first unit of query i's log
+    int32_t* vis_n;          // [nq] its length; 0 = counted by the search kernel (zeroed per call)
+};
+
+// one launch of jv_visited_kernel: jvector's visitedCount of every query whose log sits in the arena
+struct JvVisArgs {
+    const int32_t* adj;      // [n][R] adjacency of the base layer
+    int32_t R;
+    int32_t entry;           // entry point: in the set before the counted inserts, never counted
+    const int32_t* arena;
+    const uint32_t* vis_off;
+    const int32_t* vis_n;
+    int32_t nq;
+    int32_t slots;           // hash slots in LDS (power of two)
+    int32_t* out_stats;      // [nq][4]: word 0 = visited
+    unsigned long long* dbg; // diagnostic build (-DJV_STAMPS) only: cycle accumulators of jv_visited_fast_kernel; nullptr in the product
 };
 
 // query-server words and slot layout (shared by jv_abi.cpp and the SERVE kernel instances)

@@ -994,7 +994,31 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
     }
     __syncthreads();
     int visited = 0;
-    if (why == 0) {
+    // Round 5: a batch launch without a visit limit does not count here.  The pass below is two waves walking the log behind one
+    // memory round trip per group while the query holds its slot of the CU; jv_visited_kernel (jv_kernels_vis.hip) counts the
+    // whole batch afterwards from copies of the logs, many waves per query and one hash class.  A log the arena has no room for
+    // is counted here as before.
+    bool vis_later = false;
+    if (why == 0 && a.vis_arena != nullptr && a.visit_limit <= 0 && a.done == nullptr && nexp > 0) {
+        if (threadIdx.x == 0) {
+            const uint32_t units = ((uint32_t)nexp + 3u) >> 2;
+            const uint32_t off = atomicAdd(a.vis_cursor, units);
+            ctrl[PQW_AGAIN] = (off <= a.vis_cap_units && units <= a.vis_cap_units - off) ? (int)off : -1;
+        }
+        __syncthreads();
+        const int off = __builtin_amdgcn_readfirstlane(ctrl[PQW_AGAIN]);
+        if (off >= 0) {
+            vis_later = true;
+            int32_t* dst = a.vis_arena + (size_t)off * 4;
+            for (int i = threadIdx.x; i < nexp; i += JV_WAVE * W) dst[i] = __hip_atomic_load(&explog[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (threadIdx.x == 0) {
+                a.vis_off[qi] = (uint32_t)off;
+                a.vis_n[qi] = nexp;
+            }
+        }
+        __syncthreads();
+    }
+    if (why == 0 && !vis_later) {
         // ---- jvector's visitedCount: distinct neighbours of the expanded nodes, entry point excluded; `parts` hash
         // classes are counted one after the other when one table cannot hold them all ----
         uint32_t* vh = (uint32_t*)smem;
@@ -1274,7 +1298,7 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
     if (lane == 0) {
         a.out_count[qi] = cnt;
         int32_t* st = a.out_stats + (size_t)qi * 4;
-        st[0] = visited;
+        st[0] = vis_later ? -1 : visited;  // (-1: jv_visited_kernel's to fill in)
         st[1] = reranked;
         st[2] = expanded;
         st[3] = expanded;

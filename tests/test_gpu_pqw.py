@@ -53,6 +53,46 @@ def test_shapes_and_pool_classes(pkg, pyoracle, sim, M, R, d):
     gpu.close()
 
 
+@pytest.mark.parametrize("R", [32, 24])
+def test_visited_counts_taken_after_the_launch(pkg, pyoracle, R):
+    """Round 5: a batch launch without a visit limit copies its expansion logs to an arena and jv_visited_kernel /
+    jv_visited_fast_kernel (csrc/jv_kernels_vis.hip) count jvector's visitedCount for the whole batch afterwards.  Every way
+    through must give the oracle's counters: the fast kernel (R = 32), the any-shape kernel (R = 24), a set so small that every
+    log needs several hash classes, an arena too small for most logs (those are counted inside the search kernel as before),
+    the in-kernel count alone, and a visit limit (always in-kernel: the limit is tested against the count)."""
+    b, bl, dg = pkg.binding, pkg.builder, pkg.datagen
+    n, d = 6000, 64
+    base = dg.splitmix_uniform(170 + R, n, d) - np.float32(0.25)
+    q = dg.splitmix_uniform(171 + R, 700, d) - np.float32(0.25)   # (more queries than one launch keeps resident on 256 CUs x 2)
+    ix = bl.build_index_cpu(base, 0, R=R, L=60, pq_M=32)
+    gpu = b.GpuIndex(ix, flags=b.DESC_FUSED_ADC)
+    orc = pyoracle.Oracle(b, ix)
+    for k, rk in [(10, 60), (10, 400), (20, 1500)]:
+        want = orc.search_batch(q, k, rk)
+        for name, opts in [("after the launch", {}), ("small set: several classes", {"visited_slots": 512}),
+                           ("small arena: most logs counted in the search kernel", {"visited_arena_units": 64 * max(rk // 4, 16)}),
+                           ("inside the search kernel", {"visited_after": 0})]:
+            try:
+                for key, val in opts.items():
+                    gpu.set_option(key, val)
+                before = gpu.counter("launches_pqw")
+                _assert_same(gpu.search_batch(q, k, rk), want, f"R={R} k={k} rk={rk} [{name}]")
+                assert gpu.counter("launches_pqw") > before
+            finally:
+                gpu.set_option("visited_slots", 16384)
+                gpu.set_option("visited_arena_units", 0)
+                gpu.set_option("visited_after", 1)
+    # a visit limit: exactly the searches whose visited + expanded reaches it come back early-terminated
+    want = orc.search_batch(q[:64], 10, 120)
+    work = want.stats[:, 0] + want.stats[:, 2]
+    lim = int(np.median(work))
+    got, status, flags, rc = gpu.search_batch_ex(q[:64], 10, 120, visit_limit=lim)
+    early = (flags & b.QFLAG_EARLY_TERMINATED) != 0
+    assert np.array_equal(early, work >= lim)
+    assert np.array_equal(got.stats[~early], want.stats[~early])
+    gpu.close()
+
+
 @pytest.mark.parametrize("seed", [41, 42])
 def test_tie_storm_and_second_launch(pkg, pyoracle, seed):
     """whole groups of nodes share one PQ code: strict admission (rejected entries), tie runs longer than the first

@@ -35,7 +35,7 @@ print(f"index ready in {time.time() - t0:.1f} s", flush=True)
 for key, val in os.environ.items():
     if key.startswith("JV_OPT_"):
         ix.set_option(key[len("JV_OPT_"):].lower(), int(val))
-dbg = torch.zeros(16, dtype=torch.int64, device=dev)
+dbg = torch.zeros(32, dtype=torch.int64, device=dev)  # [0, 16): the search kernel's phases; [16, 28): jv_visited_fast_kernel's
 
 
 def run(no_pqw, rk, iters=3):
@@ -77,5 +77,13 @@ for rk in rks:
             print(f"  {label}: cycles per expansion by phase")
             for i, nme in enumerate(names):
                 print(f"     {nme:40s} {100 * cyc[i] / max(cyc.sum(), 1):5.1f} %   {cyc[i] / ne:8.0f}")
+            if label != "one-wave" and v[16:28].sum() > 0:
+                vv = v[16:28]
+                steps = max(vv[7], 1)
+                vn = ["close / clear / barriers", "rows arrive", "full-width rounds", "packing", "packed walk", "next steps + loads issued", "tail"]
+                print("  jv_visited_fast_kernel: cycles per step and wave (steps per query: %.2f)" % (vv[7] / B / 3))
+                for i, nme in enumerate(vn):
+                    print(f"     {nme:40s} {100 * vv[i] / max(vv[:7].sum(), 1):5.1f} %   {vv[i] / steps:8.0f}")
+                print(f"     full-width rounds / step {vv[8] / steps:.2f}, packed ids / step {vv[9] / steps:.1f}, packed-walk instructions / step {vv[10] / steps:.1f}")
             print(f"     raw slots / expansion: " + " ".join(f"[{i}]={v[i] / ne:.2f}" if i in (8, 10, 11, 12) else f"[{i}]={v[i] / ne:.0f}" for i in range(16)))
 ix.close()
