@@ -71,6 +71,135 @@ typedef int i32x16 __attribute__((ext_vector_type(16)));
 // ctrl words (ints) behind the exchange area
 enum { PQW_C = 0, PQW_C2 = 1, PQW_WHY = 2, PQW_NP = 3, PQW_NEXP = 4, PQW_EXPANDED = 5, PQW_QI = 6, PQW_AGAIN = 7, PQW_C3 = 12, PQW_C4 = 13, PQW_CNT = 48 /* [W <= 16]: behind the diagnostic build's accumulators */ };
 
+// One hash class of the visited-count pass in STEPS (round 5; the form jv_kernels_vis.hip's batch kernel was built around): a wave
+// takes E = 1 024 / R log entries per step — one load of the log chunk, four 16-byte row loads, sixteen neighbour ids per lane —
+// and sends all of them down the probe chains together: one full-width round (sixteen compare-and-swap instructions), then what
+// is still pending is packed into the wave's list in LDS (each lane's ids behind those of the lanes below) and walked 64 ids at
+// a time, each lane down its own chain.  The LDS charges per instruction, not per live lane, and a group-of-16-rows pass spent
+// most of its instructions on the chains' tails with two or three lanes alive.  The rows of the step after next are requested
+// before the current step probes.  Shapes: R = 4 * LPR in {16, 32, 64}, adjacency rows 16-byte aligned.
+// Returns false when a chain ran past `chain_max` slots (the set is too full: the caller doubles the classes).
+template <int LPR, int W>
+__device__ __forceinline__ bool pqw_visited_steps(uint32_t* vh, const uint32_t vmask, const int vshift, const int pshift, const uint32_t pmask,
+                                                  const uint32_t p, int32_t* lst, const int lcap, const int32_t* explog, const int nexp,
+                                                  const int32_t* adj, const int wv, const int lane, int& cntl) {
+    constexpr int R = LPR * 4, RPL = JV_WAVE / LPR, E = 1024 / R, NLD = E / RPL, IDS = NLD * 4;
+    static_assert(NLD == 4 && IDS == 16, "four row loads, sixteen ids per lane and step");
+    constexpr int chain_max = 96;
+    const int nsteps = (nexp + E - 1) / E;
+    auto load_log = [&](int s) -> int {
+        if (s >= nsteps) return 0;
+        return __hip_atomic_load(&explog[min(s * E + (lane & (E - 1)), nexp - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto load_rows = [&](int s, int cur, int (&dst)[IDS]) {
+        if (s >= nsteps) return;
+        int lo = lane;
+        asm volatile("" : "+v"(lo));  // (nothing derived from the lane id is worth a register across the steps)
+        const int lr4 = (lo / LPR) << 2, lc = (lo % LPR) * 4;
+#pragma unroll
+        for (int h = 0; h < NLD; h++) {
+            const int node = __builtin_amdgcn_ds_bpermute(h * RPL * 4 + lr4, cur);  // (entries behind the log's end repeat its last node)
+            const u32x4 v = *(const u32x4*)(adj + (size_t)node * R + lc);
+            dst[4 * h] = (int)v.x, dst[4 * h + 1] = (int)v.y, dst[4 * h + 2] = (int)v.z, dst[4 * h + 3] = (int)v.w;
+        }
+    };
+    bool fine = true;
+    auto probe = [&](int s, const int (&q)[IDS]) {
+        int lo = lane;
+        asm volatile("" : "+v"(lo));
+        const int lrow = lo / LPR;
+        uint32_t pm = 0;  // bit u: id u of this lane is still on its way down a chain
+#pragma unroll
+        for (int h = 0; h < NLD; h++) {
+            const bool ok = s * E + h * RPL + lrow < nexp;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int id = q[4 * h + j];
+                if (ok && id >= 0 && (((uint32_t)id * 0x9E3779B1u >> pshift) & pmask) == p) pm |= 1u << (4 * h + j);  // (rows are padded with -1)
+            }
+        }
+        int round = 0, npend = 0, first = 0;
+        for (;; round++) {
+            if (round >= chain_max) {
+                fine = false;
+                return;
+            }
+            uint32_t K = 0x9E3779B1u;
+            asm volatile("" : "+s"(K));  // (a product per id kept across the rounds is sixteen registers)
+#pragma unroll
+            for (int c = 0; c < IDS; c += 4) {
+                if (!__any((pm & (0xFu << c)) != 0)) continue;
+                uint32_t oldv[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    oldv[u] = 0;
+                    if (pm & (1u << (c + u))) oldv[u] = atomicCAS(&vh[((((uint32_t)q[c + u] * K) >> vshift) + (uint32_t)round) & vmask], HASH_EMPTY, (uint32_t)q[c + u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (pm & (1u << (c + u))) {
+                        const bool fresh = oldv[u] == HASH_EMPTY;
+                        cntl += fresh ? 1 : 0;
+                        if (fresh || oldv[u] == (uint32_t)q[c + u]) pm &= ~(1u << (c + u));
+                    }
+                }
+            }
+            const int mine = __popc(pm);
+            int incl = mine;
+#pragma unroll
+            for (int o = 1; o < JV_WAVE; o <<= 1) {
+                const int t = __shfl_up(incl, o, JV_WAVE);
+                if (lo >= o) incl += t;
+            }
+            npend = __builtin_amdgcn_readlane(incl, JV_WAVE - 1);
+            first = incl - mine;
+            if (npend <= lcap) break;
+        }
+        round++;
+        if (npend == 0) return;
+#pragma unroll
+        for (int u = 0; u < IDS; u++)
+            if (pm & (1u << u)) lst[first + __popc(pm & ((1u << u) - 1u))] = q[u];
+        for (int b = 0; b < npend; b += JV_WAVE) {
+            bool pend = b + lo < npend;
+            const uint32_t id = (uint32_t)lst[min(b + lo, npend - 1)];
+            uint32_t slot = (((id * 0x9E3779B1u) >> vshift) + (uint32_t)round) & vmask;
+            for (int chain = round; __any(pend); chain++) {
+                if (chain >= chain_max) {
+                    fine = false;
+                    return;
+                }
+                if (pend) {
+                    const uint32_t old = atomicCAS(&vh[slot], HASH_EMPTY, id);
+                    cntl += old == HASH_EMPTY ? 1 : 0;
+                    pend = !(old == HASH_EMPTY || old == id);
+                    slot = (slot + 1) & vmask;
+                }
+            }
+        }
+    };
+    int idsA[IDS], idsB[IDS];
+#pragma unroll
+    for (int u = 0; u < IDS; u++) idsA[u] = -1, idsB[u] = -1;
+    int s0 = wv, curL;
+    {
+        const int c0 = load_log(s0), c1 = load_log(s0 + W);
+        curL = load_log(s0 + 2 * W);
+        load_rows(s0, c0, idsA);
+        load_rows(s0 + W, c1, idsB);
+    }
+    for (; s0 < nsteps && fine; s0 += 2 * W) {
+        probe(s0, idsA);
+        load_rows(s0 + 2 * W, curL, idsA);
+        curL = load_log(s0 + 3 * W);
+        if (s0 + W >= nsteps || !fine) break;
+        probe(s0 + W, idsB);
+        load_rows(s0 + 3 * W, curL, idsB);
+        curL = load_log(s0 + 4 * W);
+    }
+    return fine;
+}
+
 // NCHT: row length in 64-float chunks known at compile time (rerank), 0 = any d
 // CAPK: pool capacity class: 0 -> <= 512 entries, 1 -> <= 1 024, 2 -> <= 2 048
 // W:    waves per query = pq_M / 16 (2, 4; 12 = the reference's default 192 subspaces for 768-d .. 1 536-d fields)
@@ -1042,6 +1171,14 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
         const int G = vec ? rpl * 2 : rpl * VB;          // log entries per group (divides 64: a group sits in one log chunk)
         const int lrow = lane / lpr, lcol = (lane % lpr) * (vec ? 4 : 1);
         const bool lane_ok = lane < rpl * lpr;
+        // the waves' lists of the step form sit behind the set, in what the power-of-two set leaves of the LDS
+        const int lcap = min(256, ((hash_bytes - vslots * 4) / (4 * W)) & ~63);
+        int32_t* const lst_w = (int32_t*)(smem + (size_t)vslots * 4) + wv * lcap;
+        // (only the instances with the whole table in LDS — the latency variant and the query server, 200+ registers — take the step
+        //  form: in the 128-register throughput instances its sixteen + sixteen id registers next to the pool's 32 pushed the
+        //  kernel from 46 to 117 spills and the search loop lost 4 %; their batches count after the launch anyway)
+        constexpr bool steps_inst = NL == 16 && !FILT;
+        const bool steps_ok = steps_inst && vec && (R == 16 || R == 32 || R == 64) && lcap >= 64;
         bool again = true;
         while (again && why == 0) {
             again = false;
@@ -1066,7 +1203,15 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
                 // NPF = 2 / 3 / 4: 3.12 / 3.10 / 2.81 M QPS at rerankK 160, 566 / 568 / 567 k at 1 200).  Loads are unconditional
                 // with clamped indices.
                 constexpr int NPF = 2;
-                for (int blk0 = 0; blk0 < nexp && !over; blk0 += 1024) {
+                if constexpr (steps_inst) if (steps_ok) {
+                    // (round 5: the common shapes take the log in steps of E rows per wave, see pqw_visited_steps)
+                    bool fine;
+                    if (R == 32) fine = pqw_visited_steps<8, W>(vh, vmask, vshift, pshift, pmask, (uint32_t)p, lst_w, lcap, explog, nexp, ix.adj, wv, lane, cntl);
+                    else if (R == 16) fine = pqw_visited_steps<4, W>(vh, vmask, vshift, pshift, pmask, (uint32_t)p, lst_w, lcap, explog, nexp, ix.adj, wv, lane, cntl);
+                    else fine = pqw_visited_steps<16, W>(vh, vmask, vshift, pshift, pmask, (uint32_t)p, lst_w, lcap, explog, nexp, ix.adj, wv, lane, cntl);
+                    over = !fine;
+                }
+                for (int blk0 = 0; blk0 < nexp && !over && !steps_ok; blk0 += 1024) {
                     const int nblk = min(1024, nexp - blk0);
                     i32x16 logv;
 #pragma unroll
