@@ -36,10 +36,27 @@ __global__ __launch_bounds__(JV_WAVE * JV_VIS_WAVES) void jv_visited_kernel(cons
     const int G = vec ? rpl * 2 : rpl * VB;          // log entries per group (divides 64)
     const int lrow = lane / lpr, lcol = (lane % lpr) * (vec ? 4 : 1);
     const bool lane_ok = lane < rpl * lpr;
-    for (int qi = blockIdx.x; qi < a.nq; qi += gridDim.x) {
+    // A workgroup takes a contiguous range of the batch; its threads look at one query each for what is still to count — a log in the
+    // arena (else: counted by the search kernel, or a row a later rung redoes) whose stats row still says -1 (else: counted by
+    // jv_visited_fast_kernel) — and the workgroup walks that list.  (One query at a time behind two dependent loads each cost
+    // 1.2 ms per 262 144 queries with nothing to do.)
+    int* const todo_q = (int*)(smem + (size_t)a.slots * 4 + 64);  // [JV_WAVE * W] (the fast kernel's list area)
+    const int per = (a.nq + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int qb0 = (int)blockIdx.x * per, qb1 = min(a.nq, qb0 + per);
+    for (int qc = qb0; qc < qb1; qc += JV_WAVE * W) {
+    __syncthreads();
+    if (threadIdx.x == 0) ctrl[1] = 0;
+    __syncthreads();
+    {
+        const int qi = qc + (int)threadIdx.x;
+        if (qi < qb1 && a.vis_n[qi] > 0 && __hip_atomic_load(&a.out_stats[(size_t)qi * 4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0)
+            todo_q[atomicAdd(&ctrl[1], 1)] = qi;
+    }
+    __syncthreads();
+    const int ntodo = __builtin_amdgcn_readfirstlane(ctrl[1]);
+    for (int ti = 0; ti < ntodo; ti++) {
+        const int qi = __builtin_amdgcn_readfirstlane(todo_q[ti]);
         const int nexp = a.vis_n[qi];
-        if (nexp <= 0) continue;  // (counted by the search kernel, or a row a later rung redoes)
-        if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&a.out_stats[(size_t)qi * 4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= 0) continue;  // (counted by jv_visited_fast_kernel)
         const int32_t* explog = a.arena + (size_t)a.vis_off[qi] * 4;
         int parts = 1;
         while ((long long)nexp * 7 > (long long)vlimit * parts * 2) parts <<= 1;
@@ -172,6 +189,7 @@ __global__ __launch_bounds__(JV_WAVE * JV_VIS_WAVES) void jv_visited_kernel(cons
             a.out_stats[(size_t)qi * 4] = v;
         }
         __syncthreads();
+    }
     }
 }
 

@@ -67,6 +67,9 @@ for rk in rks:
     bad = int((old[0] != new[0]).any(1).sum())
     print(f"rk={rk}: one-wave {B / t_old:,.0f} QPS, several-waves {B / t_new:,.0f} QPS ({t_old / t_new:.2f}x); equal nodes/docs/scores/count/stats/flags = {eq}; "
           f"queries with different ids {bad}; expansions/query {st[2]:.1f} visited {st[0]:.1f}; flagged(new) {(new[5] != 0).sum()}", flush=True)
+    if (new[5] != 0).any():
+        why = (new[5].view(np.uint32) >> 8) & 0xFF
+        print("  flagged rows by reason code:", {int(k): int((why[new[5] != 0] == k).sum()) for k in np.unique(why[new[5] != 0])}, flush=True)
     if not all(eq):
         i = int(np.argmax((old[0] != new[0]).any(1) | (old[4] != new[4]).any(1)))
         print("  first differing query", i, "\n   old", old[0][i], old[4][i], old[5][i], "\n   new", new[0][i], new[4][i], new[5][i])

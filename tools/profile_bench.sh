@@ -17,7 +17,7 @@ t=$(find /tmp/rp_kt -name "*kernel_trace.csv" | head -1)
 if [ -n "$t" ]; then head -1 $t > $OUT/jv_kernel_trace.csv; grep -E "jv_" $t | grep -v builder >> $OUT/jv_kernel_trace.csv; fi
 for C in FETCH_SIZE WRITE_SIZE; do
   d=/tmp/rp_$C; rm -rf $d
-  rocprofv3 --pmc $C --kernel-include-regex "jv_search_(lds|pqf|pqp|pqw)_kernel" --output-format csv -d $d -- python3 $R/bench.py "$@" --profile-mode > $OUT/bench_under_pmc_$C.json 2> $OUT/bench_under_pmc_$C.err
+  rocprofv3 --pmc $C --kernel-include-regex "jv_(search_(lds|pqf|pqp|pqw)_kernel|visited)" --output-format csv -d $d -- python3 $R/bench.py "$@" --profile-mode > $OUT/bench_under_pmc_$C.json 2> $OUT/bench_under_pmc_$C.err
   c=$(find $d -name "*counter_collection.csv" | head -1)
   [ -n "$c" ] && cp $c $OUT/pmc_$C.csv
 done

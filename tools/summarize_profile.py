@@ -108,6 +108,16 @@ def main(src, name):
         vals = vals[-steps:]
         if vals:
             traffic[cname] = sum(vals) / len(vals)
+        # round 5: the batch's visited counts are taken by jv_visited_fast_kernel / jv_visited_kernel after the search launch (one
+        # dispatch of each per step): their bytes belong to the step's traffic
+        vis = {}
+        for r in csv.DictReader(open(p)):
+            if "jv_visited" in r["Kernel_Name"]:
+                vis.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
+        extra = sum(sum(v[-steps:]) / len(v[-steps:]) for v in vis.values() if v)
+        if vals and extra:
+            traffic[cname + "_visited"] = extra
+            traffic[cname] += extra
     if "FETCH_SIZE" in traffic:
         rd = traffic["FETCH_SIZE"] * 1024 * 2
         wr = traffic.get("WRITE_SIZE", 0.0) * 1024
@@ -115,6 +125,7 @@ def main(src, name):
         lines += ["## HBM traffic of the main kernel (PMC, separate passes)", "",
                   f"* FETCH_SIZE mean over the {steps} timed launches: {traffic['FETCH_SIZE']:.1f} KiB -> x1024 x2 (gfx950 wide-load correction) = {rd / 1e9:.3f} GB",
                   f"* WRITE_SIZE mean: {traffic.get('WRITE_SIZE', 0.0):.1f} KiB -> {wr / 1e9:.4f} GB",
+                  f"* of which the visited-count kernels behind the launch (jv_kernels_vis.hip): FETCH {traffic.get('FETCH_SIZE_visited', 0.0) * 2048 / 1e9:.3f} GB, WRITE {traffic.get('WRITE_SIZE_visited', 0.0) * 1024 / 1e9:.4f} GB",
                   f"* **HBM bytes per launch = {hbm / 1e9:.3f} GB** vs algorithmic {bench['roofline']['algorithmic_bytes_per_launch'] / 1e9:.3f} GB",
                   ""]
         tj = {"workload": bench["config"]["workload"].split(":")[0], "n": bench["config"]["docs_per_gpu"], "batch": B,
