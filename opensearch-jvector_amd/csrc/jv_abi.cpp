@@ -135,10 +135,13 @@ int fail(int code, const char* fmt, ...) {
 //   filter_cache                         device-resident doc-filter bitsets kept per index (0 = off)
 //   serve / serve_wgs_per_cu / serve_idle_ms   device-resident query servers for one-query calls — one grid for unfiltered calls, one for calls with a doc filter (resident workgroups per CU, idle time before they leave)
 //   lazy_big_rung                        host-pointer calls enqueue the HBM-scratch rung only when a row came back flagged (it serialises batches otherwise)
+//   visited_after                        several-waves batch launches without a visit limit copy their expansion logs to an arena and jv_visited_kernel counts visitedCount for the whole batch afterwards (0 = count inside the search kernel)
+//   visited_slots / visited_arena_units  its hash slots per workgroup / arena size in 16-byte units (tests: small values exercise the several-classes path and the in-kernel fall-back)
+//   time_search_kernel                   measurement: HIP events around the first search launch of every batch call (counters search_kernel_ns / search_kernel_timed)
 //   direct_completion                    combined one-query calls: rows land in pinned memory, every caller is woken by its own query's completion word
 //   lutr_min_queries                     launches with more queries keep the PQ look-up table in registers (-1 = 4 per CU)
 //   dbg_ptr                              diagnostic build only
-enum OptId { OPT_LDS_VISITED_SLOTS, OPT_LDS_CANDIDATES, OPT_FORCE_BIG, OPT_FORCE_GENERAL, OPT_NO_ESCALATION, OPT_DBG_PTR, OPT_NO_PQF, OPT_NO_PQP, OPT_NO_LUTR, OPT_LUTR_MIN_QUERIES, OPT_PQP_BLOCKS_PER_CU, OPT_NO_PQW, OPT_PQW_MIN_QUERIES, OPT_PQW_LAT_QUERIES, OPT_PQF_ONLY, OPT_SPILL_TABLES, OPT_SPILL_SLOTS, OPT_BIG_BLOCKS, OPT_BIG_CAND_CAP, OPT_BIG_BUDGET_MB, OPT_COMBINE, OPT_COMBINE_LEADERS, OPT_COMBINE_MAX_BATCH, OPT_MAX_CONTEXTS, OPT_FILTER_CACHE, OPT_DIRECT_COMPLETION, OPT_LAZY_BIG, OPT_SERVE, OPT_SERVE_WGS_PER_CU, OPT_SERVE_IDLE_MS, OPT_ASYNC_CONTEXTS, OPT_VISITED_AFTER, OPT_VISITED_SLOTS, OPT_VISITED_ARENA_UNITS, OPT_COUNT };
+enum OptId { OPT_LDS_VISITED_SLOTS, OPT_LDS_CANDIDATES, OPT_FORCE_BIG, OPT_FORCE_GENERAL, OPT_NO_ESCALATION, OPT_DBG_PTR, OPT_NO_PQF, OPT_NO_PQP, OPT_NO_LUTR, OPT_LUTR_MIN_QUERIES, OPT_PQP_BLOCKS_PER_CU, OPT_NO_PQW, OPT_PQW_MIN_QUERIES, OPT_PQW_LAT_QUERIES, OPT_PQF_ONLY, OPT_SPILL_TABLES, OPT_SPILL_SLOTS, OPT_BIG_BLOCKS, OPT_BIG_CAND_CAP, OPT_BIG_BUDGET_MB, OPT_COMBINE, OPT_COMBINE_LEADERS, OPT_COMBINE_MAX_BATCH, OPT_MAX_CONTEXTS, OPT_FILTER_CACHE, OPT_DIRECT_COMPLETION, OPT_LAZY_BIG, OPT_SERVE, OPT_SERVE_WGS_PER_CU, OPT_SERVE_IDLE_MS, OPT_ASYNC_CONTEXTS, OPT_VISITED_AFTER, OPT_VISITED_SLOTS, OPT_VISITED_ARENA_UNITS, OPT_TIME_SEARCH_KERNEL, OPT_COUNT };
 struct OptName { const char* name; int64_t def; };
 const OptName kOptNames[OPT_COUNT] = {
     {"lds_visited_slots", 0},
@@ -175,6 +178,7 @@ const OptName kOptNames[OPT_COUNT] = {
     {"visited_after", 1},
     {"visited_slots", 16384},      // hash slots of jv_visited_kernel's set (tests: a small set sends every log through several classes)
     {"visited_arena_units", 0},    // > 0: the log arena's size in 16-byte units (tests: a small arena sends logs back to the in-kernel count)
+    {"time_search_kernel", 0},     // measurement: HIP events around the first (main) search launch of every batch call -> counters search_kernel_ns / search_kernel_timed
 };
 struct Opts {
     std::atomic<int64_t> v[OPT_COUNT];
@@ -240,6 +244,10 @@ struct Ctx {
     uint32_t* vis_off = nullptr;
     int32_t* vis_n = nullptr;
     size_t vis_nq_cap = 0;
+    // measurement (option time_search_kernel): event pairs around the main search launch, read back by jv_index_get_counter
+    hipEvent_t kt[16][2] = {};
+    bool kt_pending[16] = {};
+    int kt_head = 0;
 };
 
 // One caller's jv_search waiting to be served.  Lives on the caller's stack.
@@ -363,6 +371,7 @@ struct jv_index {
     std::mutex async_mu;
     // launches per kernel family since creation (jv_index_get_counter): which rung served a call is observable
     std::atomic<int64_t> launches[8] = {};
+    std::atomic<int64_t> search_kernel_ns{0}, search_kernel_timed{0};  // (option time_search_kernel)
     struct JvQueryServer* server = nullptr;  // device-resident query server (created by the first eligible one-query call)
     struct JvQueryServer* server_f = nullptr;  // the same for one-query calls WITH a doc filter (one-wave filtered pool kernel)
     std::mutex server_mu;
@@ -439,6 +448,9 @@ void ctx_destroy(Ctx* c) {
     jv_free(c->vis_arena);
     jv_free(c->vis_off);
     jv_free(c->vis_n);
+    for (int i = 0; i < 16; i++)
+        for (int j = 0; j < 2; j++)
+            if (c->kt[i][j]) hipEventDestroy(c->kt[i][j]);
     if (c->last_use) hipEventDestroy(c->last_use);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -652,6 +664,37 @@ int plan_pqp_lds(const jv_index* ix, JvSearchArgs& x, bool regs, int rk) {
     return lds;
 }
 
+// Measurement (option time_search_kernel; bench.py's roofline): the duration of the batch call's FIRST search launch — the kernel
+// that moves the bytes — from HIP events recorded around it on the stream it is launched on.  The later launches of a call (the
+// visited-count kernels, the launch that redoes flagged rows) are not inside the pair.
+void kt_harvest(jv_index* ix, Ctx* c) {
+    for (int i = 0; i < 16; i++)
+        if (c->kt_pending[i]) {
+            float ms = 0.0f;
+            if (hipEventSynchronize(c->kt[i][1]) == hipSuccess && hipEventElapsedTime(&ms, c->kt[i][0], c->kt[i][1]) == hipSuccess) {
+                ix->search_kernel_ns += (int64_t)((double)ms * 1e6);
+                ix->search_kernel_timed++;
+            }
+            c->kt_pending[i] = false;
+        }
+}
+int kt_begin(jv_index* ix, Ctx* c, hipStream_t stream) {
+    if (OPT(ix, OPT_TIME_SEARCH_KERNEL) == 0) return -1;
+    const int slot = c->kt_head & 15;
+    if (c->kt_pending[slot]) kt_harvest(ix, c);
+    for (int j = 0; j < 2; j++)
+        if (!c->kt[slot][j] && hipEventCreate(&c->kt[slot][j]) != hipSuccess) return -1;
+    if (hipEventRecord(c->kt[slot][0], stream) != hipSuccess) return -1;
+    return slot;
+}
+void kt_end(Ctx* c, int slot, hipStream_t stream) {
+    if (slot < 0) return;
+    if (hipEventRecord(c->kt[slot][1], stream) == hipSuccess) {
+        c->kt_pending[slot] = true;
+        c->kt_head++;
+    }
+}
+
 // enqueue one batch on `stream`; all pointers are device pointers
 void trace_point(Ctx* c, int i, hipStream_t stream);  // (JV_BATCH_TRACE diagnostics)
 int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queries, int nq, int topK, int rk,
@@ -811,7 +854,9 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
             ap.pqp_counter = c->work_counter + 6;
             servers_yield_lds(ix->device, lds);
             if ((rc = vis_attach(ap)) != JV_OK) return rc;
+            const int kts = kt_begin(ix, c, stream);
             HIPCHK(jvk_launch_search_pqw(&ix->dev, &ap, lds, blocks, 0, stream));
+            kt_end(c, kts, stream);
             if ((rc = vis_count(ap)) != JV_OK) return rc;
             ix->launches[LAUNCH_PQW]++;
             wide_first = true;
@@ -991,10 +1036,16 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
             }
             if (pqw) {
                 if ((rc = vis_attach(ap)) != JV_OK) return rc;
+                const int kts = kt_begin(ix, c, stream);
                 HIPCHK(jvk_launch_search_pqw(&ix->dev, &ap, lds, blocks, pqw_variant, stream));
+                kt_end(c, kts, stream);
                 if ((rc = vis_count(ap)) != JV_OK) return rc;
-            } else if (pqwf) HIPCHK(launchF(ap, lds, blocks, 0));
-            else HIPCHK(jvk_launch_search_pqp(&ix->dev, &ap, lds, blocks, lutr, stream));
+            } else {
+                const int kts = kt_begin(ix, c, stream);
+                if (pqwf) HIPCHK(launchF(ap, lds, blocks, 0));
+                else HIPCHK(jvk_launch_search_pqp(&ix->dev, &ap, lds, blocks, lutr, stream));
+                kt_end(c, kts, stream);
+            }
             ix->launches[(pqw || pqwf) ? LAUNCH_PQW : LAUNCH_PQP]++;
             trace_point(c, 5, stream);
             if (second_now) {
@@ -1055,7 +1106,9 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
     if (!force_big) {
         if (!pqf) {
             servers_yield_lds(ix->device, g.lds_fast);
+            const int kts = kt_begin(ix, c, stream);
             HIPCHK(jvk_launch_search_lds(&ix->dev, &a, pq ? 1 : 0, g.pool ? 1 : 0, ix->build_client ? 2 : 0, g.lds_fast, stream));
+            kt_end(c, kts, stream);
             ix->launches[LAUNCH_LDS]++;
         }
         // (after a PQF launch the flagged queries go straight to the rung below: generic kernel, 4x visited table)
@@ -1935,6 +1988,16 @@ int jv_index_get_counter(const jv_index* index, const char* name, int64_t* out) 
             *out = index->launches[i].load();
             return JV_OK;
         }
+    if (strcmp(name, "search_kernel_ns") == 0 || strcmp(name, "search_kernel_timed") == 0) {
+        // (measurement: waits for the timed launches still in flight; not meant to be read while other threads search)
+        jv_index* ix = const_cast<jv_index*>(index);
+        {
+            std::lock_guard<std::mutex> lk(ix->mu);
+            for (Ctx* c : ix->all_ctx) kt_harvest(ix, c);
+        }
+        *out = name[14] == 'n' ? ix->search_kernel_ns.load() : ix->search_kernel_timed.load();
+        return JV_OK;
+    }
     if (strcmp(name, "exact_calls") == 0) { *out = index->xb.exact_calls.load(); return JV_OK; }
     if (strcmp(name, "exact_batches") == 0) { *out = index->xb.exact_batches.load(); return JV_OK; }
     return fail(JV_EINVAL, "unknown counter '%s'", name);

@@ -93,6 +93,27 @@ def test_visited_counts_taken_after_the_launch(pkg, pyoracle, R):
     gpu.close()
 
 
+def test_search_kernel_timing_counters(pkg):
+    """bench.py's roofline divides by the main search kernel's own duration: HIP events the library records around the first
+    search launch of a batch call (option time_search_kernel), read back through search_kernel_ns / search_kernel_timed."""
+    b, bl, dg = pkg.binding, pkg.builder, pkg.datagen
+    base = dg.splitmix_uniform(7, 3000, 64)
+    q = dg.splitmix_uniform(8, 600, 64)
+    gpu = b.GpuIndex(bl.build_index_cpu(base, 0, R=32, L=60, pq_M=32), flags=b.DESC_FUSED_ADC)
+    gpu.search_batch(q, 10, 200)
+    assert gpu.counter("search_kernel_timed") == 0          # (off by default)
+    gpu.set_option("time_search_kernel", 1)
+    for _ in range(20):                                       # (more calls than the ring of event pairs holds)
+        gpu.search_batch(q, 10, 200)
+    assert gpu.counter("search_kernel_timed") == 20
+    ns = gpu.counter("search_kernel_ns")
+    assert 20 * 10_000 < ns < 20 * 50_000_000, ns             # 10 us .. 50 ms per launch
+    gpu.set_option("time_search_kernel", 0)
+    gpu.search_batch(q, 10, 200)
+    assert gpu.counter("search_kernel_timed") == 20
+    gpu.close()
+
+
 @pytest.mark.parametrize("seed", [41, 42])
 def test_tie_storm_and_second_launch(pkg, pyoracle, seed):
     """whole groups of nodes share one PQ code: strict admission (rejected entries), tie runs longer than the first
