@@ -736,6 +736,9 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
     a.cand_cap = g.cand_cap;
     a.res_cap = g.res_cap;
     a.visit_limit = visit_limit > 0 ? (int32_t)std::min<int64_t>(visit_limit, INT32_MAX) : 0;
+    // (visited <= n distinct nodes and expanded <= n: a limit beyond 2 n can never be reached — such a call is a call without one,
+    //  and takes the launches without the in-kernel count; Lucene's unfiltered searches carry Integer.MAX_VALUE)
+    if (visit_limit > 2 * (int64_t)ix->dev.n) a.visit_limit = 0;
     a.done = done;  // (completion words: honoured by the several-waves pool kernel; rows of other kernels are final at stream end)
     a.work_counter = c->work_counter;
     a.retry_only = 0;
@@ -769,7 +772,7 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
     // completion words copies every query's expansion log into an arena (2 x rerankK + 256 entries per query on average, at most
     // 8 GB; a log that finds no room is counted inside the search kernel as before) and jv_visited_kernel counts the batch.
     auto vis_attach = [&](JvSearchArgs& x) -> int {
-        if (OPT(ix, OPT_VISITED_AFTER) == 0 || done != nullptr || a.visit_limit > 0) return JV_OK;
+        if (OPT(ix, OPT_VISITED_AFTER) == 0 || done != nullptr) return JV_OK;
         // (its workgroups need 78 KB of LDS: beside a query-server grid — existing, running or not, see retry_rung_ok above — they
         //  would wait for the grid to idle out; such a batch counts inside the search kernel
         //  — unless it is a throughput batch, which asks the grids to leave as the search launch itself does)
@@ -777,7 +780,9 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
         else if (servers_free_lds(ix->device) < jvk_visited_lds_bytes(16384)) return JV_OK;
         const size_t per_q = ((size_t)x.pqp_log_cap + 3) / 4;  // 16-byte units of the longest log
         if ((size_t)nq * per_q >= ((size_t)1 << 32)) return JV_OK;  // (the cursor is 32 bits wide)
-        size_t units = std::min<size_t>((size_t)nq * std::min<size_t>(per_q, ((size_t)2 * rk + 256 + 3) / 4), (size_t)1 << 29);
+        // (with a doc filter a search expands ~ rerankK / selectivity entries: room for a pool's worth of entries per query)
+        const size_t typical = d_accept ? (size_t)x.cand_cap + 256 : (size_t)2 * rk + 256;
+        size_t units = std::min<size_t>((size_t)nq * std::min<size_t>(per_q, (typical + 3) / 4), (size_t)1 << 29);
         if (OPT(ix, OPT_VISITED_ARENA_UNITS) > 0) units = (size_t)OPT(ix, OPT_VISITED_ARENA_UNITS);
         if (units > c->vis_arena_units) {
             if (c->vis_arena) HIPCHK(jv_free(c->vis_arena));
@@ -822,6 +827,13 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
         if (OPT(ix, OPT_VISITED_SLOTS) >= 256 && OPT(ix, OPT_VISITED_SLOTS) < 16384) slots = next_pow2((int)OPT(ix, OPT_VISITED_SLOTS));
         v.slots = slots;
         v.out_stats = x.out_stats;
+        v.visit_limit = x.visit_limit;
+        v.topK = x.topK;
+        v.out_nodes = x.out_nodes;
+        v.out_docs = x.out_docs;
+        v.out_scores = x.out_scores;
+        v.out_count = x.out_count;
+        v.out_flags = x.out_flags;
         v.dbg = x.dbg ? (unsigned long long*)x.dbg + 16 : nullptr;  // (diagnostic runs: the words behind the search kernel's sixteen)
         static const int per_cu = jvk_visited_blocks_per_cu(16384);
         HIPCHK(jvk_launch_visited(&v, std::min(nq, ix->cu_count * per_cu), stream));
@@ -1041,6 +1053,15 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
                 kt_end(c, kts, stream);
                 if ((rc = vis_count(ap)) != JV_OK) return rc;
             } else {
+                // (doc filters on the several-waves kernel: the first launch and every rung behind it hand their logs to the same arena)
+                if (pqwf) {
+                    if ((rc = vis_attach(ap)) != JV_OK) return rc;
+                    auto share = [&](JvSearchArgs& y) {
+                        y.vis_arena = ap.vis_arena, y.vis_cap_units = ap.vis_cap_units, y.vis_cursor = ap.vis_cursor, y.vis_off = ap.vis_off, y.vis_n = ap.vis_n;
+                    };
+                    share(ap2);
+                    for (int i = 0; i < nrungs; i++) share(rungs[i].a);
+                }
                 const int kts = kt_begin(ix, c, stream);
                 if (pqwf) HIPCHK(launchF(ap, lds, blocks, 0));
                 else HIPCHK(jvk_launch_search_pqp(&ix->dev, &ap, lds, blocks, lutr, stream));
@@ -1057,6 +1078,7 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
                 rungs[i].a.pqp_log = c->pqp_log;
                 HIPCHK(launchF(rungs[i].a, rungs[i].lds, rungs[i].blocks, lutr2));
             }
+            if (pqwf && (rc = vis_count(ap)) != JV_OK) return rc;
             pqf = true;
         }
     }

@@ -122,6 +122,14 @@ struct JvVisArgs {
     int32_t nq;
     int32_t slots;           // hash slots in LDS (power of two)
     int32_t* out_stats;      // [nq][4]: word 0 = visited
+    // Lucene's visit limit (> 0): a row whose visited + expanded reaches it becomes an early-terminated row (flag, no results), as
+    // the search kernel makes it when it counts itself (J/JVectorReader.java:202-207, AbstractKnnVectorQuery)
+    int32_t visit_limit, topK;
+    int32_t* out_nodes;      // [nq][topK]
+    int32_t* out_docs;       // [nq][topK] or nullptr
+    float* out_scores;       // [nq][topK]
+    int32_t* out_count;      // [nq]
+    int32_t* out_flags;      // [nq]
     unsigned long long* dbg; // diagnostic build (-DJV_STAMPS) only: cycle accumulators of jv_visited_fast_kernel; nullptr in the product
 };
 

@@ -14,6 +14,27 @@
 #define JV_VIS_WAVES 8
 typedef int vis_i32x16 __attribute__((ext_vector_type(16)));
 
+// one query's count goes out (called by a whole wave): word 0 of its stats row, and — with a visit limit — the row turns into
+// an early-terminated one when visited + expanded reaches the limit (what jv_pqw_body.h does when it counts inside the search kernel)
+__device__ __forceinline__ void vis_publish(const JvVisArgs& a, const int qi, const int v, const int lane) {
+    int32_t* st = a.out_stats + (size_t)qi * 4;
+    bool early = false;
+    if (a.visit_limit > 0) early = v + __builtin_amdgcn_readfirstlane(st[2]) >= a.visit_limit;
+    if (lane == 0) st[0] = v;
+    if (early) {
+        if (lane == 0) {
+            st[1] = 0;
+            a.out_flags[qi] = (int32_t)JV_FLAG_EARLY;
+            a.out_count[qi] = 0;
+        }
+        for (int i = lane; i < a.topK; i += JV_WAVE) {
+            a.out_nodes[(size_t)qi * a.topK + i] = -1;
+            if (a.out_docs) a.out_docs[(size_t)qi * a.topK + i] = -1;
+            a.out_scores[(size_t)qi * a.topK + i] = 0.0f;
+        }
+    }
+}
+
 __global__ __launch_bounds__(JV_WAVE * JV_VIS_WAVES) void jv_visited_kernel(const JvVisArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int W = JV_VIS_WAVES;
@@ -182,11 +203,11 @@ __global__ __launch_bounds__(JV_WAVE * JV_VIS_WAVES) void jv_visited_kernel(cons
         }
         if (lane == 0) ctrl[4 + wv] = visited;
         __syncthreads();
-        if (threadIdx.x == 0) {
+        if (wv == 0) {
             int v = 0;
 #pragma unroll
-            for (int w2 = 0; w2 < W; w2++) v += ctrl[4 + w2];
-            a.out_stats[(size_t)qi * 4] = v;
+            for (int w2 = 0; w2 < W; w2++) v += __builtin_amdgcn_readfirstlane(ctrl[4 + w2]);
+            vis_publish(a, qi, v, lane);
         }
         __syncthreads();
     }
@@ -394,11 +415,11 @@ __global__ __launch_bounds__(JV_WAVE * JV_VIS_WAVES, 4) void jv_visited_fast_ker
                     if (lane == 0) ctrl[4 + wv] = c;
                     if (over && lane == 0) ctrl[0] = 1;
                     __syncthreads();
-                    if (threadIdx.x == 0) {
+                    if (wv == 0) {
                         int v = 0;
 #pragma unroll
-                        for (int w2 = 0; w2 < W; w2++) v += ctrl[4 + w2];
-                        a.out_stats[(size_t)(qbase + p_k) * 4] = ctrl[0] != 0 ? -1 : v;  // (-1: the generic kernel's)
+                        for (int w2 = 0; w2 < W; w2++) v += __builtin_amdgcn_readfirstlane(ctrl[4 + w2]);
+                        if (__builtin_amdgcn_readfirstlane(ctrl[0]) == 0) vis_publish(a, qbase + p_k, v, lane);  // (else the row stays at -1: the generic kernel's)
                     }
                     cntl = 0;
                     over = false;

@@ -1123,12 +1123,12 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
     }
     __syncthreads();
     int visited = 0;
-    // Round 5: a batch launch without a visit limit does not count here.  The pass below is two waves walking the log behind one
+    // Round 5: a batch launch (no completion words) does not count here.  The pass below is two waves walking the log behind one
     // memory round trip per group while the query holds its slot of the CU; jv_visited_kernel (jv_kernels_vis.hip) counts the
     // whole batch afterwards from copies of the logs, many waves per query and one hash class.  A log the arena has no room for
     // is counted here as before.
     bool vis_later = false;
-    if (why == 0 && a.vis_arena != nullptr && a.visit_limit <= 0 && a.done == nullptr && nexp > 0) {
+    if (why == 0 && a.vis_arena != nullptr && a.done == nullptr && nexp > 0) {
         if (threadIdx.x == 0) {
             const uint32_t units = ((uint32_t)nexp + 3u) >> 2;
             const uint32_t off = atomicAdd(a.vis_cursor, units);
@@ -1335,7 +1335,7 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
     // sum, AbstractKnnVectorQuery tests it).  The loop above stops on expansions alone (visited is only known now): a search
     // that ran to its end but whose SUM reaches the limit is flagged the same way, with its real counters.
     int early_vis = -1;
-    if (why == 0 && a.visit_limit > 0 && visited + expanded >= a.visit_limit) {
+    if (why == 0 && !vis_later && a.visit_limit > 0 && visited + expanded >= a.visit_limit) {  // (a row counted after the launch: jv_visited_kernel applies the same rule)
         why = 15;
         early_vis = visited;
     }

@@ -49,6 +49,13 @@ def run(budget, seed0):
             opts["lutr_min_queries"] = 0
         if rng.random() < 0.3:
             opts["no_lutr"] = 1
+        # round 5: visited counts after the launch — small sets (several hash classes), small arenas (in-kernel fall-back), off
+        if rng.random() < 0.3:
+            opts["visited_slots"] = int(rng.choice([256, 512, 2048]))
+        if rng.random() < 0.25:
+            opts["visited_arena_units"] = int(rng.choice([4, 64, 1024]))
+        if rng.random() < 0.2:
+            opts["visited_after"] = 0
         for k_, v_ in opts.items():
             gpu.set_option(k_, v_)
         nq = int(rng.integers(8, 70))
@@ -82,6 +89,19 @@ def run(budget, seed0):
                     i = bad[0]
                     print(" got ", got.nodes[i][:10], got.stats[i], "\n want", want.nodes[i][:10], want.stats[i])
                 return False
+            # Lucene's visit limit on the same call: exactly the searches whose visited + expanded reaches it come back early-terminated
+            # (no results), the others unchanged — whichever kernel counted, inside the search launch or after it
+            if rng.random() < 0.3 and "rerank_floor" not in kw:
+                work = want.stats[:, 0].astype(np.int64) + want.stats[:, 2]
+                lim = max(1, int(np.quantile(work, float(rng.choice([0.2, 0.5, 0.9])))))
+                got, status, flags, rc = gpu.search_batch_ex(q, k, rk, visit_limit=lim, **kw)
+                early = (flags & b.QFLAG_EARLY_TERMINATED) != 0
+                checks += 1
+                if not (np.array_equal(early, work >= lim) and np.array_equal(got.nodes[~early], want.nodes[~early]) and
+                        np.array_equal(got.stats[~early], want.stats[~early]) and (got.count[early] == 0).all() and (got.nodes[early] == -1).all()):
+                    print(f"VISIT-LIMIT MISMATCH seed={seed} n={n} d={d} R={R} M={M} sim={sim} ties={ties} opts={opts} k={k} rk={rk} lim={lim} filter={'accept' in kw}")
+                    print(" early got ", early.astype(int)[:32], "\n early want", (work >= lim).astype(int)[:32])
+                    return False
         # the batched exact scorer on the same index (jv_score_ordinals_batch: bf16 matrix-core pre-filter forced on for these
         # short lists half of the time, canonical re-score) against the oracle's scan + (score desc, doc asc)
         docs_of = ord2doc if ord2doc is not None else np.arange(n, dtype=np.int32)
