@@ -1989,7 +1989,7 @@ int jv_index_get_info(const jv_index* index, jv_index_info* out) {
         std::lock_guard<std::mutex> lk(ix->mu);
         for (const Ctx* c : ix->all_ctx)
             scratch += (int64_t)(c->queries_cap * 4 + c->nq_cap * 4 + c->accept_cap * 8 + c->arena_cap + c->pqp_log_ints * 4 +
-                                 (size_t)c->spill_tables * (size_t)c->spill_slots * 4 + 32);
+                                 (size_t)c->spill_tables * (size_t)c->spill_slots * 4 + 32 + c->vis_arena_units * 16 + c->vis_nq_cap * 8);
     }
     {
         std::lock_guard<std::mutex> lk(ix->filter_mu);
