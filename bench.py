@@ -224,6 +224,22 @@ JV_FLAG_FAILED = 0x40000000
 JV_FLAG_OVERFLOW = 0x80000000
 
 
+def roofline_object(bytes_per_launch, kernel_avg_ms, call_avg_ms, traffic, traffic_source, main_kernel, pq_M, fused):
+    """the `roofline` object of the bench line: algorithmic bytes of one launch (SURVEY 8(d) per-query figure x the step's
+    queries) / the dominant kernel's own mean launch duration, against the 8 TB/s HBM peak; the whole call's duration (search +
+    visited-count kernels + the launch that redoes flagged rows) is kept beside it"""
+    achieved_gbs = bytes_per_launch / (kernel_avg_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+            "kernel": main_kernel, "kernel_avg_ms": round(kernel_avg_ms, 4),
+            "kernel_time_source": "HIP events around the call's first search launch, recorded by the library on the launch stream (option time_search_kernel)",
+            "call_avg_ms": round(call_avg_ms, 4),
+            "frac_whole_call": round(bytes_per_launch / (call_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "algorithmic_bytes_per_launch": round(bytes_per_launch, 1),
+            "formula": ("expanded*R*(M+4) + reranked*4d + 1024d/B" if fused else
+                        ("visited*M + expanded*4(R+1) + reranked*4d + 1024d/B" if pq_M else "visited*4d + expanded*4(R+1)"))}
+
+
 def algorithmic_bytes(visited, reranked, expanded, nq_total, launches, pq_M, d, R, fused):
     """SURVEY 8(d), summed over `nq_total` queries issued in `launches` launches.
        fp32 path:              visited*4d + expanded*4(R+1)
@@ -890,15 +906,7 @@ def main():
                       "algorithmic_bytes": round(bytes_total / total_queries, 1)},
         "big_path_queries_last_step": t["big_path_last_step"],
         "build_seconds": round(eng.build_s, 1),
-        "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                     "kernel": main_kernel, "kernel_avg_ms": round(kernel_avg_ms, 4),
-                     "kernel_time_source": "HIP events around the call's first search launch, recorded by the library on the launch stream (option time_search_kernel)",
-                     "call_avg_ms": round(t["call_avg_ms"], 4),
-                     "frac_whole_call": round(bytes_per_launch / (t["call_avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                     "algorithmic_bytes_per_launch": round(bytes_per_launch, 1),
-                     "formula": ("expanded*R*(M+4) + reranked*4d + 1024d/B" if fused else
-                                 ("visited*M + expanded*4(R+1) + reranked*4d + 1024d/B" if pq_M else "visited*4d + expanded*4(R+1)"))},
+        "roofline": roofline_object(bytes_per_launch, kernel_avg_ms, t["call_avg_ms"], traffic, traffic_source, main_kernel, pq_M, fused),
     }
     if not pq_M:
         # 65 536 queries over 4 096 shared cluster centres re-read the same rows ~160x per launch: those re-reads are

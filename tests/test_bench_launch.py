@@ -58,3 +58,24 @@ def test_kept_bench_line_has_the_contract_fields():
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == j["unit"] and c["sample"]
     # value = queries of the timed steps / time: steps x batch / (steps x ms_per_step)
     assert abs(j["value"] - j["config"]["queries_per_step"] / (j["ms_per_step"] * 1e-3)) / j["value"] < 0.01
+
+
+def test_roofline_arithmetic_of_the_bench_line():
+    """the numbers `bench.py` derives, on made-up counters (no GPU): SURVEY 8(d)'s bytes per query for the three layouts, the
+    roofline object (fraction = achieved / peak on the KERNEL's time, the whole call's fraction beside it)"""
+    sys.path.insert(0, ROOT)
+    import bench
+    nq, launches, d, R, M = 1000, 2, 768, 32, 32
+    visited, reranked, expanded = 4000.0 * nq, 1200.0 * nq, 1377.0 * nq
+    fused = bench.algorithmic_bytes(visited, reranked, expanded, nq, launches, M, d, R, True)
+    assert fused == expanded * R * (M + 4) + reranked * 4 * d + launches * 1024 * d
+    plain = bench.algorithmic_bytes(visited, reranked, expanded, nq, launches, M, d, R, False)
+    assert plain == visited * M + expanded * 4 * (R + 1) + reranked * 4 * d + launches * 1024 * d
+    assert bench.algorithmic_bytes(visited, 0.0, expanded, nq, launches, 0, d, R, False) == visited * 4 * d + expanded * 4 * (R + 1)
+    # per query at the headline's counters: 1 377 x 32 x 36 + 1 200 x 3 072 (+ the shared codebook read)
+    assert abs(fused / nq - (1377 * 32 * 36 + 1200 * 3072 + launches * 1024 * d / nq)) < 1e-6
+    r = bench.roofline_object(1.382e12, 464.0, 489.0, 1.5e12, "kept", "jv_search_pqw_kernel", M, True)
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["achieved"] - 1.382e12 / 0.464 / 1e9) < 0.1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert abs(r["frac_whole_call"] - 1.382e12 / 0.489 / 1e9 / 8000.0) < 1e-4 and r["frac_whole_call"] < r["frac"]
+    assert r["kernel_avg_ms"] == 464.0 and r["call_avg_ms"] == 489.0 and r["traffic"] == 1.5e12 and "reranked*4d" in r["formula"]
