@@ -5,10 +5,13 @@
 // pool kernels keep no visited set while they search — they rebuild the count from the expansion log.  Inside the several-waves
 // search kernel that pass is two waves behind one memory round trip per group of rows, on a hash set that needs two classes
 // (two walks over the log) because the query's LDS share is 19 KB: 11-16 % of the time a query holds its slot of the CU.  Here
-// the same count is a throughput job: one workgroup of four waves per query, a 32 KB set (one class for logs of up to ~1 900
-// expansions), four groups of adjacency rows in flight per wave, sixteen waves per CU.
-//
-// Same hash, same probe sequence and the same `parts` rule as jv_pqw_body.h's pass; the count does not depend on any of them.
+// the same count is a throughput job, on copies of the batch's logs (JvSearchArgs.vis_*, jv_pqw_body.h): one workgroup of
+// eight waves per query and a 64 KB set (one class for logs of up to ~3 800 expansions), two workgroups per CU.
+//   jv_visited_fast_kernel   R = 16 / 32 / 64, 16-byte aligned rows, logs that fit one class (below: steps, packed tails)
+//   jv_visited_kernel        any shape, any number of classes: what the fast kernel leaves at -1, or everything
+// Both apply Lucene's visit limit to the rows they count (vis_publish).  The count does not depend on hash, probe order or
+// classes; tests/test_gpu_pqw.py::test_visited_counts_taken_after_the_launch and tools/fuzz_parity.py hold every way through
+// against the oracle's counters.
 #include "jv_dev_common.h"
 
 #define JV_VIS_WAVES 8
