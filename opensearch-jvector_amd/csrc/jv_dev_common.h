@@ -393,7 +393,7 @@ __device__ __forceinline__ void score_rows_nvq_t(const JvIndexDev& ix, const flo
 template <int NCHT>
 struct RowsInFlight { static constexpr int U = NCHT <= 6 ? 4 : (NCHT <= 12 ? 2 : 1); };
 
-template <int NCHT, int UMUL = 1, bool STREAM = false>
+template <int NCHT, int UMUL = 1, bool STREAM = false, int UADD = 0>   // UADD: more row groups in flight where the caller has the registers
 __device__ __forceinline__ void score_rows(const JvIndexDev& ix, const float* q_lds, const int32_t* todo, int m,
                                            float* todo_score, float qnorm2, float scale, int lane) {
     // NVQ-inline field: exact scores against the dequantised records.  Only the "any d" instances (NCHT = 0) carry the
@@ -411,7 +411,7 @@ __device__ __forceinline__ void score_rows(const JvIndexDev& ix, const float* q_
         else score_rows_t<2>(ix, q_lds, todo, m, todo_score, qnorm2, scale, lane);
     } else {
         constexpr int N = NCHT == 0 ? 1 : NCHT;
-        constexpr int U = RowsInFlight<N>::U * UMUL;
+        constexpr int U = RowsInFlight<N>::U * UMUL + UADD;
         if (ix.sim == 0) score_rows_fixed<0, N, U, true, STREAM>(ix, q_lds, todo, m, todo_score, qnorm2, scale, lane);
         else if (ix.sim == 1) score_rows_fixed<1, N, U, true, STREAM>(ix, q_lds, todo, m, todo_score, qnorm2, scale, lane);
         else score_rows_fixed<2, N, U, true, STREAM>(ix, q_lds, todo, m, todo_score, qnorm2, scale, lane);

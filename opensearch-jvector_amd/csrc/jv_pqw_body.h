@@ -1411,7 +1411,9 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
         if (take) todo[slot] = node;
         pqw_wave_sync();
         if (m > 0) {
-            score_rows<NCHT, 1, true>(ix, q_lds, todo, m, todo_score, qnorm2, 1.0f, lane);  // (rows in flight sized for 128 VGPRs)
+            // (rows in flight sized for 128 VGPRs; the two-wave LDS-table instances — the latency variant, the query server: 256 registers —
+            //  keep a third group of four 768-float rows in flight)
+            score_rows<NCHT, 1, true, (NL == 16 && W == 2 && NCHT == 12 && !FILT) ? 1 : 0>(ix, q_lds, todo, m, todo_score, qnorm2, 1.0f, lane);
             pqw_wave_sync();
         }
         if (i < nres) fin[i] = take ? make_key(todo_score[slot], node) : KEY_MIN;
