@@ -293,6 +293,8 @@ int jv_index_get_info(const jv_index* index, jv_index_info* out);
 /* Diagnostics: launches per kernel family since the handle was created — "launches_pqw" (several-waves-per-query pool
  * kernel), "launches_pqp" (one-wave pool kernel), "launches_pqf" (round-1 fused-PQ kernel), "launches_lds" (generic LDS
  * kernel).  Lets a test or an operator see which rung served a workload.  JV_EINVAL for unknown names.
+ * "retry_rungs_skipped": redo launches that host-pointer batch calls left out because their workgroups would not have fitted beside a
+ * live query-server grid (the flagged rows of such a call take the HBM-scratch rung instead).
  * Measurement: with option "time_search_kernel" = 1 the library records HIP events around the first (main) search launch of every
  * batch call on the stream it launches on; "search_kernel_ns" / "search_kernel_timed" are their sum and number (reading them waits for
  * the timed launches still in flight).  bench.py's roofline divides by that duration. */

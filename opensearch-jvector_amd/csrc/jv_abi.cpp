@@ -372,6 +372,7 @@ struct jv_index {
     // launches per kernel family since creation (jv_index_get_counter): which rung served a call is observable
     std::atomic<int64_t> launches[8] = {};
     std::atomic<int64_t> search_kernel_ns{0}, search_kernel_timed{0};  // (option time_search_kernel)
+    std::atomic<int64_t> retry_rungs_skipped{0};  // redo launches a host-pointer batch call left out beside a live query-server grid (its flagged rows take the HBM-scratch rung)
     struct JvQueryServer* server = nullptr;  // device-resident query server (created by the first eligible one-query call)
     struct JvQueryServer* server_f = nullptr;  // the same for one-query calls WITH a doc filter (one-wave filtered pool kernel)
     std::mutex server_mu;
@@ -764,7 +765,10 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
     // until the grid idles out" of round 3 (JV_BATCH_TRACE=1: the stream stopped in front of the escalation rung's launch, whose
     // workgroups had no row to redo but each needed ~100 KB of LDS).
     auto retry_rung_ok = [&](int lds_bytes) -> bool {
-        if (phase == 1 && d_accept == nullptr && servers_free_lds(ix->device) < lds_bytes) return false;
+        if (phase == 1 && d_accept == nullptr && servers_free_lds(ix->device) < lds_bytes) {
+            ix->retry_rungs_skipped++;  // (observable: jv_index_get_counter "retry_rungs_skipped")
+            return false;
+        }
         servers_yield_lds(ix->device, lds_bytes);
         return true;
     };
@@ -2020,6 +2024,7 @@ int jv_index_get_counter(const jv_index* index, const char* name, int64_t* out) 
         *out = name[14] == 'n' ? ix->search_kernel_ns.load() : ix->search_kernel_timed.load();
         return JV_OK;
     }
+    if (strcmp(name, "retry_rungs_skipped") == 0) { *out = index->retry_rungs_skipped.load(); return JV_OK; }
     if (strcmp(name, "exact_calls") == 0) { *out = index->xb.exact_calls.load(); return JV_OK; }
     if (strcmp(name, "exact_batches") == 0) { *out = index->xb.exact_batches.load(); return JV_OK; }
     return fail(JV_EINVAL, "unknown counter '%s'", name);
