@@ -135,13 +135,14 @@ int fail(int code, const char* fmt, ...) {
 //   filter_cache                         device-resident doc-filter bitsets kept per index (0 = off)
 //   serve / serve_wgs_per_cu / serve_idle_ms   device-resident query servers for one-query calls — one grid for unfiltered calls, one for calls with a doc filter (resident workgroups per CU, idle time before they leave)
 //   lazy_big_rung                        host-pointer calls enqueue the HBM-scratch rung only when a row came back flagged (it serialises batches otherwise)
+//   serve_spin_waiters                   one-query calls: up to this many concurrent callers poll (sched_yield) for their completion word behind the first nap; 0 = naps only
 //   visited_after                        several-waves batch launches without a visit limit copy their expansion logs to an arena and jv_visited_kernel counts visitedCount for the whole batch afterwards (0 = count inside the search kernel)
 //   visited_slots / visited_arena_units  its hash slots per workgroup / arena size in 16-byte units (tests: small values exercise the several-classes path and the in-kernel fall-back)
 //   time_search_kernel                   measurement: HIP events around the first search launch of every batch call (counters search_kernel_ns / search_kernel_timed)
 //   direct_completion                    combined one-query calls: rows land in pinned memory, every caller is woken by its own query's completion word
 //   lutr_min_queries                     launches with more queries keep the PQ look-up table in registers (-1 = 4 per CU)
 //   dbg_ptr                              diagnostic build only
-enum OptId { OPT_LDS_VISITED_SLOTS, OPT_LDS_CANDIDATES, OPT_FORCE_BIG, OPT_FORCE_GENERAL, OPT_NO_ESCALATION, OPT_DBG_PTR, OPT_NO_PQF, OPT_NO_PQP, OPT_NO_LUTR, OPT_LUTR_MIN_QUERIES, OPT_PQP_BLOCKS_PER_CU, OPT_NO_PQW, OPT_PQW_MIN_QUERIES, OPT_PQW_LAT_QUERIES, OPT_PQF_ONLY, OPT_SPILL_TABLES, OPT_SPILL_SLOTS, OPT_BIG_BLOCKS, OPT_BIG_CAND_CAP, OPT_BIG_BUDGET_MB, OPT_COMBINE, OPT_COMBINE_LEADERS, OPT_COMBINE_MAX_BATCH, OPT_MAX_CONTEXTS, OPT_FILTER_CACHE, OPT_DIRECT_COMPLETION, OPT_LAZY_BIG, OPT_SERVE, OPT_SERVE_WGS_PER_CU, OPT_SERVE_IDLE_MS, OPT_ASYNC_CONTEXTS, OPT_VISITED_AFTER, OPT_VISITED_SLOTS, OPT_VISITED_ARENA_UNITS, OPT_TIME_SEARCH_KERNEL, OPT_COUNT };
+enum OptId { OPT_LDS_VISITED_SLOTS, OPT_LDS_CANDIDATES, OPT_FORCE_BIG, OPT_FORCE_GENERAL, OPT_NO_ESCALATION, OPT_DBG_PTR, OPT_NO_PQF, OPT_NO_PQP, OPT_NO_LUTR, OPT_LUTR_MIN_QUERIES, OPT_PQP_BLOCKS_PER_CU, OPT_NO_PQW, OPT_PQW_MIN_QUERIES, OPT_PQW_LAT_QUERIES, OPT_PQF_ONLY, OPT_SPILL_TABLES, OPT_SPILL_SLOTS, OPT_BIG_BLOCKS, OPT_BIG_CAND_CAP, OPT_BIG_BUDGET_MB, OPT_COMBINE, OPT_COMBINE_LEADERS, OPT_COMBINE_MAX_BATCH, OPT_MAX_CONTEXTS, OPT_FILTER_CACHE, OPT_DIRECT_COMPLETION, OPT_LAZY_BIG, OPT_SERVE, OPT_SERVE_WGS_PER_CU, OPT_SERVE_IDLE_MS, OPT_ASYNC_CONTEXTS, OPT_VISITED_AFTER, OPT_VISITED_SLOTS, OPT_VISITED_ARENA_UNITS, OPT_TIME_SEARCH_KERNEL, OPT_SERVE_SPIN_WAITERS, OPT_COUNT };
 struct OptName { const char* name; int64_t def; };
 const OptName kOptNames[OPT_COUNT] = {
     {"lds_visited_slots", 0},
@@ -179,6 +180,7 @@ const OptName kOptNames[OPT_COUNT] = {
     {"visited_slots", 16384},      // hash slots of jv_visited_kernel's set (tests: a small set sends every log through several classes)
     {"visited_arena_units", 0},    // > 0: the log arena's size in 16-byte units (tests: a small arena sends logs back to the in-kernel count)
     {"time_search_kernel", 0},     // measurement: HIP events around the first (main) search launch of every batch call -> counters search_kernel_ns / search_kernel_timed
+    {"serve_spin_waiters", 4},     // one-query calls: up to this many concurrent callers poll for their completion word (sched_yield) instead of napping; 0 = naps only
 };
 struct Opts {
     std::atomic<int64_t> v[OPT_COUNT];
@@ -1257,6 +1259,8 @@ struct JvQueryServer {
     std::mutex mu;                  // launch / stop
     std::atomic<int> inflight{0};
     std::atomic<int> lat_us{3000};  // running estimate of one query's latency (how long a caller sleeps before it polls)
+    std::atomic<int> waiters{0};    // callers waiting for their completion word right now
+    int spin_waiters = 4;           // up to this many of them poll with sched_yield() behind their first nap (option serve_spin_waiters)
     std::atomic<int64_t> last_call_ms{0};  // when a one-query call last took a slot (servers_free_lds: "may be restarted any moment")
 };
 namespace {
@@ -1450,6 +1454,7 @@ Server* server_get(jv_index* ix, int kind, int need_cap, int* rc) {
     Server* sv = new Server();
     sv->ix = ix;
     sv->kind = kind;
+    sv->spin_waiters = (int)std::max<int64_t>(0, OPT(ix, OPT_SERVE_SPIN_WAITERS));
     auto bail = [&](const char* what, hipError_t e) -> Server* {
         *rc = fail(e == hipErrorOutOfMemory ? JV_ENOMEM : JV_EDEVICE, "query server: %s: %s", what, hipGetErrorString(e));
         ref = sv;

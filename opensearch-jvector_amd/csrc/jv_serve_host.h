@@ -73,17 +73,40 @@ inline int jvsh_wait_done(SV* sv, JvServeSlot* slot, uint32_t seq, int si, Alive
     if (rc != 0 && !answered) return rc;
     const int est = sv->lat_us.load(std::memory_order_relaxed);
     long nap_ns = (long)est * 600;  // 0.6 x
+    // A few callers at a time (a lone searcher thread is the reference's latency case): after the first nap the caller polls with
+    // sched_yield() instead of napping — a nanosleep of 60 us returns after ~110 (timer slack), which was ~0.06 ms of every
+    // one-query call's p50.  With many callers waiting that would only burn the cores the other callers need, so they keep napping;
+    // and a query that takes much longer than the estimate goes back to naps as well.
+    const int waiting = sv->waiters.fetch_add(1, std::memory_order_relaxed) + 1;
+    const bool spin = sv->spin_waiters > 0 && waiting <= sv->spin_waiters;
     for (int it = 0; !answered; it++) {
         if (__atomic_load_n(&slot->done, __ATOMIC_ACQUIRE) != 0) break;
         if (it < 3 && est < 200) {
             sched_yield();
             continue;
         }
+        if (spin && it > 0) {
+            struct timespec tn;
+            clock_gettime(CLOCK_MONOTONIC, &tn);
+            const int64_t waited_us = (int64_t)(tn.tv_sec - t0.tv_sec) * 1000000 + (tn.tv_nsec - t0.tv_nsec) / 1000;
+            if (waited_us < 2 * (int64_t)est + 200) {
+                for (int k = 0; k < 64 && __atomic_load_n(&slot->done, __ATOMIC_ACQUIRE) == 0; k++) sched_yield();
+                if ((it & 63) == 63 && (rc = ensure_alive(give_up)) != 0 && !answered) {
+                    sv->waiters.fetch_sub(1, std::memory_order_relaxed);
+                    return rc;
+                }
+                continue;
+            }
+        }
         struct timespec ts = {0, std::max<long>(20000, std::min<long>(nap_ns, 5000000))};
         nanosleep(&ts, nullptr);
         nap_ns = std::max<long>(20000, (long)est * 25);  // then every est / 40
-        if ((it & 7) == 7 && (rc = ensure_alive(give_up)) != 0 && !answered) return rc;
+        if ((it & 7) == 7 && (rc = ensure_alive(give_up)) != 0 && !answered) {
+            sv->waiters.fetch_sub(1, std::memory_order_relaxed);
+            return rc;
+        }
     }
+    sv->waiters.fetch_sub(1, std::memory_order_relaxed);
     struct timespec t1;
     clock_gettime(CLOCK_MONOTONIC, &t1);
     const int us = (int)std::min<int64_t>(1000000, (int64_t)(t1.tv_sec - t0.tv_sec) * 1000000 + (t1.tv_nsec - t0.tv_nsec) / 1000);

@@ -76,6 +76,8 @@ struct SimServer {
     std::atomic<uint32_t> reserve{0};
     std::atomic<uint32_t>* slot_free = nullptr;
     std::atomic<int> lat_us{200};
+    std::atomic<int> waiters{0};
+    int spin_waiters = 4;
     std::mutex mu;                // launch / stop
     std::vector<std::thread> grid;
     JvSearchArgs args{};

@@ -89,4 +89,13 @@ for rk in rks:
                     print(f"     {nme:40s} {100 * vv[i] / max(vv[:7].sum(), 1):5.1f} %   {vv[i] / steps:8.0f}")
                 print(f"     full-width rounds / step {vv[8] / steps:.2f}, packed ids / step {vv[9] / steps:.1f}, packed-walk instructions / step {vv[10] / steps:.1f}")
             print(f"     raw slots / expansion: " + " ".join(f"[{i}]={v[i] / ne:.2f}" if i in (8, 10, 11, 12) else f"[{i}]={v[i] / ne:.0f}" for i in range(16)))
+if os.environ.get("SINGLE", "0") == "1":   # one-query calls from one thread through the host API (the query server): p50 / p99
+    qh = q[:400].cpu().numpy()
+    for rk in rks:
+        for i in range(50):
+            ix.search(qh[i], 10, rk)
+        lat = []
+        for i in range(50, len(qh)):
+            t = time.perf_counter(); ix.search(qh[i], 10, rk); lat.append((time.perf_counter() - t) * 1e3)
+        print(f"one query per call, rk={rk}: p50 {np.percentile(lat, 50):.3f} ms  p99 {np.percentile(lat, 99):.3f} ms  mean {np.mean(lat):.3f} ms", flush=True)
 ix.close()
