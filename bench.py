@@ -842,9 +842,13 @@ def main():
             filtered_rows = f"unavailable: {e!r}"
 
     in_flight = None
-    if not args.profile_mode and world == 1 and eng.B <= 1024:
+    if not args.profile_mode and world == 1:
         try:
-            in_flight = [eng.timed_in_flight(rk, max(args.steps, 10), S) for S in (int(x) for x in os.environ.get("JV_BENCH_IN_FLIGHT", "1,2,3,4,8").split(","))]
+            # (large batches: two in flight show what the call's tail costs — the counting kernels and the launch that redoes the few
+            #  flagged rows of batch i run while batch i + 1 searches; `value` stays one batch at a time)
+            small = eng.B <= 1024
+            in_flight = [eng.timed_in_flight(rk, max(args.steps, 10) if small else 4, S)
+                         for S in (int(x) for x in os.environ.get("JV_BENCH_IN_FLIGHT", "1,2,3,4,8" if small else "1,2").split(","))]
         except (Exception, SystemExit) as e:  # pragma: no cover - a side report never costs the line its headline number
             in_flight = f"unavailable: {e!r}"
     exact_batch = None
