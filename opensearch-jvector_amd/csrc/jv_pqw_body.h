@@ -721,8 +721,21 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
                         if (CAPK == 5) lo = rank_level<128, 16>(pool, lo, cap, v);
                         if (CAPK == 4) lo = rank_level<1024, 8>(pool, lo, cap, v);
                         if (CAPK == 3) lo = rank_level<512, 8>(pool, lo, cap, v);
-                        if (CAPK == 2) lo = rank_level<512, 4>(pool, lo, cap, v);
-                        if (CAPK == 1) lo = rank_level<256, 4>(pool, lo, cap, v);
+                        // (classes 1, 2: the three pivots of the first level are last keys of pool chunks — lane 8k + 7 / 4k + 3 of `pv`,
+                        //  up to the stale low bits that never decide a comparison with a new key: three register reads instead of
+                        //  an LDS round trip)
+                        if (CAPK == 2 || CAPK == 1) {
+                            constexpr int CPB = CAPK == 2 ? 8 : 4;  // pool chunks per first-level block
+                            const int pvl = (int)(uint32_t)(pv & 0xFFFFFFFFll), pvh = (int)(pv >> 32);
+                            int c1 = 0;
+    #pragma unroll
+                            for (int k2 = 0; k2 < 3; k2++) {
+                                const int64_t pk = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(pvh, CPB * k2 + CPB - 1) << 32) |
+                                                             (uint64_t)(uint32_t)__builtin_amdgcn_readlane(pvl, CPB * k2 + CPB - 1));
+                                c1 += pk > v ? 1 : 0;
+                            }
+                            lo = c1 * CPB * 64;
+                        }
                         if (CAPK == 1) lo = rank_level<64, 4>(pool, lo, cap, v);
                         else if (CAPK == 4) lo = rank_level<64, 16>(pool, lo, cap, v);
                         else if (CAPK != 5) lo = rank_level<64, 8>(pool, lo, cap, v);
