@@ -15,6 +15,7 @@
 #include <cstring>
 #include <condition_variable>
 #include <deque>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -33,6 +34,7 @@
 extern "C" {
 // batched exact scorer (jv_kernels_xb.hip)
 hipError_t jvk_xb_mirror(const float* src, long long rows, int d, long long src_stride, int kp, uint16_t* dst, float* norm2, int scalar, hipStream_t s);
+hipError_t jvk_xb_mark_dead(const int32_t* ord2doc, long long n, float* norm2, hipStream_t s);
 hipError_t jvk_xb_build_list(const JvIndexDev* ix, const uint64_t* d_accept, long long accept_docs, int32_t* d_counts, int32_t* d_list, hipStream_t s);
 int jvk_xb_list_blocks(int n);
 hipError_t jvk_xb_tile(const JvXbTileArgs* a, int mode, hipStream_t s);
@@ -2030,6 +2032,17 @@ int jv_index_get_counter(const jv_index* index, const char* name, int64_t* out) 
         return JV_OK;
     }
     if (strcmp(name, "retry_rungs_skipped") == 0) { *out = index->retry_rungs_skipped.load(); return JV_OK; }
+    if (strcmp(name, "serve_alive") == 0) {
+        // how many of this index's resident grids are running right now (the grid itself clears the word when it leaves idle:
+        // jv_serve_claim.h) — lets a test DRIVE grid restarts instead of hoping for them
+        int64_t alive = 0;
+        jv_index* ix = const_cast<jv_index*>(index);
+        std::lock_guard<std::mutex> lk(ix->server_mu);
+        for (const JvQueryServer* sv : {ix->server, ix->server_f})
+            if (sv && sv->h_words && __atomic_load_n(&sv->h_words[JV_SH_ALIVE], __ATOMIC_ACQUIRE) != 0) alive++;
+        *out = alive;
+        return JV_OK;
+    }
     if (strcmp(name, "exact_calls") == 0) { *out = index->xb.exact_calls.load(); return JV_OK; }
     if (strcmp(name, "exact_batches") == 0) { *out = index->xb.exact_batches.load(); return JV_OK; }
     return fail(JV_EINVAL, "unknown counter '%s'", name);
@@ -2939,6 +2952,7 @@ static int xb_ensure_mirror(jv_index* ix) {
         return JV_OK;  // no room: not an error, the canonical scan answers
     }
     hipError_t e = jvk_xb_mirror(dv.vectors, dv.n, dv.d, dv.stride, kp, vb, vn, 0, x.stream);
+    if (e == hipSuccess) e = jvk_xb_mark_dead(dv.ord2doc, dv.n, vn, x.stream);   // (norm2 = -1: a deleted ordinal is no candidate of the pre-filter)
     if (e == hipSuccess) e = hipStreamSynchronize(x.stream);
     if (e != hipSuccess) {
         jv_free(vb);
@@ -2985,6 +2999,22 @@ static int xb_pass(jv_index* ix, JvXbTileArgs& ta, int mode) {
     }
     HIPCHK(jvk_xb_tile(&ta, mode, ix->xb.stream));
     return JV_OK;
+}
+
+// The matrix-core kernels take a whole CU's LDS (query-stationary: 163 840 B at kp = 768; LDS-tiled ~75 KB; re-score ~56 KB): beside
+// a live query-server grid (serve_wgs_per_cu x its pool on EVERY CU) their workgroups are never placed until the grid idles out —
+// under steady one-query traffic never (the default JVectorKnnFloatVectorQuery::exactSearch of the host mirror
+// comes through here while other searcher threads keep the grid alive).  So for the length of a batched exact call the device's
+// grids are asked to leave and kept from restarting: one-query callers that arrive meanwhile wait on the servers' launch
+// mutexes for the milliseconds the scan takes, then restart their grid.  nullptr when the device has no server (the usual case).
+static std::unique_ptr<ServerPause> xb_pause_servers(jv_index* ix) {
+    {
+        std::lock_guard<std::mutex> g(g_servers_mu);
+        bool any = false;
+        for (Server* sv : g_servers) any = any || sv->ix->device == ix->device;
+        if (!any) return nullptr;
+    }
+    return std::unique_ptr<ServerPause>(new ServerPause(ix->device));
 }
 
 // d_* = device pointers on the index's device; d_ords = nullptr: every ordinal is a candidate (C = n).  Enqueues on x.stream.
@@ -3211,6 +3241,7 @@ int jv_score_ordinals_batch(jv_index* index, const float* queries, int32_t nq, c
     int32_t* dc = (int32_t*)(ds + rows);
     HIPCHK(hipMemcpyAsync(x.d_queries, queries, (size_t)nq * d * 4, hipMemcpyHostToDevice, x.stream));
     int64_t info[4] = {0, 0, 0, 0};
+    std::unique_ptr<ServerPause> pause = xb_pause_servers(index);   // (until the results are on the host)
     if ((rc = xb_run(index, x.d_queries, nq, topK, d_ords, C, p->flags, dn, dd, ds, dc, out_info ? info : nullptr)) != JV_OK) {
         hipStreamSynchronize(x.stream);
         return rc;
@@ -3250,13 +3281,16 @@ int jv_score_ordinals_batch_device(jv_index* index, const float* d_queries, int3
     const int32_t* d_ords = nullptr;
     int C = 0, slot = -1;
     if ((rc = xb_candidates(index, p, true, &d_ords, &C, &slot)) != JV_OK) return rc;
+    std::unique_ptr<ServerPause> pause = xb_pause_servers(index);
     if ((rc = xb_run(index, d_queries, nq, p->topK, d_ords, C, p->flags, d_out_nodes, d_out_docs, d_out_scores, d_out_count, out_info)) != JV_OK) {
         hipStreamSynchronize(x.stream);
         return rc;
     }
     HIPCHK(hipEventRecord(ev, x.stream));
     HIPCHK(hipStreamWaitEvent(caller, ev, 0));
-    if (!hip_stream) HIPCHK(hipStreamSynchronize(x.stream));
+    // (beside query servers the call is synchronous: a grid restarted between two of the enqueued passes would hold the LDS the
+    //  later pass needs until it idles out)
+    if (!hip_stream || pause) HIPCHK(hipStreamSynchronize(x.stream));
     return JV_OK;
 }
 
@@ -3313,11 +3347,14 @@ int jv_exact_search(jv_index* index, const float* query, const jv_exact_batch_pa
         x.cleader = true;
     }
     // ---- leader: every queued call with this filter and topK, this one included ----
+    // Under the lock candidates are only FOUND (key, length, topK); the bits decide, and they are compared after the lock is
+    // dropped (a 10M-doc filter is 1.25 MB: round 5 compared it for every queued caller while every arrival waited on x.cmu).
+    // A call whose bits differ goes back to the head of the queue.  Nothing in the leader section may leave the lead taken: an
+    // exception (std::bad_alloc from the staging vectors) becomes JV_ENOMEM and the hand-over below still runs.
     std::vector<XbPending*> mine{&me};
     for (auto it = x.cqueue.begin(); it != x.cqueue.end() && mine.size() < XB_ROUND_QUERIES;) {
         XbPending* o = *it;
-        if (o->topK == me.topK && o->key == me.key && o->ndocs == me.ndocs &&
-            (o->words == me.words || memcmp(o->words, me.words, nwords * 8) == 0)) {   // (the key only FINDS candidates: the bits decide)
+        if (o->topK == me.topK && o->key == me.key && o->ndocs == me.ndocs) {
             mine.push_back(o);
             it = x.cqueue.erase(it);
         } else {
@@ -3325,29 +3362,49 @@ int jv_exact_search(jv_index* index, const float* query, const jv_exact_batch_pa
         }
     }
     lk.unlock();
+    std::vector<XbPending*> back;
+    for (size_t i = 1; i < mine.size();) {
+        XbPending* o = mine[i];
+        if (o->words != me.words && memcmp(o->words, me.words, nwords * 8) != 0) {
+            back.push_back(o);
+            mine.erase(mine.begin() + (long)i);
+        } else {
+            i++;
+        }
+    }
+    if (!back.empty()) {
+        lk.lock();
+        x.cqueue.insert(x.cqueue.begin(), back.begin(), back.end());
+        lk.unlock();
+    }
     const int nq = (int)mine.size(), d = index->dev.d, k = me.topK;
     int brc = JV_OK;
     std::string berr;
-    if (nq == 1) {
-        brc = jv_score_ordinals_batch(index, query, 1, p, out_nodes, out_docs, out_scores, out_count, nullptr);
-        if (brc != JV_OK) berr = g_last_error;
-    } else {
-        std::vector<float> q((size_t)nq * d);
-        std::vector<int32_t> nodes((size_t)nq * k), docs((size_t)nq * k), count((size_t)nq);
-        std::vector<float> scores((size_t)nq * k);
-        for (int i = 0; i < nq; i++) memcpy(q.data() + (size_t)i * d, mine[(size_t)i]->query, (size_t)d * sizeof(float));
-        jv_exact_batch_params bp = *p;
-        bp.accept_key = me.key;
-        brc = jv_score_ordinals_batch(index, q.data(), nq, &bp, nodes.data(), docs.data(), scores.data(), count.data(), nullptr);
-        if (brc != JV_OK) berr = g_last_error;
-        else
-            for (int i = 0; i < nq; i++) {
-                XbPending* o = mine[(size_t)i];
-                if (o->out_nodes) memcpy(o->out_nodes, nodes.data() + (size_t)i * k, (size_t)k * 4);
-                if (o->out_docs) memcpy(o->out_docs, docs.data() + (size_t)i * k, (size_t)k * 4);
-                if (o->out_scores) memcpy(o->out_scores, scores.data() + (size_t)i * k, (size_t)k * 4);
-                if (o->out_count) *o->out_count = count[(size_t)i];
-            }
+    try {
+        if (nq == 1) {
+            brc = jv_score_ordinals_batch(index, query, 1, p, out_nodes, out_docs, out_scores, out_count, nullptr);
+            if (brc != JV_OK) berr = g_last_error;
+        } else {
+            std::vector<float> q((size_t)nq * d);
+            std::vector<int32_t> nodes((size_t)nq * k), docs((size_t)nq * k), count((size_t)nq);
+            std::vector<float> scores((size_t)nq * k);
+            for (int i = 0; i < nq; i++) memcpy(q.data() + (size_t)i * d, mine[(size_t)i]->query, (size_t)d * sizeof(float));
+            jv_exact_batch_params bp = *p;
+            bp.accept_key = me.key;
+            brc = jv_score_ordinals_batch(index, q.data(), nq, &bp, nodes.data(), docs.data(), scores.data(), count.data(), nullptr);
+            if (brc != JV_OK) berr = g_last_error;
+            else
+                for (int i = 0; i < nq; i++) {
+                    XbPending* o = mine[(size_t)i];
+                    if (o->out_nodes) memcpy(o->out_nodes, nodes.data() + (size_t)i * k, (size_t)k * 4);
+                    if (o->out_docs) memcpy(o->out_docs, docs.data() + (size_t)i * k, (size_t)k * 4);
+                    if (o->out_scores) memcpy(o->out_scores, scores.data() + (size_t)i * k, (size_t)k * 4);
+                    if (o->out_count) *o->out_count = count[(size_t)i];
+                }
+        }
+    } catch (const std::exception& e) {
+        brc = JV_ENOMEM;
+        berr = std::string("jv_exact_search: ") + e.what();
     }
     x.exact_batches++;
     lk.lock();
@@ -3421,6 +3478,7 @@ int jv_xb_debug_bounds(jv_index* index, const float* queries, int32_t nq, const 
     ta.sample = x.d_sample;
     ta.sample_ld = count;
     if (out_kappa) *out_kappa = ta.kappa;
+    std::unique_ptr<ServerPause> pause = xb_pause_servers(index);
     for (int mode = 0; mode <= 2; mode += 2) {
         float* dst = mode == 0 ? out_lower : out_upper;
         if (!dst) continue;

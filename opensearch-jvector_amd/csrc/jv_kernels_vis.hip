@@ -22,7 +22,11 @@ typedef int vis_i32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ void vis_publish(const JvVisArgs& a, const int qi, const int v, const int lane) {
     int32_t* st = a.out_stats + (size_t)qi * 4;
     bool early = false;
-    if (a.visit_limit > 0) early = v + __builtin_amdgcn_readfirstlane(st[2]) >= a.visit_limit;
+    // (a row the search kernel left flagged for a later rung — e.g. why = 6, the rerankFloor tie, which returns after its log was
+    //  copied and before its stats row is written — has no valid st[2]: the limit is the later rung's business, and its OVERFLOW flag
+    //  must not be replaced by EARLY with count 0.  ADVICE r5, low)
+    if (a.visit_limit > 0 && ((uint32_t)__builtin_amdgcn_readfirstlane(a.out_flags[qi]) & JV_FLAG_OVERFLOW) == 0u)
+        early = v + __builtin_amdgcn_readfirstlane(st[2]) >= a.visit_limit;
     if (lane == 0) st[0] = v;
     if (early) {
         if (lane == 0) {

@@ -95,6 +95,21 @@ extern "C" hipError_t jvk_xb_mirror(const float* src, long long rows, int d, lon
     return hipGetLastError();
 }
 
+// Deleted ordinals (ord2doc[ord] < 0: never returned, J/JVectorReader.java:157-163) carry norm2 = -1 in the index's mirror: the
+// pre-filter's epilogues read the norm anyway, so "is this candidate alive" costs them one compare and no load — a dead row is
+// then no candidate at all (lower bound -inf in the sample, never a survivor).  Round 5 let dead rows into the k-of-S sample:
+// the bar could sit above the k-th best LIVE candidate and true neighbours were dropped.
+__global__ __launch_bounds__(256) void jvx_mark_dead_kernel(const int32_t* __restrict__ ord2doc, long long n, float* __restrict__ norm2) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        if (ord2doc[i] < 0) norm2[i] = -1.0f;
+}
+extern "C" hipError_t jvk_xb_mark_dead(const int32_t* ord2doc, long long n, float* norm2, hipStream_t s) {
+    if (!ord2doc || n <= 0) return hipSuccess;
+    const long long want = (n + 255) / 256;
+    jvx_mark_dead_kernel<<<(int)(want < 16384 ? want : 16384), 256, 0, s>>>(ord2doc, n, norm2);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------
 // doc filter -> ascending ordinal list (the reference's acceptOrds lambda, J/JVectorReader.java:157-163, evaluated once for
 // the whole batch): per-block counts, one-workgroup scan, scatter.
@@ -316,9 +331,10 @@ __global__ __launch_bounds__(256, 2) void jvx_tile_kernel(const JvXbTileArgs a) 
         long long idx = (cin ? ci : a.rows - 1) * a.cstride;
         if (idx >= a.C) idx = a.C - 1;
         int ord = a.ords ? a.ords[idx] : (int)idx;
-        const bool cval = cin && ord >= 0 && ord < a.n;
+        bool cval = cin && ord >= 0 && ord < a.n;
         if (!cval) ord = 0;
         const float cn2 = a.vnorm2[ord], cn = sqrtf(cn2);
+        cval = cval && !(cn2 < 0.0f);   // (norm2 = -1: a deleted ordinal, jvx_mark_dead_kernel)
 #pragma unroll
         for (int n = 0; n < 2; n++) {
 #pragma unroll
@@ -572,7 +588,8 @@ __global__ __launch_bounds__(512) void jvx_qs_kernel(const JvXbTileArgs a) {
             const long long ci = (long long)t * 32 + r31;
             const bool cin = ci < a.rows;
             const float cn2 = s_cn2[nslot * 64 + r31];
-            const bool cval = cin && s_val[nslot * 64 + r31] != 0;   // (an invalid list entry: row 0 was staged in its place)
+            // (an invalid list entry: row 0 was staged in its place; norm2 = -1: a deleted ordinal, jvx_mark_dead_kernel)
+            const bool cval = cin && s_val[nslot * 64 + r31] != 0 && !(cn2 < 0.0f);
             if (MODE == 1) {
                 const float cn = sqrtf(cn2);
                 const float Qc = a.sim == 0 ? 0.5f * cn2 * (1.0f - (1.2e-5f * 1.000001f + 4e-7f * 2.01f)) * 0.999999f : 0.0f;

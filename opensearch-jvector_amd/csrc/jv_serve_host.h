@@ -12,7 +12,9 @@
 // the ticket stays published, the grid that claims it later skips it.
 //
 // SV is any struct with: unsigned char* ring; int slots (a power of two), slot_bytes; int32_t* h_words (JV_SH_*);
-// std::atomic<uint32_t> reserve; std::atomic<uint32_t>* slot_free; std::atomic<int> lat_us.
+// std::atomic<uint32_t> reserve; std::atomic<uint32_t>* slot_free; std::atomic<int> lat_us (running estimate of one query's
+// latency in microseconds); std::atomic<int> waiters (callers inside jvsh_wait_done right now); int spin_waiters (up to this many
+// of them poll with sched_yield() behind their first nap; 0 = naps only).
 #pragma once
 #include <algorithm>
 #include <atomic>

@@ -76,6 +76,12 @@ def test_roofline_arithmetic_of_the_bench_line():
     assert abs(fused / nq - (1377 * 32 * 36 + 1200 * 3072 + launches * 1024 * d / nq)) < 1e-6
     r = bench.roofline_object(1.382e12, 464.0, 489.0, 1.5e12, "kept", "jv_search_pqw_kernel", M, True)
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert abs(r["achieved"] - 1.382e12 / 0.464 / 1e9) < 0.1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
-    assert abs(r["frac_whole_call"] - 1.382e12 / 0.489 / 1e9 / 8000.0) < 1e-4 and r["frac_whole_call"] < r["frac"]
+    # the fraction is on the WHOLE call's time: the bytes are counted over every row, whichever launch finished it
+    assert abs(r["achieved"] - 1.382e12 / 0.489 / 1e9) < 0.1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert r["frac"] == r["frac_whole_call"]
     assert r["kernel_avg_ms"] == 464.0 and r["call_avg_ms"] == 489.0 and r["traffic"] == 1.5e12 and "reranked*4d" in r["formula"]
+    assert abs(r["first_launch"]["share_of_call"] - 464.0 / 489.0) < 1e-3
+    # a step whose rows mostly finish in a heavy second launch (round 5's mixtureB leg printed 1.04 on the first launch's time):
+    # 0.9 TB counted over all rows, a 100 ms first launch, a 900 ms call -> 1 000 GB/s = 0.125, never above 1
+    h = bench.roofline_object(0.9e12, 100.0, 900.0, None, None, "jv_search_pqw_kernel", M, True)
+    assert abs(h["frac"] - 0.125) < 1e-4 and h["frac"] <= 1.0 and abs(h["first_launch"]["share_of_call"] - 1 / 9) < 1e-3

@@ -357,3 +357,104 @@ def test_concurrent_one_query_exact_searches_are_combined(pkg, pyoracle):
     assert calls == 48 * 6 and batches < calls, (calls, batches)
     print(f"{calls} one-query exact searches answered in {batches} engine calls")
     gpu.close()
+
+
+@pytest.mark.parametrize("sim", [0, 1, 2])
+def test_half_the_ordinals_deleted_short_lists_with_the_pre_filter_forced(pkg, pyoracle, sim):
+    """the matrix-core pre-filter took every in-range ordinal for a candidate — deleted ones (ord2doc < 0,
+    never returned: J/JVectorReader.java:157-163) too.  With a list of 2048 ... 4096 entries the sample IS the list, so the bar
+    was the k-th best bound over live AND dead rows while the re-score dropped the dead ones: live true neighbours were lost and
+    count < k.  Half the ordinals are deleted here, and the dead ones are the BEST rows for every query (copies of the queries):
+    forced pre-filter, no pre-filter and the oracle's scan must agree, on explicit lists and on the identity path."""
+    b = pkg.binding
+    rng = np.random.default_rng(77 + sim)
+    n, d, nq = 9000, 96, 40
+    base = pkg.datagen.splitmix_uniform(300 + sim, n, d) - np.float32(0.5)
+    queries = pkg.datagen.splitmix_uniform(301 + sim, nq, d) - np.float32(0.5)
+    dead = rng.random(n) < 0.5
+    dead_idx = np.nonzero(dead)[0]
+    # every query has 30 deleted near-duplicates: the dead rows would fill the whole top of any sample that admits them
+    for i in range(nq):
+        rows = dead_idx[i * 30:(i + 1) * 30]
+        base[rows] = queries[i] + np.float32(1e-3) * rng.standard_normal((30, d)).astype(np.float32)
+    ord2doc = np.where(dead, -1, np.arange(n)).astype(np.int32)
+    ix = _index(b, base, sim, 1.0, ord2doc, n)
+    gpu = b.GpuIndex(ix)
+    orc = pyoracle.Oracle(b, ix)
+    for C in (2048, 3000, 4096):
+        lst = rng.choice(n, C, replace=False).astype(np.int32)
+        lst[:nq * 30] = dead_idx[:nq * 30]              # (the planted dead rows are on every list)
+        valid = lst[ord2doc[lst] >= 0]
+        for k in (10, 100):
+            forced = gpu.score_ordinals_batch(queries, k, ordinals=lst, flags=b.XB_FORCE_PREFILTER)
+            plain = gpu.score_ordinals_batch(queries, k, ordinals=lst, flags=b.XB_NO_PREFILTER)
+            assert forced[4][1] > 0 and plain[4][1] == 0
+            _check(plain, orc, queries, valid, ord2doc, k, f"no pre-filter C={C} k={k}")
+            _check(forced, orc, queries, valid, ord2doc, k, f"forced pre-filter C={C} k={k}")
+    live = np.nonzero(~dead)[0].astype(np.int32)
+    got = gpu.score_ordinals_batch(queries, 10, flags=b.XB_FORCE_PREFILTER)   # identity path: every ordinal, dead ones included
+    assert got[4][1] > 0
+    _check(got, orc, queries, live, ord2doc, 10, "identity path")
+    gpu.close()
+
+
+def test_exact_calls_next_to_one_query_traffic(pkg, pyoracle):
+    """the batched exact scorer's kernels take a whole CU's LDS, and a live query-server grid holds LDS on every
+    CU until it has been idle for serve_idle_ms — under steady one-query jv_search traffic it never is, so an exact call (the
+    host mirror's default exactSearch comes through jv_exact_search) waited without a bound while it held the scorer's lock.
+    Four searcher threads keep the grid busy (no pauses); two others issue exact searches and batched exact calls: every answer
+    is right and no exact call takes longer than a second (they take milliseconds; the old code never returned)."""
+    import threading, time
+    b, bl = pkg.binding, pkg.builder
+    rng = np.random.default_rng(5)
+    n, d = 20000, 64
+    base = pkg.datagen.splitmix_uniform(61, n, d)
+    q = pkg.datagen.splitmix_uniform(62, 256, d)
+    ix = bl.build_index_cpu(base, 0, R=32, L=60, pq_M=32)
+    gpu = b.GpuIndex(ix, flags=b.DESC_FUSED_ADC)
+    orc = pyoracle.Oracle(b, ix)
+    ident = np.arange(n, dtype=np.int32)
+    docs = np.nonzero(rng.random(n) < 0.3)[0].astype(np.int32)
+    words = b.accept_words(docs, n)
+    want = gpu.search_batch(q, 10, 120)
+    stop, bad, lat = threading.Event(), [], []
+
+    def searcher(t):
+        i = t
+        while not stop.is_set():
+            j = i % len(q)
+            i += 5
+            r = gpu.search(q[j], 10, 120)
+            if not np.array_equal(r.nodes[0], want.nodes[j]):
+                bad.append(("search", j))
+
+    def exact(t):
+        for it in range(40):
+            qi = (t * 40 + it) % len(q)
+            t0 = time.perf_counter()
+            if it % 2:
+                nodes, dcs, sc, cnt = gpu.exact_search(q[qi], 10, words, n)
+            else:
+                got = gpu.score_ordinals_batch(q[qi:qi + 1], 10, accept=words, accept_num_docs=n, flags=b.XB_FORCE_PREFILTER)
+                dcs, sc, cnt = got[1][0], got[2][0], int(got[3][0])
+            lat.append((time.perf_counter() - t0) * 1e3)
+            wn, wd, ws = _want(orc, q[qi], docs, ident, 10)
+            if cnt != len(wn) or not np.array_equal(dcs[:cnt], wd) or not np.array_equal(sc[:cnt].view(np.uint32), ws.view(np.uint32)):
+                bad.append(("exact", qi))
+
+    ss = [threading.Thread(target=searcher, args=(t,)) for t in range(4)]
+    [t.start() for t in ss]
+    time.sleep(0.2)
+    assert gpu.counter("serve_alive") >= 1, "the one-query traffic is not served by a resident grid: the fixture tests nothing"
+    es = [threading.Thread(target=exact, args=(t,)) for t in range(2)]
+    [t.start() for t in es]
+    [t.join(timeout=120) for t in es]
+    stuck = any(t.is_alive() for t in es)
+    stop.set()
+    [t.join(timeout=60) for t in ss]
+    assert not stuck and not any(t.is_alive() for t in ss), "a caller is stuck"
+    assert not bad, bad[:4]
+    assert len(lat) == 80 and max(lat) < 1000.0, f"exact calls beside a live grid: max {max(lat):.1f} ms"
+    assert gpu.counter("served_queries") > 100
+    print(f"exact calls beside one-query traffic: p50 {np.percentile(lat, 50):.2f} ms, max {max(lat):.2f} ms")
+    gpu.close()
