@@ -265,11 +265,14 @@ class Engine:
     """one built index + its device-resident search plumbing"""
 
     def __init__(self, torch, dist, binding, sharding, device, local_rank, world, backend, base, queries, sim, R, L, k,
-                 pq_M, row_offset, n_total, builder_kind, builder_mod, B, n_gt, fused):
+                 pq_M, row_offset, n_total, builder_kind, builder_mod, B, n_gt, fused, replicas=1, replica_rank=0):
         self.torch, self.dist, self.binding, self.sharding = torch, dist, binding, sharding
         self.device, self.local_rank, self.world, self.backend = device, local_rank, world, backend
         self.base, self.queries, self.sim, self.R, self.k, self.pq_M = base, queries, sim, R, k, pq_M
         self.row_offset, self.n_total, self.B, self.n_gt, self.fused = row_offset, n_total, B, n_gt, fused
+        # "replicas" (SURVEY 8(e): the right choice whenever the index fits one GPU): `world` is 1 for everything the engine does —
+        # whole index, no gather, no merge — and `replicas` ranks answer DIFFERENT batches of queries side by side
+        self.replicas, self.replica_rank = replicas, replica_rank
         n, d = base.shape
         self.n, self.d = n, d
         t0 = time.time()
@@ -390,6 +393,9 @@ class Engine:
         B = self.B if batch is None else min(batch, self.B)
         nq_pool = self.queries.shape[0]
         batches = [self.queries[i * B:(i + 1) * B] for i in range(nq_pool // B)]
+        if self.replicas > 1:   # every replica starts at another batch of the pool
+            r0 = self.replica_rank % len(batches)
+            batches = batches[r0:] + batches[:r0]
         for w in range(warmup):
             self.run_step(batches[w % len(batches)], rk)
         barrier()
@@ -422,7 +428,7 @@ class Engine:
                 bad += ((self.out_flags[:B] & JV_FLAG_FAILED) != 0).sum() + (self.out_flags[:B] < 0).sum()
         barrier()
         elapsed = time.perf_counter() - t_start
-        if world > 1:
+        if world > 1 or self.replicas > 1:
             tmax = torch.tensor([elapsed], device=(self.device if self.backend == "nccl" else "cpu"), dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
@@ -434,7 +440,8 @@ class Engine:
         kernel_avg_ms = (kt1[0] - kt0[0]) / (kt1[1] - kt0[1]) * 1e-6 if kt1[1] - kt0[1] == steps else call_avg_ms
         big = self.check_flags(B)
         st = stat_sums.cpu().numpy().astype(np.float64)
-        return dict(elapsed=elapsed, qps=steps * B / elapsed, kernel_avg_ms=kernel_avg_ms, call_avg_ms=call_avg_ms, visited=st[0], reranked=st[1],
+        # (replicas: the job's queries = every replica's; the counters and kernel times below stay THIS rank's — the roofline is per GPU)
+        return dict(elapsed=elapsed, qps=steps * B * self.replicas / elapsed, kernel_avg_ms=kernel_avg_ms, call_avg_ms=call_avg_ms, visited=st[0], reranked=st[1],
                     expanded=st[2], total_queries=steps * B, big_path_last_step=big)
 
     def timed_in_flight(self, rk, steps, streams):
@@ -768,8 +775,18 @@ def main():
     # so that the MERGED recall@10 stays >= 0.95).  JV_BENCH_SCALING=weak keeps n docs per GPU instead.
     # (the label does not depend on N: c2/c3/c5 lines belong to the strong curve — the same corpus on 1, 2, 4, 8 GPUs —,
     #  c4 lines to the weak one)
-    scaling = os.environ.get("JV_BENCH_SCALING", "weak" if wl.get("per_gpu") else "strong")
-    if world > 1 and scaling == "strong":
+    # JV_BENCH_SCALING=replicas: every rank holds the WHOLE corpus and answers its own batches of queries, no collective on the data
+    # path — what SURVEY 8(e) asks to be reported beside the shards for a corpus that fits one GPU (c2 / c3 / c5).  Work per GPU is
+    # fixed as N grows, so the line says "weak"; config.sharding names the mode.
+    scaling_mode = os.environ.get("JV_BENCH_SCALING", "weak" if wl.get("per_gpu") else "strong")
+    if scaling_mode not in ("strong", "weak", "replicas"):
+        raise SystemExit(f"bench: JV_BENCH_SCALING={scaling_mode!r} (strong | weak | replicas)")
+    replicas = world if (scaling_mode == "replicas" and world > 1) else 1
+    scaling = "weak" if scaling_mode == "replicas" else scaling_mode
+    shard_world = 1 if replicas > 1 else world   # ranks one query's answer is merged over
+    if replicas > 1:
+        n, row_offset, n_total = n_cfg, 0, n_cfg
+    elif world > 1 and scaling == "strong":
         lo_doc, hi_doc = sharding.shard_range(n_cfg, world, rank)
         n, row_offset, n_total = hi_doc - lo_doc, lo_doc, n_cfg
     else:
@@ -794,8 +811,8 @@ def main():
             queries = gen_rows(torch, nq_pool, d, 43, 0, cen, basis, 0.15, 0.01, wl["normalize"], device)
         torch.cuda.synchronize()
         log(f"rank {rank}: generated {n}x{d} base ({dist_name if pq_M else 'low-rank mixture'}) + {nq_pool} queries in {time.time() - t0:.1f}s")
-        eng = Engine(torch, dist, binding, sharding, device, local_rank, world, backend, base, queries, sim, R, L, k, pq_M,
-                     row_offset, n_total, args.builder, builder, B, n_gt, fused)
+        eng = Engine(torch, dist, binding, sharding, device, local_rank, shard_world, backend, base, queries, sim, R, L, k, pq_M,
+                     row_offset, n_total, args.builder, builder, B, n_gt, fused, replicas=replicas, replica_rank=rank)
         log(f"rank {rank}: built index ({args.builder}) in {eng.build_s:.1f}s, entry={eng.entry}")
         return eng
 
@@ -910,7 +927,10 @@ def main():
     recall_txt = "nan" if chosen_recall != chosen_recall else f"{chosen_recall:.4f}"
     metric = "queries/sec at recall@10>=0.95" if target_met in (True, None) else \
         f"queries/sec at recall@10={recall_txt} (target 0.95 NOT reached by any rerankK of the sweep)"
-    if world > 1:
+    if replicas > 1:
+        shard_txt = (f"replicas: each of the {world} GPUs holds the whole corpus and answers its own batches of {B} queries per step; "
+                     "no collective on the data path (the process group only carries the barrier and the max-over-ranks clock)")
+    elif world > 1:
         shard_txt = ("doc-id range, RCCL all-gather of per-shard top-k + GPU merge" if backend == "nccl" else
                      f"doc-id range, {backend} all-gather (host-staged debug backend, NOT RCCL) + GPU merge")
     else:
@@ -920,7 +940,7 @@ def main():
         "value": round(qps, 1),
         "unit": "queries/s",
         "n_gpus": world,
-        "rccl_ranks": (world if (world > 1 and backend == "nccl") else 0),
+        "rccl_ranks": (world if (world > 1 and backend == "nccl" and replicas == 1) else 0),
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -934,7 +954,7 @@ def main():
                         ("" if pq_M == data_M else f" [codec overridden: PQ-{pq_M} instead of the workload's PQ-{data_M}]"),
             "distribution": dist_name,
             "docs_per_gpu": n, "total_docs": n_total, "dim": d, "similarity": ["l2", "dot", "cosine"][sim],
-            "R": R, "ef_construction": L, "k": k, "rerankK": rk, "pq_M": pq_M, "queries_per_step": B,
+            "R": R, "ef_construction": L, "k": k, "rerankK": rk, "pq_M": pq_M, "queries_per_step": B * replicas,
             "sharding": shard_txt,
             "graph_builder": args.builder, "pq_layout": ("fused" if fused else ("plain" if pq_M else None)),
         },

@@ -44,6 +44,8 @@ hipError_t jvk_xb_kth(const float* sample, int ld, int S, int k, float* thr, int
 hipError_t jvk_xb_rescore(const JvIndexDev* ix, const JvXbRescoreArgs* a, int nq, hipStream_t s);
 hipError_t jvk_set_max_lds(int bytes);
 hipError_t jvk_build_fused(const uint8_t* codes, const int32_t* adj, uint8_t* fused, long long n, int R, int cs, hipStream_t s);
+hipError_t jvk_build_code_norms(const uint8_t* codes, const float* norm_lut, const int32_t* adj, float* node_norm, float* fused_norm,
+                                long long n, int R, int M, int cs, int lpn, hipStream_t s);
 hipError_t jvk_launch_search_lds(const JvIndexDev* ix, const JvSearchArgs* a, int pq, int pool, int tag, int lds_bytes, hipStream_t s);
 hipError_t jvk_launch_search_pqf(const JvIndexDev* ix, const JvSearchArgs* a, int lds_bytes, hipStream_t s);
 hipError_t jvk_launch_search_big(const JvIndexDev* ix, const JvSearchArgs* a, int pq, int blocks, int lds_bytes,
@@ -1294,9 +1296,18 @@ void server_stop_locked(Server* sv, const char* why = "pause") {  // sv->mu held
 
 // RAII: no query server runs on `device` while this object lives (hipFree / hipDeviceSynchronize would otherwise wait for
 // a grid that only leaves when it is idle).  Callers that arrive meanwhile wait on the servers' launch mutexes.
+// Re-entrant per thread: a batched exact call keeps the device's servers paused while it runs (xb_pause_servers) and grows its
+// buffers inside — jv_free -> free_with_servers_paused would take the same launch mutexes again on the same thread.
+static thread_local int t_pause_depth = 0, t_pause_device = -1;
 struct ServerPause {
     std::vector<Server*> held;
+    enum { NESTED, OUTER, PLAIN } mode = PLAIN;   // NESTED: this thread already holds the device's pause; OUTER: this object marks the thread
     explicit ServerPause(int device) {
+        if (t_pause_depth > 0 && t_pause_device == device) {
+            mode = NESTED;
+            t_pause_depth++;
+            return;
+        }
         std::lock_guard<std::mutex> g(g_servers_mu);
         for (Server* sv : g_servers)
             if (sv->ix->device == device) {
@@ -1304,10 +1315,22 @@ struct ServerPause {
                 server_stop_locked(sv);
                 held.push_back(sv);
             }
+        if (t_pause_depth == 0) {   // (a pause on ANOTHER device inside a pause stays PLAIN: locks only)
+            mode = OUTER;
+            t_pause_depth = 1;
+            t_pause_device = device;
+        }
     }
     ~ServerPause() {
+        if (mode == NESTED) {
+            t_pause_depth--;
+            return;
+        }
         for (Server* sv : held) sv->mu.unlock();
+        if (mode == OUTER) t_pause_depth = 0, t_pause_device = -1;
     }
+    ServerPause(const ServerPause&) = delete;
+    ServerPause& operator=(const ServerPause&) = delete;
 };
 
 void free_with_servers_paused(void* p, bool host) {
@@ -1316,8 +1339,10 @@ void free_with_servers_paused(void* p, bool host) {
     hipPointerAttribute_t attr;
     if (hipPointerGetAttributes(&attr, p) == hipSuccess && attr.device >= 0) dev = attr.device;
     else if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-    bool any;
-    {
+    bool any = false;
+    // (a thread that already holds the device's pause must not touch g_servers_mu: servers_yield_lds takes g_servers_mu and THEN a
+    //  server's launch mutex — a batch caller waiting there for the mutex this thread holds would never release the list lock)
+    if (!(t_pause_depth > 0 && t_pause_device == dev)) {
         std::lock_guard<std::mutex> g(g_servers_mu);
         any = !g_servers.empty();
     }
@@ -1955,6 +1980,15 @@ int jv_index_create(const jv_index_desc* desc, jv_index** out) {
             uint8_t* fused = nullptr;
             TRY(dev_alloc(ix, &fused, (size_t)n * R * D.pq_code_stride));
             TRYHIP(jvk_build_fused(D.pq_codes, D.adj, fused, (long long)n, R, D.pq_code_stride, nullptr));
+            if (D.sim == JV_SIM_COSINE && D.pq_norm_lut && D.pq_lanes <= 16) {
+                // cosine on the several-waves kernels: the code vectors' squared norms, per node and per adjacency slot (jv_device.h)
+                float *nn = nullptr, *fn = nullptr;
+                TRY(dev_alloc(ix, &nn, (size_t)n));
+                TRY(dev_alloc(ix, &fn, (size_t)n * R));
+                TRYHIP(jvk_build_code_norms(D.pq_codes, D.pq_norm_lut, D.adj, nn, fn, (long long)n, R, M, D.pq_code_stride, D.pq_lanes, nullptr));
+                D.pq_node_norm = nn;
+                D.pq_fused_norm = fn;
+            }
             TRYHIP(hipDeviceSynchronize());
             D.pq_fused = fused;
             ix->info.fused_adc = 1;

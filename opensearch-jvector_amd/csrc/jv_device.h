@@ -38,6 +38,11 @@ struct JvIndexDev {
     const uint8_t* pq_codes;    // [n][M]
     const float* pq_norm_lut;   // [M][256] |centroid|^2 (cosine) or nullptr
     const uint8_t* pq_fused;    // fused layout: [n][R][M] neighbours' codes next to the adjacency order, or nullptr
+    // cosine on the fused layout (round 6): |decoded code vector|^2 = the canonical sum over the norm table's M entries of a node's
+    // code row — a property of the NODE, not of the query, so it is summed once at index creation (same chunks, same pair tree:
+    // bit-equal to jvo_pq_raw over the norm table) and read by the pool wave next to the neighbour's ordinal
+    const float* pq_node_norm;  // [n] or nullptr
+    const float* pq_fused_norm; // [n][R]: pq_node_norm[adj[u][j]] (0 for -1) or nullptr
     // NVQ-inline vectors (exact scores against the dequantised record; `vectors` may be nullptr then)
     int32_t nvq_M;
     int32_t nvq_stride;         // bytes per row = roundup(d, 4)

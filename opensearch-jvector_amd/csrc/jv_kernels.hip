@@ -1622,6 +1622,47 @@ extern "C" hipError_t jvk_build_fused(const uint8_t* codes, const int32_t* adj, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Cosine on the fused layout: |decoded code vector|^2 per node = the norm table's entries of its code row in the CANONICAL order
+// (16-subspace chunks summed left to right, slots beyond M contribute +0.0f; chunk sums combined by the adjacent-pair tree over
+// pq_lanes chunks: adc_chunk + lanes_tree_sum, oracle/jv_oracle.c jvo_pq_raw) — one thread per node — and the same value per
+// adjacency slot, next to the fused codes' order.
+// ---------------------------------------------------------------------------------------------
+__global__ void jv_node_norm_kernel(const uint8_t* codes, const float* norm_lut, float* out, long long n, int M, int cs, int lpn) {
+    for (long long node = (long long)blockIdx.x * blockDim.x + threadIdx.x; node < n; node += (long long)gridDim.x * blockDim.x) {
+        const uint8_t* code = codes + (size_t)node * cs;
+        float c[16];
+        for (int w = 0; w < 16; w++) {
+            float s = 0.0f;
+            if (w < lpn && w * 16 < M) {
+                for (int i = 0; i < 16; i++) {
+                    const int mi = w * 16 + i;
+                    const float t = mi < M ? norm_lut[mi * 256 + code[mi]] : 0.0f;
+                    s = s + t;
+                }
+            }
+            c[w] = s;
+        }
+        for (int span = 1; span < lpn; span <<= 1)
+            for (int w = 0; w + span < 16; w += 2 * span) c[w] = c[w] + c[w + span];
+        out[node] = c[0];
+    }
+}
+__global__ void jv_fused_norm_kernel(const float* node_norm, const int32_t* adj, float* out, long long slots) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (long long)gridDim.x * blockDim.x) {
+        const int nb = adj[i];
+        out[i] = nb >= 0 ? node_norm[nb] : 0.0f;
+    }
+}
+extern "C" hipError_t jvk_build_code_norms(const uint8_t* codes, const float* norm_lut, const int32_t* adj, float* node_norm, float* fused_norm,
+                                           long long n, int R, int M, int cs, int lpn, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    if (lpn > 16) return hipErrorInvalidValue;
+    jv_node_norm_kernel<<<2048, 256, 0, stream>>>(codes, norm_lut, node_norm, n, M, cs, lpn);
+    jv_fused_norm_kernel<<<4096, 256, 0, stream>>>(node_norm, adj, fused_norm, n * R);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // launch wrappers (called from jv_abi.cpp)
 // ---------------------------------------------------------------------------------------------
 // kernel tables: [pq][pool][nch slot]; nch slots: 0 -> any d (runtime chunk loop), 1 -> d = 128,

@@ -14,6 +14,7 @@ static const pqs_kernel_t g_pqs_kernels[2][3][4] = {
 
 static int pqs_nch_slot(const JvIndexDev* ix) {
     if (ix->nvq_M > 0) return 0;
+    if (ix->sim == 2) return 0;   // (cosine lives in the "any d" instances: jv_pqw_body.h COSI)
     if (ix->stride != ix->nch * 64) return 0;
     return ix->nch == 2 ? 1 : ix->nch == 12 ? 2 : ix->nch == 24 ? 3 : 0;
 }

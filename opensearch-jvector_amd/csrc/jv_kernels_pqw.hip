@@ -25,6 +25,7 @@ static bool pqw_occ5_ok(const JvIndexDev* ix, int cap);
 
 static int pqw_nch_slot(const JvIndexDev* ix) {
     if (ix->nvq_M > 0) return 0;  // the NVQ decoder lives in the "any d" instances only (score_rows)
+    if (ix->sim == 2) return 0;   // ... and so does cosine (jv_pqw_body.h COSI)
     if (ix->stride != ix->nch * 64) return 0;
     return ix->nch == 2 ? 1 : ix->nch == 12 ? 2 : ix->nch == 24 ? 3 : 0;
 }
@@ -36,7 +37,7 @@ extern "C" hipError_t jvk_pqw12_set_max_lds(int bytes);
 extern "C" int jvk_pqw_lds_rows(const JvIndexDev* ix, int variant) { return ix->pq_M >= 128 ? 8 : (variant == 1 ? 16 : (variant == 2 ? 0 : 4)); }
 // shapes this kernel runs: one wave per 16-subspace chunk, one lane per stored neighbour, whole log groups per 64-entry chunk
 extern "C" int jvk_pqw_ok(const JvIndexDev* ix, int cap) {
-    if (!(ix->pq_M == 32 || ix->pq_M == 64 || ix->pq_M == 128 || ix->pq_M == 192) || ix->sim == 2 || !ix->pq_fused || ix->num_upper != 0) return 0;
+    if (!(ix->pq_M == 32 || ix->pq_M == 64 || ix->pq_M == 128 || ix->pq_M == 192) || (ix->sim == 2 && !ix->pq_fused_norm) || !ix->pq_fused || ix->num_upper != 0) return 0;
     if (ix->R < 1 || ix->R > JV_WAVE || 64 % ((JV_WAVE / ix->R) * 8) != 0) return 0;
     return cap <= 2048 && ix->n < (1 << 30) ? 1 : 0;
 }

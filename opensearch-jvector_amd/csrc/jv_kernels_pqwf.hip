@@ -22,6 +22,7 @@ extern "C" hipError_t jvk_pqw12f_set_max_lds(int bytes);
 
 static int pqwf_nch_slot(const JvIndexDev* ix) {
     if (ix->nvq_M > 0) return 0;  // the NVQ decoder lives in the "any d" instances only (score_rows)
+    if (ix->sim == 2) return 0;   // ... and so does cosine (jv_pqw_body.h COSI)
     if (ix->stride != ix->nch * 64) return 0;
     return ix->nch == 2 ? 1 : ix->nch == 12 ? 2 : ix->nch == 24 ? 3 : 0;
 }
@@ -29,13 +30,13 @@ static int pqwf_capk(int cap) { return cap <= 1024 ? 1 : cap <= 2048 ? 2 : cap <
 extern "C" int jvk_pqwf_max_entries(const JvIndexDev* ix) { return ix->pq_M >= 128 ? 4096 : 16384; }
 // shapes this kernel runs (jvk_pqw_ok's, with the filtered key's 29 ordinal bits)
 extern "C" int jvk_pqwf_ok(const JvIndexDev* ix, int cap) {
-    if (!(ix->pq_M == 32 || ix->pq_M == 64 || ix->pq_M == 128 || ix->pq_M == 192) || ix->sim == 2 || !ix->pq_fused || ix->num_upper != 0) return 0;
+    if (!(ix->pq_M == 32 || ix->pq_M == 64 || ix->pq_M == 128 || ix->pq_M == 192) || (ix->sim == 2 && !ix->pq_fused_norm) || !ix->pq_fused || ix->num_upper != 0) return 0;
     if (ix->R < 1 || ix->R > JV_WAVE || 64 % ((JV_WAVE / ix->R) * 8) != 0) return 0;
     if (ix->pq_M >= 128 && ix->nvq_M > 0) return 0;  // (the default-codec instances carry no NVQ decoder)
     return cap <= jvk_pqwf_max_entries(ix) && ix->n < (1 << 29) ? 1 : 0;
 }
 static pqwf_kernel_t pqwf_pick(const JvIndexDev* ix, int cap) {
-    if (ix->pq_M >= 128) return (pqwf_kernel_t)jvk_pqw12f_kernel(ix->pq_M / 16, pqwf_capk(cap), ix->stride == ix->nch * 64 ? ix->nch : 0);
+    if (ix->pq_M >= 128) return (pqwf_kernel_t)jvk_pqw12f_kernel(ix->pq_M / 16, pqwf_capk(cap), (ix->stride == ix->nch * 64 && ix->sim != 2) ? ix->nch : 0);
     return g_pqwf_kernels[ix->pq_M == 64 ? 1 : 0][pqwf_capk(cap) - 1][pqwf_nch_slot(ix)];
 }
 

@@ -370,6 +370,17 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
             }
         }
     }
+    // Cosine (round 6) rides on the "any d" instances (NCHT = 0): the look-up table is the dot product's, the code vector's squared
+    // norm comes with the neighbour (JvIndexDev.pq_fused_norm: summed once per node at index creation, canonical order) and the
+    // query's |q|^2 is taken here, from the uncentred query (cosine never centres: no centroid), before the pool overwrites it.
+    // score = (1 + dot / sqrt(|q|^2 |c|^2)) / 2 — the expression of every other kernel and of the oracle (jvo_pq_score).
+    constexpr bool COSI = NCHT == 0;
+    const bool cosine = COSI && ix.sim == 2;
+    float qn2 = 0.0f;
+    if (COSI && cosine && wv == 0) {
+        qn2 = query_norm2(ix, qc_lds, lane);
+        qn2 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(qn2)));
+    }
     __syncthreads();  // every wave is done with qc_lds: the pool may overwrite it
 
     // this wave's chunk of one code row: 16 look-ups summed left to right (the canonical order inside a chunk)
@@ -444,7 +455,9 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
         if (wv > 0 && lane == 0) xchg[wv * 64] = s;
         __syncthreads();
         if (wv == 0) {
-            float sc = map_score(ix.sim == 0 ? 0 : 1, combine(s, 0));
+            float sc;
+            if (COSI && cosine) sc = map_score(2, combine(s, 0) / sqrtf(qn2 * ix.pq_node_norm[ep]));
+            else sc = map_score(ix.sim == 0 ? 0 : 1, combine(s, 0));
             sc = __shfl(sc, 0, JV_WAVE);
             const bool acc_ep = FILT ? accepts(ep) : true;
             if (lane == 0) pool[0] = pqp_key<FILT>(sc, ep, acc_ep);
@@ -471,6 +484,7 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
         return l;
     };
     int pf_nn = -1;
+    float pf_na = 0.0f;  // (cosine: the neighbours' code norms travel with their ordinals)
     u32x4 pf_cw = (u32x4){0, 0, 0, 0};
     if (wv == 0) PQW_STAMP(7)  // LUT build + entry point
     if (wv == 0) {
@@ -491,6 +505,7 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
         int pf_node0 = -1, pf_node1 = -1;  // nodes whose blocks were requested ahead into the lower / upper lanes
         float score = 0.0f;
         int nn = -1;
+        float na = 0.0f;   // cosine: |code vector of this lane's neighbour|^2
         bool accn = true;  // FILT: this lane's neighbour is accepted by the query's doc filter
         int64_t pv = KEY_MIN;  // lane t: last key of pool chunk t (low bits may be stale: they never decide a comparison with a new key)
         // ranks of BOTH halves' keys are taken in the pass iteration (the per-lane search costs the same for 32 or 64 keys); the
@@ -653,10 +668,12 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
                     if (hit) {
                         nn = pf_nn;
                         cw = pf_cw;
+                        if (COSI && cosine) na = pf_na;
                     } else {
                         const int node = hf ? wy : c;
                         nn = *(const int32_t*)((const unsigned char*)(ix.adj + (size_t)node * (size_t)R) + adj_off);
                         cw = JV_STREAM_LOAD((const u32x4*)(ix.pq_fused + (size_t)node * (size_t)R * (size_t)cs + cw_off));
+                        if (COSI && cosine) na = *(const float*)((const unsigned char*)(ix.pq_fused_norm + (size_t)node * (size_t)R) + adj_off);
                     }
                 }
                 if (hl >= R) nn = -1;
@@ -679,11 +696,13 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
                     const int node = hf ? y : x;
                     pf_nn = *(const int32_t*)((const unsigned char*)(ix.adj + (size_t)node * (size_t)R) + adj_off);
                     pf_cw = JV_STREAM_LOAD((const u32x4*)(ix.pq_fused + (size_t)node * (size_t)R * (size_t)cs + cw_off));
+                    if (COSI && cosine) pf_na = *(const float*)((const unsigned char*)(ix.pq_fused_norm + (size_t)node * (size_t)R) + adj_off);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 const float s0 = adc_chunk_regs(cw);
                 if (W > 1) pqw_barrier();  // B: the other waves' chunk sums are in xchg
-                score = map_score(ix.sim == 0 ? 0 : 1, combine(s0, lane));
+                if (COSI && cosine) score = map_score(2, combine(s0, lane) / sqrtf(qn2 * na));
+                else score = map_score(ix.sim == 0 ? 0 : 1, combine(s0, lane));
 #ifdef JV_STAMPS
                 asm volatile("" ::"v"(score));
 #endif
