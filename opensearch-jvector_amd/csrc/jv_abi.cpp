@@ -2939,12 +2939,22 @@ static bool xb_trace() {
     static const bool on = getenv("JV_XB_TRACE") != nullptr;
     return on;
 }
+static double xb_now_ms() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec / 1e6;
+}
+// diagnostics (JV_XB_TRACE=1): host-side points of a batched exact call with a clock (which step waits, and for how long)
+#define XB_POINT(what)                                                              \
+    do {                                                                            \
+        if (xb_trace()) fprintf(stderr, "[jvgpu xb %.2f ms] %s\n", xb_now_ms(), what); \
+    } while (0)
 // diagnostics (JV_XB_TRACE=1): drain the stream after every step and say which one failed
 #define XB_STEP(what)                                                                                        \
     do {                                                                                                     \
         if (xb_trace()) {                                                                                    \
             hipError_t e_ = hipStreamSynchronize(ix->xb.stream);                                             \
-            fprintf(stderr, "[jvgpu xb] %s: %s\n", what, hipGetErrorString(e_));                             \
+            fprintf(stderr, "[jvgpu xb %.2f ms] %s: %s\n", xb_now_ms(), what, hipGetErrorString(e_));        \
             if (e_ != hipSuccess) return fail(JV_EDEVICE, "%s: %s", what, hipGetErrorString(e_));            \
         }                                                                                                    \
     } while (0)
@@ -3186,7 +3196,9 @@ static int xb_candidates(jv_index* ix, const jv_exact_batch_params* p, bool devi
         if (device_ptrs) {
             d_acc = p->accept_doc_words;
         } else {
+            XB_POINT("candidates: filter_acquire");
             if ((rc = filter_acquire(ix, p->accept_doc_words, nwords, p->accept_key, x.stream, &d_acc, filter_slot)) != JV_OK) return rc;
+            XB_POINT("candidates: filter acquired");
             if (*filter_slot < 0) {
                 if ((rc = xb_grow(x, &x.d_accept, &x.accept_cap, nwords)) != JV_OK) return rc;
                 HIPCHK(hipMemcpyAsync(x.d_accept, p->accept_doc_words, nwords * 8, hipMemcpyHostToDevice, x.stream));
@@ -3200,9 +3212,12 @@ static int xb_candidates(jv_index* ix, const jv_exact_batch_params* p, bool devi
             HIPCHK(hipMalloc((void**)&x.d_info, 4 * sizeof(int64_t)));
             HIPCHK(hipHostMalloc((void**)&x.h_info, 4 * sizeof(int64_t), hipHostMallocDefault));
         }
+        XB_POINT("candidates: list kernels");
         HIPCHK(jvk_xb_build_list(&dv, d_acc, p->accept_num_docs, x.d_counts, x.d_list, x.stream));
         HIPCHK(hipMemcpyAsync(x.h_info + 2, x.d_counts + nb, 4, hipMemcpyDeviceToHost, x.stream));
+        XB_POINT("candidates: enqueued, waiting");
         HIPCHK(hipStreamSynchronize(x.stream));  // the grid of the tile kernel is sized by the filter's cardinality
+        XB_POINT("candidates: list ready");
         *C = (int)(*(int32_t*)(x.h_info + 2));
         *d_ords = x.d_list;
     } else if (p->ordinals) {
@@ -3235,6 +3250,7 @@ int jv_score_ordinals_batch(jv_index* index, const float* queries, int32_t nq, c
     if (nq == 0) return JV_OK;
     XbState& x = index->xb;
     std::lock_guard<std::mutex> lk(x.mu);
+    XB_POINT("host call: lock taken");
     if ((rc = xb_prepare(index)) != JV_OK) return rc;
     const int topK = p->topK, d = index->dev.d;
     if (index->dev.n == 0) {
@@ -3246,6 +3262,12 @@ int jv_score_ordinals_batch(jv_index* index, const float* queries, int32_t nq, c
         }
         return JV_OK;
     }
+    // From the first kernel of the call (the filter's ordinal list) to the results on the host no grid runs or STARTS on this device:
+    // measured (tools/exact_beside_server_probe.py, JV_XB_TRACE=1), work enqueued a moment after a grid's restart — the list kernels
+    // of the call after the one whose pause had just ended — waited 12 s, until the one-query traffic stopped and the grid idled out.
+    XB_POINT("host call: pausing the servers");
+    std::unique_ptr<ServerPause> pause = xb_pause_servers(index);
+    XB_POINT("host call: paused");
     const int32_t* d_ords = nullptr;
     int C = 0, slot = -1;
     rc = xb_candidates(index, p, false, &d_ords, &C, &slot);
@@ -3275,13 +3297,13 @@ int jv_score_ordinals_batch(jv_index* index, const float* queries, int32_t nq, c
     int32_t* dc = (int32_t*)(ds + rows);
     HIPCHK(hipMemcpyAsync(x.d_queries, queries, (size_t)nq * d * 4, hipMemcpyHostToDevice, x.stream));
     int64_t info[4] = {0, 0, 0, 0};
-    std::unique_ptr<ServerPause> pause = xb_pause_servers(index);   // (until the results are on the host)
     if ((rc = xb_run(index, x.d_queries, nq, topK, d_ords, C, p->flags, dn, dd, ds, dc, out_info ? info : nullptr)) != JV_OK) {
         hipStreamSynchronize(x.stream);
         return rc;
     }
     HIPCHK(hipMemcpyAsync(x.h_out, x.d_out, need, hipMemcpyDeviceToHost, x.stream));
     HIPCHK(hipStreamSynchronize(x.stream));
+    XB_POINT("host call: results on the host");
     if (out_nodes) memcpy(out_nodes, x.h_out, rows * 4);
     if (out_docs) memcpy(out_docs, x.h_out + rows * 4, rows * 4);
     if (out_scores) memcpy(out_scores, x.h_out + rows * 8, rows * 4);
@@ -3314,8 +3336,8 @@ int jv_score_ordinals_batch_device(jv_index* index, const float* d_queries, int3
     HIPCHK(hipStreamWaitEvent(x.stream, ev, 0));
     const int32_t* d_ords = nullptr;
     int C = 0, slot = -1;
+    std::unique_ptr<ServerPause> pause = xb_pause_servers(index);   // (before the call's first kernel: see jv_score_ordinals_batch)
     if ((rc = xb_candidates(index, p, true, &d_ords, &C, &slot)) != JV_OK) return rc;
-    std::unique_ptr<ServerPause> pause = xb_pause_servers(index);
     if ((rc = xb_run(index, d_queries, nq, p->topK, d_ords, C, p->flags, d_out_nodes, d_out_docs, d_out_scores, d_out_count, out_info)) != JV_OK) {
         hipStreamSynchronize(x.stream);
         return rc;

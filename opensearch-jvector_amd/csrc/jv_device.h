@@ -141,7 +141,7 @@ struct JvVisArgs {
 // query-server words and slot layout (shared by jv_abi.cpp and the SERVE kernel instances)
 enum { JV_SV_HEAD = 0, JV_SV_PUBLISHED = 1, JV_SV_LOCK = 2, JV_SV_EXITED = 3, JV_SV_LAST_CLAIM = 4, JV_SV_STOP_SEEN = 5 };
 enum { JV_SH_TAIL = 0, JV_SH_STOP = 1, JV_SH_ALIVE = 2 };
-#define JV_SERVE_TOPK_MAX 64
+#define JV_SERVE_TOPK_MAX 128  /* (round 6: 64 -> 128: the reference benchmark's own shape is K = 100, README.md:90-95) */
 struct JvServeSlot {           // header of one ring slot; the query (float[d], zero padded to 16 B) follows at JV_SERVE_QUERY_OFF
     int32_t topK, rk, visit_limit;
     float rerank_floor;
