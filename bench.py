@@ -159,7 +159,37 @@ def gen_rows_block(torch, n, d, seed, row_offset, zc, Bl, Bg, sigma, gscale, iso
     return out
 
 
-DISTS = ("rotated", "aligned", "mixtureB")
+DISTS = ("rotated", "aligned", "mixtureB", "uniformA")
+
+
+def _i64(v):
+    """a 64-bit constant as torch's signed int64 sees it"""
+    v &= (1 << 64) - 1
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def splitmix_uniform_torch(torch, seed, n, d, row_offset, device, normalize=False):
+    """SURVEY 8(d) distribution A, the reference's own data shape (i.i.d. uniform [0,1)^d: B/FormatBenchmarkQueryWithRandomVectors.java:77-86
+    draws java.util.Random floats) from the counter-based generator of opensearch_jvector_amd.datagen.splitmix_uniform — element (i, j)
+    depends only on (seed, (row_offset + i) d + j) — computed in HBM with int64 arithmetic (wrapping multiplies, logical shifts spelled
+    out): bit-equal to the numpy generator (tests/test_abi_and_datagen.py)."""
+    srl = lambda x, sh: (x >> sh) & ((1 << (64 - sh)) - 1)
+    out = torch.empty((n, d), dtype=torch.float32, device=device)
+    cols = torch.arange(d, device=device, dtype=torch.int64)[None, :]
+    add = _i64(seed * 0xD1342543DE82EF95)
+    chunk = 1 << 17
+    for s in range(0, n, chunk):
+        m = min(chunk, n - s)
+        idx = (torch.arange(s, s + m, device=device, dtype=torch.int64)[:, None] + row_offset) * d + cols
+        z = idx + add + _i64(0x9E3779B97F4A7C15)
+        z = (z ^ srl(z, 30)) * _i64(0xBF58476D1CE4E5B9)
+        z = (z ^ srl(z, 27)) * _i64(0x94D049BB133111EB)
+        z = z ^ srl(z, 31)
+        x = srl(z, 40).to(torch.float32) / float(1 << 24)
+        if normalize:
+            x = x / x.norm(dim=1, keepdim=True)
+        out[s:s + m] = x
+    return out
 
 
 def make_pq_data(torch, dist_name, n, nq, d, pq_M, row_offset, n_total, normalize, device):
@@ -169,8 +199,14 @@ def make_pq_data(torch, dist_name, n, nq, d, pq_M, row_offset, n_total, normaliz
        rotated  — the same model times a fixed random orthogonal matrix: same distances, same intrinsic dimension
                   (64 + 8), no alignment with the subspaces (DEFAULT);
        mixtureB — SURVEY 8(d) distribution B: 4 096-centre Gaussian mixture, centres ~ U[0,1)^d, sigma = 0.05
-                  (full-rank isotropic noise inside a cluster: not rankable by 32-byte codes, reported for honesty)."""
+                  (full-rank isotropic noise inside a cluster: not rankable by 32-byte codes, reported for honesty);
+       uniformA — SURVEY 8(d) distribution A, the reference benchmark's own data shape: i.i.d. uniform [0,1)^d, base seed 42,
+                  queries seed 43 (no structure at all: in 768 dimensions every point is about equally far from every other,
+                  so neither the graph's beam nor 32-byte codes can rank it — reported for honesty as well)."""
     centres = max(64, min(4096, n_total // 256))
+    if dist_name == "uniformA":
+        return (splitmix_uniform_torch(torch, 42, n, d, row_offset, device, normalize),
+                splitmix_uniform_torch(torch, 43, nq, d, 0, device, normalize))
     if dist_name == "mixtureB":
         g = torch.Generator(device=device)
         g.manual_seed(44)
@@ -910,6 +946,16 @@ def main():
                          for S in (int(x) for x in os.environ.get("JV_BENCH_IN_FLIGHT", "1,2,3,4,8" if small else "1,2").split(","))]
         except (Exception, SystemExit) as e:  # pragma: no cover - a side report never costs the line its headline number
             in_flight = f"unavailable: {e!r}"
+    # BASELINE.json configs[4] (C5: batch = 256 concurrent queries on the C3 index) inside the default line: one batch of 256 at a
+    # time, device-resident, the same timing protocol as `value` (a step = its slowest query: a latency figure in throughput clothes)
+    c5_row = None
+    if not args.profile_mode and world == 1 and args.workload == "c3" and B > 256:
+        try:
+            t5 = eng.timed(rk, 20, 3, barrier, batch=256)
+            c5_row = {"workload": "c5: the same index, 256 queries per step, one step at a time", "value": round(t5["qps"], 1), "unit": "queries/s",
+                      "ms_per_step": round(t5["elapsed"] / 20 * 1e3, 4), "queries_per_step": 256, "rerankK": rk, "steps": 20, "warmup": 3}
+        except (Exception, SystemExit) as e:  # pragma: no cover
+            c5_row = f"unavailable: {e!r}"
     exact_batch = None
     if not args.profile_mode and world == 1 and args.workload in ("c3", "c5") and os.environ.get("JV_BENCH_EXACT_BATCH", "1") == "1":
         try:
@@ -966,6 +1012,7 @@ def main():
         "single_query_api": caller_rows,
         "batches_in_flight": in_flight,
         "single_query_api_filtered": filtered_rows,
+        "c5_batch_256": c5_row,
         "exact_batch_shared_filter": exact_batch,
         "per_query": {"visited": round(t["visited"] / total_queries, 1), "expanded": round(t["expanded"] / total_queries, 1),
                       "reranked": round(t["reranked"] / total_queries, 1),

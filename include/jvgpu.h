@@ -295,9 +295,12 @@ int jv_index_get_info(const jv_index* index, jv_index_info* out);
  * kernel).  Lets a test or an operator see which rung served a workload.  JV_EINVAL for unknown names.
  * "retry_rungs_skipped": redo launches that host-pointer batch calls left out because their workgroups would not have fitted beside a
  * live query-server grid (the flagged rows of such a call take the HBM-scratch rung instead).
+ * "launches_serve" / "served_queries": starts of the device-resident query-server grid and one-query calls it answered;
+ * "serve_alive": how many of this handle's resident grids are running right now (0 once the grid has idled out after
+ * option "serve_idle_ms" without a query — a test can wait for that instead of sleeping).
  * Measurement: with option "time_search_kernel" = 1 the library records HIP events around the first (main) search launch of every
  * batch call on the stream it launches on; "search_kernel_ns" / "search_kernel_timed" are their sum and number (reading them waits for
- * the timed launches still in flight).  bench.py's roofline divides by that duration. */
+ * the timed launches still in flight).  bench.py reports that duration beside the whole call's (its roofline fraction is on the whole call). */
 int jv_index_get_counter(const jv_index* index, const char* name, int64_t* out);
 
 /* Tunables are PER INDEX: jv_index_set_option changes one handle; jv_set_option only changes the defaults that indexes

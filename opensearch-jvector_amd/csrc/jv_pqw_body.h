@@ -421,6 +421,25 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
         }
         return sum;
     };
+    // Round 6, the latency variant of two-wave queries (whole table in LDS, one to three queries per CU: instances NL = 16, W = 2, no
+    // filter — small launches and the query server): the helper wave PRE-SCORES the pair of blocks requested ahead while the pool wave
+    // ranks and inserts the current pair's keys.  The pair requested at a pass is the next pass's pair four times out of five
+    // (counter 11 of the stamped build); such a pass then finds its 64 raw sums waiting in LDS and runs without
+    // its own ADC, without the exchange and without barrier B — a quarter of the pool wave's chain.  Same arithmetic, same order:
+    // with the whole table in LDS any wave can sum any chunk (sixteen gathers left to right), and for W = 2 the pair tree is the
+    // one add chunk 0 + chunk 1, so the pre-scored value has the bits `combine` would produce.  Two buffers, alternating per pass:
+    // the helper writes the one the pool wave reads NEXT pass; barrier A of that pass orders the two.
+    constexpr bool PRE = NL == 16 && W == 2 && !FILT;
+    float* const psb = (float*)(smem + a.pqp_scratch_off + W * 256 + 256);  // [2][64] (plan_pqw_lds: variant 1, two waves)
+    auto adc_chunk_lds = [&](const float* rows, const u32x4 cw) -> float {
+        float tl[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) tl[i] = rows[i * 256 + ((cw[i >> 2] >> ((i & 3) * 8)) & 0xFFu)];
+        float sum = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; i++) sum = sum + tl[i];
+        return sum;
+    };
     // chunk sums of lane l's node -> raw distance / dot product: adjacent-pair tree over the W chunks (lanes_tree_sum)
     auto combine = [&](float s0, int l) -> float {
         if (W == 1) return s0;
@@ -519,6 +538,7 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
         unsigned long long um = 1ull;
         constexpr int UGS = CAPK >= 5 ? 2 : (CAPK >= 4 ? 1 : 0);  // log2(pool chunks per mask bit): 64 bits cover every capacity class
         unsigned long long ins_lo = 0ull;  // lanes (lower half) whose keys went into the pool in the pass iteration
+        int pass_no = 0;  // PRE: scoring passes so far (which of the two pre-score buffers belongs to this pass)
         while (true) {
             // (wave-uniform state, said so: the compiler's divergence analysis gives up on values that pass through LDS loads and
             //  the joins behind lane-level branches, and then runs this whole loop with vector compares and exec masks)
@@ -662,6 +682,8 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
                 PQW_STAMP_COUNT(8, 1)
                 PQW_STAMP(0)  // barrier A
                 const int wy = bn1 >= 0 ? bn1 : c;  // (no runner-up: the upper lanes score the same block again, unused)
+                // PRE: both blocks of this pass are the pair requested (and pre-scored by the helper wave) at the previous pass
+                const bool pre_hit = PRE && pair && pf_node0 == c && pf_node1 == wy;
                 u32x4 cw;
                 {
                     const bool hit = hf ? pf_node1 == wy : pf_node0 == c;
@@ -699,10 +721,17 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
                     if (COSI && cosine) pf_na = *(const float*)((const unsigned char*)(ix.pq_fused_norm + (size_t)node * (size_t)R) + adj_off);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                const float s0 = adc_chunk_regs(cw);
-                if (W > 1) pqw_barrier();  // B: the other waves' chunk sums are in xchg
-                if (COSI && cosine) score = map_score(2, combine(s0, lane) / sqrtf(qn2 * na));
-                else score = map_score(ix.sim == 0 ? 0 : 1, combine(s0, lane));
+                float raw;
+                if (PRE && pre_hit) {
+                    raw = psb[(pass_no & 1) * 64 + lane];  // (written by the helper wave before it reached barrier A of this pass)
+                } else {
+                    const float s0 = adc_chunk_regs(cw);
+                    if (W > 1) pqw_barrier();  // B: the other waves' chunk sums are in xchg
+                    raw = combine(s0, lane);
+                }
+                pass_no++;
+                if (COSI && cosine) score = map_score(2, raw / sqrtf(qn2 * na));
+                else score = map_score(ix.sim == 0 ? 0 : 1, raw);
 #ifdef JV_STAMPS
                 asm volatile("" ::"v"(score));
 #endif
@@ -1099,6 +1128,8 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
         const int jl = min(hl, R - 1);
         const uint32_t cw_off = (uint32_t)(jl * cs + wv * 16);
         int pf_node0 = -1, pf_node1 = -1;
+        int pass_no = 0;
+        const float* const lut0 = (const float*)(smem + a.pqw_lut_off);  // PRE: chunk 0's table rows (the pool wave's), all sixteen in LDS
         while (true) {
             pqw_barrier();  // A
             const int c = __builtin_amdgcn_readfirstlane(ctrl[PQW_C]);
@@ -1107,8 +1138,10 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
             const int bn3 = __builtin_amdgcn_readfirstlane(ctrl[PQW_C4]);
             if (c < 0) break;
             const int wy = bn1 >= 0 ? bn1 : c;
-            u32x4 cw;
-            {
+            // (the pool wave takes the same decision from the same values: a pre-scored pass has no exchange and no barrier B)
+            const bool pre_hit = PRE && pair && pf_node0 == c && pf_node1 == wy;
+            u32x4 cw = (u32x4){0, 0, 0, 0};
+            if (!(PRE && pre_hit)) {
                 const bool hit = hf ? pf_node1 == wy : pf_node0 == c;
                 if (hit) {
                     cw = pf_cw;
@@ -1119,15 +1152,26 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
             }
             pf_node0 = bn2;
             pf_node1 = bn3;
+            u32x4 pf_cw0 = (u32x4){0, 0, 0, 0};  // PRE: chunk 0's code bytes of the pair requested ahead
             {
                 const int x = bn2 >= 0 ? bn2 : c, y = bn3 >= 0 ? bn3 : x;
                 const int node = hf ? y : x;
                 pf_cw = JV_STREAM_LOAD((const u32x4*)(ix.pq_fused + (size_t)node * (size_t)R * (size_t)cs + cw_off));
+                if (PRE && pair) pf_cw0 = JV_STREAM_LOAD((const u32x4*)(ix.pq_fused + (size_t)node * (size_t)R * (size_t)cs + (uint32_t)(jl * cs)));
             }
             __builtin_amdgcn_sched_barrier(0);
-            const float s = adc_chunk_regs(cw);
-            xchg[wv * 64 + lane] = s;
-            pqw_barrier();  // B
+            if (!(PRE && pre_hit)) {
+                const float s = adc_chunk_regs(cw);
+                xchg[wv * 64 + lane] = s;
+                pqw_barrier();  // B
+            }
+            if (PRE && pair) {
+                // the pair requested ahead, both chunks, canonical order: (chunk 0) + (chunk 1) — what `combine` gives the pool wave
+                const float t0 = adc_chunk_lds(lut0, pf_cw0);
+                const float t1 = adc_chunk_lds(lutl, pf_cw);
+                psb[((pass_no + 1) & 1) * 64 + lane] = t0 + t1;
+            }
+            pass_no++;
         }
         }(opaque_lane());
     }

@@ -80,6 +80,21 @@ def test_splitmix_generator_is_counter_based(pkg):
     assert abs(a.mean() - 0.5) < 0.05
 
 
+def test_bench_uniform_distribution_equals_the_numpy_generator(pkg):
+    """bench.py's `uniformA` rows (SURVEY 8(d) distribution A, generated in HBM with torch int64 arithmetic) are bit-equal to
+    datagen.splitmix_uniform — the same counter-based generator the tests and the oracle's fixtures use"""
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    for seed, n, d, off in [(42, 300, 768, 0), (43, 17, 128, 123456789), (7, 5, 3, 2 ** 33)]:
+        got = bench.splitmix_uniform_torch(torch, seed, n, d, off, torch.device("cpu")).numpy()
+        want = pkg.datagen.splitmix_uniform(seed, n, d, off)
+        assert got.dtype == np.float32 and np.array_equal(got.view(np.uint32), want.view(np.uint32)), (seed, n, d, off)
+    assert "uniformA" in bench.DISTS
+
+
 def test_hardware_probes_cross_compile(tmp_path):
     """tools/lds_residency.hip and tools/hwq_probe.hip (the measurements behind the rung sizes and the query servers' stream
     priorities) must keep compiling for gfx950 — hipcc cross-compiles without a GPU."""

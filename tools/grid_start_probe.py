@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Host-pointer batch calls next to one-query traffic that makes the resident query-server grid start again and again
 (bursts separated by pauses longer than serve_idle_ms): the latency of every batch call, and how many grid starts it saw.
-env: TWO (0), BOPT_*, IDLE_MS (3), BURST (20), PAUSE_MS (10), SECS (6), NQ (64), RK (120), N (4000), D (64)"""
+env: SPIN (serve_spin_waiters), TWO (0), BOPT_*, IDLE_MS (3), BURST (20), PAUSE_MS (10), SECS (6), NQ (64), RK (120), N (4000), D (64)"""
 import os, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -13,6 +13,7 @@ E = lambda k, v: int(os.environ.get(k, v))
 n, d, rk, nq = E("N", 4000), E("D", 64), E("RK", 120), E("NQ", 64)
 base = dg.splitmix_uniform(31, n, d); q = dg.splitmix_uniform(32, 512, d)
 ix = bl.build_index_cpu(base, 0, R=32, L=60, pq_M=32)
+if "SPIN" in os.environ: b.set_option("serve_spin_waiters", E("SPIN", 4))   # (default of indexes created after this: 0 = naps only, round 5's 6214c03 made it 4)
 gpu = b.GpuIndex(ix, flags=b.DESC_FUSED_ADC)
 gpu.set_option("serve_idle_ms", E("IDLE_MS", 3))
 gb = gpu
