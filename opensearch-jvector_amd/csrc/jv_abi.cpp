@@ -146,7 +146,7 @@ int fail(int code, const char* fmt, ...) {
 //   direct_completion                    combined one-query calls: rows land in pinned memory, every caller is woken by its own query's completion word
 //   lutr_min_queries                     launches with more queries keep the PQ look-up table in registers (-1 = 4 per CU)
 //   dbg_ptr                              diagnostic build only
-enum OptId { OPT_LDS_VISITED_SLOTS, OPT_LDS_CANDIDATES, OPT_FORCE_BIG, OPT_FORCE_GENERAL, OPT_NO_ESCALATION, OPT_DBG_PTR, OPT_NO_PQF, OPT_NO_PQP, OPT_NO_LUTR, OPT_LUTR_MIN_QUERIES, OPT_PQP_BLOCKS_PER_CU, OPT_NO_PQW, OPT_PQW_MIN_QUERIES, OPT_PQW_LAT_QUERIES, OPT_PQF_ONLY, OPT_SPILL_TABLES, OPT_SPILL_SLOTS, OPT_BIG_BLOCKS, OPT_BIG_CAND_CAP, OPT_BIG_BUDGET_MB, OPT_COMBINE, OPT_COMBINE_LEADERS, OPT_COMBINE_MAX_BATCH, OPT_MAX_CONTEXTS, OPT_FILTER_CACHE, OPT_DIRECT_COMPLETION, OPT_LAZY_BIG, OPT_SERVE, OPT_SERVE_WGS_PER_CU, OPT_SERVE_IDLE_MS, OPT_ASYNC_CONTEXTS, OPT_VISITED_AFTER, OPT_VISITED_SLOTS, OPT_VISITED_ARENA_UNITS, OPT_TIME_SEARCH_KERNEL, OPT_SERVE_SPIN_WAITERS, OPT_COUNT };
+enum OptId { OPT_LDS_VISITED_SLOTS, OPT_LDS_CANDIDATES, OPT_FORCE_BIG, OPT_FORCE_GENERAL, OPT_NO_ESCALATION, OPT_DBG_PTR, OPT_NO_PQF, OPT_NO_PQP, OPT_NO_LUTR, OPT_LUTR_MIN_QUERIES, OPT_PQP_BLOCKS_PER_CU, OPT_NO_PQW, OPT_PQW_MIN_QUERIES, OPT_PQW_LAT_QUERIES, OPT_PQF_ONLY, OPT_SPILL_TABLES, OPT_SPILL_SLOTS, OPT_BIG_BLOCKS, OPT_BIG_CAND_CAP, OPT_BIG_BUDGET_MB, OPT_COMBINE, OPT_COMBINE_LEADERS, OPT_COMBINE_MAX_BATCH, OPT_MAX_CONTEXTS, OPT_FILTER_CACHE, OPT_DIRECT_COMPLETION, OPT_LAZY_BIG, OPT_SERVE, OPT_SERVE_WGS_PER_CU, OPT_SERVE_IDLE_MS, OPT_ASYNC_CONTEXTS, OPT_VISITED_AFTER, OPT_VISITED_SLOTS, OPT_VISITED_ARENA_UNITS, OPT_TIME_SEARCH_KERNEL, OPT_SERVE_SPIN_WAITERS, OPT_NO_PRESCORE, OPT_COUNT };
 struct OptName { const char* name; int64_t def; };
 const OptName kOptNames[OPT_COUNT] = {
     {"lds_visited_slots", 0},
@@ -185,6 +185,7 @@ const OptName kOptNames[OPT_COUNT] = {
     {"visited_arena_units", 0},    // > 0: the log arena's size in 16-byte units (tests: a small arena sends logs back to the in-kernel count)
     {"time_search_kernel", 0},     // measurement: HIP events around the first (main) search launch of every batch call -> counters search_kernel_ns / search_kernel_timed
     {"serve_spin_waiters", 4},     // one-query calls: up to this many concurrent callers poll for their completion word (sched_yield) instead of napping; 0 = naps only
+    {"no_prescore", 0},            // diagnostics (A/B): 1 = the latency variant's helper wave does not pre-score the pair requested ahead
 };
 struct Opts {
     std::atomic<int64_t> v[OPT_COUNT];
@@ -752,6 +753,7 @@ int enqueue_batch(jv_index* ix, Ctx* c, hipStream_t stream, const float* d_queri
     a.done = done;  // (completion words: honoured by the several-waves pool kernel; rows of other kernels are final at stream end)
     a.work_counter = c->work_counter;
     a.retry_only = 0;
+    a.no_prescore = OPT(ix, OPT_NO_PRESCORE) != 0 ? 1 : 0;
     a.spill = c->spill;
     a.spill_slots = c->spill_slots;
     a.spill_tables = c->spill_tables;
@@ -1496,6 +1498,7 @@ Server* server_get(jv_index* ix, int kind, int need_cap, int* rc) {
     a = JvSearchArgs{};
     a.topK = 1;
     a.nq = 1;
+    a.no_prescore = OPT(ix, OPT_NO_PRESCORE) != 0 ? 1 : 0;
     int per_cu;
     if (kind == 0) {
         sv->cap_max = need_cap <= 512 ? 512 : (need_cap <= 1024 ? 1024 : 2048);  // (the kernel's capacity classes: at most two rebuilds per index)

@@ -81,6 +81,7 @@ struct JvSearchArgs {
     float* lut_scratch;      // big path, PQ tables too large for LDS (the reference's default 192 subspaces at d >= 768): [blocks][pq_M][256] in HBM
     int32_t visit_limit;     // > 0: stop (flag EARLY) once visited + expanded reaches it (Lucene KnnCollector.visitLimit)
     int32_t retry_only;      // later launches: 1 = walk the flag array and redo pool/log overflows only; 2 = the same, last on-chip rung (filtered: never skips on the selectivity estimate)
+    int32_t no_prescore;     // diagnostics (option "no_prescore"): the latency variant's helper wave does not pre-score the pair requested ahead (jv_pqw_body.h PRE)
     int32_t* retry_counter;  // escalation launches: flag-chunk dequeue counter (zeroed per call, one per rung)
     // two-level visited set: pool of per-query spill tables in HBM (taken with spill_counter)
     uint32_t* spill;

@@ -683,7 +683,7 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
                 PQW_STAMP(0)  // barrier A
                 const int wy = bn1 >= 0 ? bn1 : c;  // (no runner-up: the upper lanes score the same block again, unused)
                 // PRE: both blocks of this pass are the pair requested (and pre-scored by the helper wave) at the previous pass
-                const bool pre_hit = PRE && pair && pf_node0 == c && pf_node1 == wy;
+                const bool pre_hit = PRE && pair && !a.no_prescore && pf_node0 == c && pf_node1 == wy;
                 u32x4 cw;
                 {
                     const bool hit = hf ? pf_node1 == wy : pf_node0 == c;
@@ -1139,7 +1139,7 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
             if (c < 0) break;
             const int wy = bn1 >= 0 ? bn1 : c;
             // (the pool wave takes the same decision from the same values: a pre-scored pass has no exchange and no barrier B)
-            const bool pre_hit = PRE && pair && pf_node0 == c && pf_node1 == wy;
+            const bool pre_hit = PRE && pair && !a.no_prescore && pf_node0 == c && pf_node1 == wy;
             u32x4 cw = (u32x4){0, 0, 0, 0};
             if (!(PRE && pre_hit)) {
                 const bool hit = hf ? pf_node1 == wy : pf_node0 == c;
@@ -1157,7 +1157,7 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
                 const int x = bn2 >= 0 ? bn2 : c, y = bn3 >= 0 ? bn3 : x;
                 const int node = hf ? y : x;
                 pf_cw = JV_STREAM_LOAD((const u32x4*)(ix.pq_fused + (size_t)node * (size_t)R * (size_t)cs + cw_off));
-                if (PRE && pair) pf_cw0 = JV_STREAM_LOAD((const u32x4*)(ix.pq_fused + (size_t)node * (size_t)R * (size_t)cs + (uint32_t)(jl * cs)));
+                if (PRE && pair && !a.no_prescore) pf_cw0 = JV_STREAM_LOAD((const u32x4*)(ix.pq_fused + (size_t)node * (size_t)R * (size_t)cs + (uint32_t)(jl * cs)));
             }
             __builtin_amdgcn_sched_barrier(0);
             if (!(PRE && pre_hit)) {
@@ -1165,7 +1165,7 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
                 xchg[wv * 64 + lane] = s;
                 pqw_barrier();  // B
             }
-            if (PRE && pair) {
+            if (PRE && pair && !a.no_prescore) {
                 // the pair requested ahead, both chunks, canonical order: (chunk 0) + (chunk 1) — what `combine` gives the pool wave
                 const float t0 = adc_chunk_lds(lut0, pf_cw0);
                 const float t1 = adc_chunk_lds(lutl, pf_cw);
