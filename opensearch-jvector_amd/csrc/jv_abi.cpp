@@ -630,8 +630,8 @@ int plan_pqw_lds(const jv_index* ix, JvSearchArgs& x, int variant, int lds_rows 
     x.pqp_scratch_off = front;
     x.pqp_lds_bytes = front + Wn * 256 + 64 + 128 + 64;  // (ctrl words, the diagnostic build's phase accumulators, the waves' visited counts)
     // (round 6, the latency variant of two-wave queries: the helper wave pre-scores the pair requested ahead into two 64-float
-    //  buffers behind the words above — jv_pqw_body.h PRE)
-    if (Wn == 2 && variant == 1 && lds_rows < 0) x.pqp_lds_bytes += 512;
+    //  buffers behind the words above — jv_pqw_body.h PRE; four-wave queries — PQ-64 — the same)
+    if ((Wn == 2 || Wn == 4) && variant == 1 && lds_rows < 0) x.pqp_lds_bytes += 512;
     return x.pqp_lds_bytes;
 }
 

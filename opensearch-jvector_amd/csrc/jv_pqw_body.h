@@ -429,7 +429,9 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
     // with the whole table in LDS any wave can sum any chunk (sixteen gathers left to right), and for W = 2 the pair tree is the
     // one add chunk 0 + chunk 1, so the pre-scored value has the bits `combine` would produce.  Two buffers, alternating per pass:
     // the helper writes the one the pool wave reads NEXT pass; barrier A of that pass orders the two.
-    constexpr bool PRE = NL == 16 && W == 2 && !FILT;
+    // (W = 4 — PQ-64, C4's shape — the same with wave 1 as the one pre-scorer: it sums all four chunks and combines them in the
+    //  pair tree ((0 + 1) + (2 + 3)) `combine` walks; waves 2 and 3 only skip their scoring on a pre-scored pass)
+    constexpr bool PRE = NL == 16 && (W == 2 || W == 4) && !FILT;
     float* const psb = (float*)(smem + a.pqp_scratch_off + W * 256 + 256);  // [2][64] (plan_pqw_lds: variant 1, two waves)
     auto adc_chunk_lds = [&](const float* rows, const u32x4 cw) -> float {
         float tl[16];
@@ -1152,12 +1154,16 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
             }
             pf_node0 = bn2;
             pf_node1 = bn3;
-            u32x4 pf_cw0 = (u32x4){0, 0, 0, 0};  // PRE: chunk 0's code bytes of the pair requested ahead
+            u32x4 pcw[PRE ? W : 1];  // PRE, wave 1: the other chunks' code bytes of the pair requested ahead (its own chunk: pf_cw)
             {
                 const int x = bn2 >= 0 ? bn2 : c, y = bn3 >= 0 ? bn3 : x;
                 const int node = hf ? y : x;
                 pf_cw = JV_STREAM_LOAD((const u32x4*)(ix.pq_fused + (size_t)node * (size_t)R * (size_t)cs + cw_off));
-                if (PRE && pair && !a.no_prescore) pf_cw0 = JV_STREAM_LOAD((const u32x4*)(ix.pq_fused + (size_t)node * (size_t)R * (size_t)cs + (uint32_t)(jl * cs)));
+                if constexpr (PRE) if (pair && !a.no_prescore && wv == 1) {
+#pragma unroll
+                    for (int w = 0; w < W; w++)
+                        if (w != 1) pcw[w] = JV_STREAM_LOAD((const u32x4*)(ix.pq_fused + (size_t)node * (size_t)R * (size_t)cs + (uint32_t)(jl * cs + w * 16)));
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             if (!(PRE && pre_hit)) {
@@ -1165,11 +1171,17 @@ __device__ __forceinline__ void search_one_pqw(const JvIndexDev& ix, const JvSea
                 xchg[wv * 64 + lane] = s;
                 pqw_barrier();  // B
             }
-            if (PRE && pair && !a.no_prescore) {
-                // the pair requested ahead, both chunks, canonical order: (chunk 0) + (chunk 1) — what `combine` gives the pool wave
-                const float t0 = adc_chunk_lds(lut0, pf_cw0);
-                const float t1 = adc_chunk_lds(lutl, pf_cw);
-                psb[((pass_no + 1) & 1) * 64 + lane] = t0 + t1;
+            if constexpr (PRE) if (pair && !a.no_prescore && wv == 1) {
+                // the pair requested ahead, every chunk, canonical order: chunk sums left to right, then the adjacent-pair tree —
+                // what `combine` gives the pool wave
+                float t[W];
+#pragma unroll
+                for (int w = 0; w < W; w++) t[w] = adc_chunk_lds(lut0 + w * 16 * 256, w == 1 ? pf_cw : pcw[w]);
+#pragma unroll
+                for (int span = 1; span < W; span <<= 1)
+#pragma unroll
+                    for (int w = 0; w < W; w += 2 * span) t[w] = t[w] + t[w + span];
+                psb[((pass_no + 1) & 1) * 64 + lane] = t[0];
             }
             pass_no++;
         }
