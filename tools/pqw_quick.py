@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Development check of the several-waves-per-query kernel (jv_kernels_pqw.hip) against the one-wave kernel on a
 C3-shaped index: identical ids / score bits / counters / flags, and the throughput of both.
-env: N (docs, default 2M), B (queries per launch), RKS (comma list), DIST, STAMPS=1 (diagnostic build + phase shares),
+env: SIM (0 L2 | 1 dot | 2 cosine), N (docs, default 2M), B (queries per launch), RKS (comma list), DIST, STAMPS=1 (diagnostic build + phase shares),
 JV_OPT_<name>=<int> per-index options applied to both runs, JV_LIB=<path> another build of libjvgpu.so."""
 import importlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -25,9 +25,10 @@ rks = [int(x) for x in os.environ.get("RKS", "160,1200").split(",")]
 dev = torch.device("cuda", 0)
 t0 = time.time()
 base, q = bench.make_pq_data(torch, os.environ.get("DIST", "rotated"), n, B, d, M, 0, n, False, dev)
-adj, entry = gb.build_graph_gpu(torch, base, 0, R=32, L=100, verbose=False)
-pq = gb.pq_train_encode_gpu(torch, base, M, 0)
-desc, keep = b.make_desc_device(n, d, 32, base.data_ptr(), adj.data_ptr(), entry, 0, pq_M=M, pq_K=pq["K"],
+SIM = int(os.environ.get("SIM", "0"))   # 0 L2, 1 dot product, 2 cosine (round 6: cosine runs on the several-waves kernels)
+adj, entry = gb.build_graph_gpu(torch, base, SIM, R=32, L=100, verbose=False)
+pq = gb.pq_train_encode_gpu(torch, base, M, SIM)
+desc, keep = b.make_desc_device(n, d, 32, base.data_ptr(), adj.data_ptr(), entry, SIM, pq_M=M, pq_K=pq["K"],
                                 pq_codebooks=pq["codebooks"], pq_centroid=pq["centroid"], pq_codes_ptr=pq["codes"].data_ptr(),
                                 borrow=True, extra_flags=b.DESC_FUSED_ADC)
 ix = b.GpuIndex(desc=desc, keepalive=keep, flags=b.DESC_BORROW)
