@@ -444,7 +444,9 @@ def test_exact_calls_next_to_one_query_traffic(pkg, pyoracle):
 
     ss = [threading.Thread(target=searcher, args=(t,)) for t in range(4)]
     [t.start() for t in ss]
-    time.sleep(0.2)
+    t_end = time.time() + 20.0   # (the first one-query call creates the server: ring, logs, launch — not a fixed number of milliseconds)
+    while gpu.counter("serve_alive") < 1 and time.time() < t_end:
+        time.sleep(0.01)
     assert gpu.counter("serve_alive") >= 1, "the one-query traffic is not served by a resident grid: the fixture tests nothing"
     es = [threading.Thread(target=exact, args=(t,)) for t in range(2)]
     [t.start() for t in es]
